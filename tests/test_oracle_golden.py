@@ -1,0 +1,127 @@
+"""Pin the oracle (oracle/pmce_oracle.py) against outputs of the reference itself (tests/golden/*.npz,
+made by tests/golden/make_golden.py from /root/reference).  CPU-only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import cached_state_dict
+from oracle import pmce_oracle as O
+from pmce_amd import assets, synth
+
+T = lambda x: torch.from_numpy(np.ascontiguousarray(x))
+
+
+def maxabs(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())
+
+
+@pytest.mark.parametrize("name", ["e2e_J17_C256_B2.npz", "e2e_J19_C256_B1.npz", "e2e_J17_C512_B1.npz"])
+def test_e2e_matches_reference(golden, name):
+    z = golden(name)
+    J, C, B = int(z["J"]), int(z["C"]), int(z["B"])
+    sd = cached_state_dict(J, C)
+    pose2d, img_feat = synth.make_inputs(B, J, int(z["input_seed"]))
+    assert float(pose2d.astype(np.float64).sum()) == float(z["pose2d_sum"])
+    assert float(img_feat.astype(np.float64).sum()) == float(z["img_feat_sum"])
+    with torch.no_grad():
+        mesh, pose, pose3d = O.pmce_forward(sd, T(pose2d), T(img_feat), z["vj_relation"])
+        pred = O.j_regress(mesh, assets.load_j_regressor("h36m"))
+    # tolerance: 1e-3 max-abs in metres (north_star); oracle vs reference is the same math on the same
+    # torch CPU kernels, so it lands ~1e-5 or better.
+    assert maxabs(mesh, z["cam_mesh"]) < 2e-5
+    assert maxabs(pose, z["cam_pose"]) < 2e-5
+    assert maxabs(pose3d, z["pose3d"]) < 5e-3          # millimetres, values ~1e3
+    assert maxabs(pred, z["pred_pose"]) < 2e-2         # millimetres (1000 x mesh)
+
+
+def test_vj_relation_and_template_bit_exact(golden):
+    z = golden("e2e_J17_C256_B2.npz")
+    v431, vj, src = assets.build_template(base_dir="/nonexistent")
+    assert src == "synthetic"
+    assert np.array_equal(vj, z["vj_relation"])                    # integer table: bit-exact
+    assert vj.min() >= 0 and vj.max() <= 16
+    assert maxabs(v431, z["init_vertices"]) < 1e-6
+    sd = cached_state_dict(17, 256)
+    pose3d = T(z["pose3d"])
+    g = O.vertex_init_gather(pose3d / 1000, vj)
+    assert np.array_equal(g.numpy(), z["vert0"])                    # gather: bit-exact copy
+
+
+def test_decoder_intermediates(golden):
+    z = golden("e2e_J17_C256_B2.npz")
+    sd = cached_state_dict(17, 256)
+    _, img_feat = synth.make_inputs(2, 17, int(z["input_seed"]))
+    with torch.no_grad():
+        j3, mesh, im = O.decoder_forward(sd, T(z["pose3d"]) / 1000, T(img_feat), z["vj_relation"],
+                                         return_intermediates=True)
+    assert maxabs(im["g"], z["g_mid"]) < 5e-6
+    for k in ("v1", "v2", "v3"):
+        assert maxabs(im[k], z[k]) < 2e-5, k
+    assert maxabs(mesh, z["cam_mesh"]) < 2e-5
+
+
+def test_modules(golden):
+    z = golden("modules_J17_C256.npz")
+    sd = cached_state_dict(17, 256)
+    u = synth.uniform_pm1
+    B = 1
+    g = T(u("mod.g", B * 2048, 11).reshape(B, 2048) * 0.8)
+    xv = T(u("mod.xv", B * 431 * 64, 11).reshape(B, 431, 64) * 1.5 + 0.1)
+    xj = T(u("mod.xj", B * 17 * 64, 11).reshape(B, 17, 64) * 1.5 - 0.2)
+    p = "pose_mesh_coevo.coevoblock3"
+    with torch.no_grad():
+        got = {
+            "adaln_v": O.ada_layer_norm(xv, g, sd, p + ".vertx_CA_FFN.normq", torch.float32),
+            "ca_v_from_j": O.cross_attention_only(xv, xj, xj, g, sd, p + ".vertx_CA_FFN", 2),
+            "cab_v_from_j": O.cross_attention_block(xv, xj, xj, g, sd, p + ".vertx_CA_FFN", 2),
+            "ca_j_from_v": O.cross_attention_only(xj, xv, xv, g, sd, p + ".joint_CA_FFN", 8),
+            "cab_j_from_v": O.cross_attention_block(xj, xv, xv, g, sd, p + ".joint_CA_FFN", 8),
+            "sab_v": O.ada_block(xv, g, sd, p + ".vertx_SA_FFN", 2),
+            "sab_j": O.ada_block(xj, g, sd, p + ".joint_SA_FFN", 8),
+        }
+        jt = T(u("mod.jt", B * 17 * 3, 11).reshape(B, 17, 3) * 0.5)
+        vt = T(u("mod.vt", B * 431 * 3, 11).reshape(B, 431, 3) * 0.5)
+        got["coevo_j"], got["coevo_v"] = O.coevo_block(jt, vt, g, sd, p)
+        got["upsample"] = torch.nn.functional.conv1d(
+            vt, sd["pose_mesh_coevo.upsample_conv.weight"], sd["pose_mesh_coevo.upsample_conv.bias"], padding=1)
+        feats = T(synth.make_inputs(2, 17, 21)[1])
+        y = O.gru_bidir2(feats.permute(1, 0, 2), sd, "pose_mesh_coevo.gru_cur")
+        got["gru_y8"] = y[8]
+        got["gru_y_all_b0"] = y[:, 0, :]
+        p2d, f2 = synth.make_inputs(1, 17, 31)
+        got["lifter_pose3d"] = O.lifter_forward(sd, T(p2d), T(f2))
+        xl = T(u("mod.xl", 3 * 17 * 256, 11).reshape(3, 17, 256))
+        got["lifter_block_s1"] = O.lifter_block(xl, sd, "pose_lifter.SpatialBlocks.1", torch.float32)
+    tol = {"lifter_pose3d": 5e-3}      # millimetres
+    for k, v in got.items():
+        e = maxabs(v, z[k])
+        assert e < tol.get(k, 2e-5), (k, e)
+
+
+def test_dead_code_claim(golden):
+    """in blocks 1-2 the joint-stream modules cannot influence any output."""
+    z = golden("e2e_J17_C256_B2.npz")
+    sd = dict(cached_state_dict(17, 256))
+    B = 1
+    pose2d, img_feat = synth.make_inputs(B, 17, 0)
+    with torch.no_grad():
+        base = O.decoder_forward(sd, T(z["pose3d"][:B]) / 1000, T(img_feat), z["vj_relation"])
+        for k in list(sd.keys()):
+            for b in ("coevoblock1", "coevoblock2"):
+                if f".{b}." in k and any(s in k for s in ("joint_CA_FFN", "joint_SA_FFN", "proj_joint_feat2coor",
+                                                          "j_Q_embed", "v2j_K_embed", "proj_v2j_dim")):
+                    sd[k] = sd[k] * 0 + 0.37
+        pert = O.decoder_forward(sd, T(z["pose3d"][:B]) / 1000, T(img_feat), z["vj_relation"])
+    assert torch.equal(base[0], pert[0]) and torch.equal(base[1], pert[1])
+
+
+def test_fp32_noise_floor(golden):
+    """How far fp32 sits from fp64 on this path — the yardstick for the GPU tolerance."""
+    z = golden("e2e_J17_C256_B2.npz")
+    sd = cached_state_dict(17, 256)
+    pose2d, img_feat = synth.make_inputs(1, 17, 0)
+    with torch.no_grad():
+        m32, p32, l32 = O.pmce_forward(sd, T(pose2d), T(img_feat), z["vj_relation"])
+        m64, p64, l64 = O.pmce_forward(sd, T(pose2d), T(img_feat), z["vj_relation"], dtype=torch.float64)
+    print("fp32-vs-fp64: mesh %.2e m, pose %.2e m, pose3d %.2e mm" % (maxabs(m32, m64), maxabs(p32, p64), maxabs(l32, l64)))
+    assert maxabs(m32, m64) < 1e-4 and maxabs(l32, l64) < 2e-2
