@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — PMCE hot-path throughput on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the full two-stream hot path (temporal pose encoder + CoEvoDecoder + 6890-vertex
+upsample + J_regressor projection) over one batch of synthetic 16-frame clips per GPU (BASELINE.json configs[2]:
+batch = 256, J = 17, C = 256), inputs resident in HBM.  Prints ONE JSON line (rank 0) with the whole-job clips/s,
+the roofline of the dominant kernel class (from HIP-event timings taken inside this run), and the oracle's CPU
+baseline on the host cores (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 MFMA == fp32 vector peak
+PEAK_HBM_GBS = 8000.0       # HBM3E peak
+
+
+def gemm_lifter_flops(B, J, C, depth=3, T=16, F=2048):
+    M = B * T * J
+    return 2.0 * B * T * F * C + depth * 2 * (2.0 * M * C * 3 * C + 2.0 * M * C * C + 2 * 2.0 * M * C * 2 * C)
+
+
+def class_work(name, B, J, C):
+    """ALGORITHMIC work of one forward for a kernel class: (amount, unit-kind)."""
+    GH, F = 1024, 2048
+    if name == "gemm_lifter":
+        return gemm_lifter_flops(B, J, C), "flop"
+    if name == "gemm_gru_in":          # as the reference computes it: both layers, all 16 steps, both directions
+        return 2 * (2.0 * 16 * B * 3 * GH * F) * 2, "flop"
+    if name == "gemm_gru_rec":
+        return 2 * (2.0 * 16 * B * 3 * GH * GH) * 2, "flop"
+    if name == "gemm_final":
+        return 2.0 * B * 3 * 431 * 3 * 6890 + 3 * 2.0 * B * 2048 * 6890, "flop"
+    if name == "gemm_ada":
+        return 72 * 2.0 * B * 2048 * 64, "flop"
+    if name == "adaln_mlp":
+        return 6 * 2 * 2.0 * B * 431 * 64 * 256, "flop"
+    if name == "vertex_sa":
+        return 3 * (2 * 2.0 * B * 431 * 431 * 64 + 2.0 * B * 431 * 64 * 64), "flop"
+    if name == "adaln_qkv":
+        return 3 * 2.0 * B * 431 * 64 * 192, "flop"
+    if name == "vertex_ca":            # 229,376 B per clip * direction * block
+        return 3 * 229376.0 * B, "byte"
+    return None, None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
+    ap.add_argument("--joints", type=int, default=17)
+    ap.add_argument("--embed-dim", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    from pmce_amd import assets, models, sharding, synth
+
+    rank, local, world = sharding.init_from_env()
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    B, J, C = args.batch, args.joints, args.embed_dim
+
+    # ---- model (random-init weights of the named architecture; no checkpoints exist offline) ----
+    sd = synth.make_state_dict(synth.pmce_spec(J, C, 3), seed=123)
+    model = models.PMCE.get_model(J, C, 3)
+    model.load_state_dict(sd)
+    model.set_j_regressor(assets.load_j_regressor("h36m"))
+    model = model.to(dev)
+
+    # ---- synthetic clips, resident in HBM; each rank gets its own shard of the global clip range ----
+    lo, hi = sharding.shard_range(B * world, rank, world)
+    pose2d_np, feat_np = synth.make_inputs(B, J, seed=1000 + rank)
+    pose2d = torch.from_numpy(pose2d_np).to(dev)
+    img_feat = torch.from_numpy(feat_np).to(dev)
+
+    def step():
+        return model.forward_with_joints(pose2d, img_feat)
+
+    for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
+        out = step()
+    if args.warmup == 0:
+        out = step()   # packing / workspace allocation must not be inside the timed region
+    torch.cuda.synchronize()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dt = sharding.reduce_max(dt, dev)
+    clips_per_s = B * world * args.steps / dt
+
+    # final metric reduction — the only collective of the path (RCCL over xGMI): per-rank partial sums
+    mesh, pose, pose3d, pred = out
+    partial = torch.stack([pred.abs().sum().double(), mesh.abs().sum().double(),
+                           torch.tensor(float(B), device=dev, dtype=torch.float64)])
+    total = sharding.reduce_metric_sums(partial)
+    finite = bool(torch.isfinite(total).all().item())
+
+    # ---- per-kernel-class timing with HIP events on the launch stream (a few extra, untimed-for-value steps) ----
+    model.profile(True)
+    nprof = 3
+    for _ in range(nprof):
+        step()
+    torch.cuda.synchronize()
+    prof = model.profile_read()
+    model.profile(False)
+    kernel_ms = {k: round(v[0] / nprof, 4) for k, v in prof.items() if v[1] > 0}
+    launches = {k: int(v[1] // nprof) for k, v in prof.items() if v[1] > 0}
+    dominant = max(kernel_ms, key=kernel_ms.get)
+    work, kind = class_work(dominant, B, J, C)
+    roofline = None
+    if work is not None:
+        secs = kernel_ms[dominant] * 1e-3
+        if kind == "flop":
+            ach = work / secs / 1e12
+            roofline = {"kernel": dominant, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
+                        "launches_per_step": launches[dominant], "avg_launch_ms": round(kernel_ms[dominant] / launches[dominant], 5)}
+        else:
+            ach = work / secs / 1e9
+            roofline = {"kernel": dominant, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                        "launches_per_step": launches[dominant], "avg_launch_ms": round(kernel_ms[dominant] / launches[dominant], 5)}
+    # the north-star kernel, always reported next to the dominant one
+    ca = None
+    if "vertex_ca" in kernel_ms:
+        w_ca, _ = class_work("vertex_ca", B, J, C)
+        ach = w_ca / (kernel_ms["vertex_ca"] * 1e-3) / 1e9
+        ca = {"kernel": "vertex_ca", "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+              "frac": round(ach / PEAK_HBM_GBS, 4), "bytes_per_clip_dir_block": 229376,
+              "avg_launch_ms": round(kernel_ms["vertex_ca"] / launches["vertex_ca"], 5)}
+
+    # ---- CPU baseline: the oracle (a port of the reference forward) on this box's host cores ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pmce_oracle as O
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        cb = 64
+        p_cpu, f_cpu = (torch.from_numpy(a) for a in synth.make_inputs(cb, J, seed=1))
+        with torch.no_grad():
+            O.pmce_forward(sd, p_cpu[:4], f_cpu[:4], model.vj_relation)      # warm-up
+            n, t_cpu = 0, 0.0
+            while t_cpu < args.cpu_seconds and n < 50:
+                t1 = time.perf_counter()
+                O.pmce_forward(sd, p_cpu, f_cpu, model.vj_relation)
+                t_cpu += time.perf_counter() - t1
+                n += 1
+        cpu = {"value": round(cb * n / t_cpu, 2), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"{n} x batch-{cb} full forwards of oracle/pmce_oracle.py (torch CPU fp32, J={J}, C={C})"}
+
+    if rank == 0:
+        flops_clip = None
+        try:
+            from oracle import pmce_oracle as O
+            flops_clip = O.flops_per_clip(J, C)["total"]
+        except Exception:
+            pass
+        line = {
+            "metric": "16-frame clips/s", "value": round(clips_per_s, 1), "unit": "clips/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"full two-stream PMCE forward (temporal pose encoder + CoEvoDecoder + 6890-vertex "
+                                   f"upsample + J_regressor), batch={B}/GPU, T=16, J={J}, C={C}, random-init weights",
+                       "global_batch": B * world, "parallelism": f"clip-sharded dp{world}, weights replicated"},
+            "roofline": roofline, "roofline_cross_attention": ca, "cpu_baseline": cpu,
+            "kernel_ms_per_step": kernel_ms, "launches_per_step": launches,
+            "ref_equiv_tflops": round(flops_clip * clips_per_s / 1e12, 2) if flops_clip else None,
+            "outputs_finite": finite,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,168 @@
+/* libpmce_hip.so — C ABI of the MI355X-native PMCE per-clip inference hot path.
+ *
+ * The reference (kasvii/PMCE) is pure Python/PyTorch and has no FFI; its boundary for this path is the
+ * nn.Module API of lib/models (PMCE.py:15-26, PoseEstimation.py:95-120, CoevoDecoder.py:226-252) plus the
+ * caller's J_regressor projection (lib/core/base.py:223-225).  The entry points below are what a binding of
+ * that path needs; pmce_amd/_lib.py is the ctypes binding, pmce_amd/models/ the nn.Module-shaped host side,
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions (all functions):
+ *   - return 0 on success, a negative PMCE_ERR_* otherwise; never throw, never exit; the message of the last
+ *     error of the calling thread is pmce_last_error_string();
+ *   - every pointer is a DEVICE pointer to contiguous row-major fp32 (int32 where noted), 16-byte aligned;
+ *   - the caller owns every buffer (weights, activations, workspace); the library allocates no device memory;
+ *   - launches are asynchronous on the hipStream_t passed in; no hidden synchronisation;
+ *   - no global mutable state except the thread-local error string, so one process per GPU or several
+ *     streams per process are both fine.
+ * Fixed structural constants of the path: T = 16 frames, F = 2048 image-feature channels, V = 431 coarse
+ * vertices, 6890 mesh vertices, D = 64 decoder channels, GRU hidden 1024, 8 lifter heads.  J <= 32,
+ * C in {256, 512}.
+ */
+#ifndef PMCE_HIP_H
+#define PMCE_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* pmce_stream_t; /* == hipStream_t */
+
+#define PMCE_OK 0
+#define PMCE_ERR_ARG (-1)
+#define PMCE_ERR_LAUNCH (-2)
+#define PMCE_ERR_WORKSPACE (-3)
+
+int pmce_version(void);
+const char* pmce_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Whole-path model object (host-side descriptor only: it stores the pointers the caller registers).
+ * Replaces: models.PMCE.get_model / PMCE.forward (PMCE.py:7-26), models.PoseEstimation.get_model /
+ * GraphormerNet.forward (PoseEstimation.py:95-120), models.CoevoDecoder.get_model / Pose2Mesh.forward
+ * (CoevoDecoder.py:226-252), and `J_regressor[None] @ (pred_mesh*1000)` (lib/core/base.py:223-225).
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct pmce_model pmce_model;
+
+/* num_joint: J (17, or 19 for COCO-input checkpoints); embed_dim: C (256|512); depth: lifter depth (3). */
+int pmce_model_create(int num_joint, int embed_dim, int depth, pmce_model** out);
+void pmce_model_destroy(pmce_model* m);
+/* Register one packed tensor by name (names: pmce_model_tensor_name).  The pointer must stay valid. */
+int pmce_model_set_tensor(pmce_model* m, const char* name, const void* dev_ptr);
+/* Enumerate the packed-tensor names the model needs (i in [0, pmce_model_tensor_count)). */
+int pmce_model_tensor_count(const pmce_model* m);
+const char* pmce_model_tensor_name(const pmce_model* m, int i);
+/* Optional caller-side projection (lib/core/base.py:196,225): register "jreg.indptr" (int32[R+1]), "jreg.indices"
+ * (int32[nnz]), "jreg.data" (fp32[nnz]) with pmce_model_set_tensor and the row count R here. */
+int pmce_model_set_regressor_rows(pmce_model* m, int rows);
+/* Check that every tensor is registered. */
+int pmce_model_finalize(pmce_model* m);
+/* Bytes of caller-provided workspace needed for a batch of B clips. */
+size_t pmce_model_workspace_bytes(const pmce_model* m, int batch);
+
+/* Byte offset inside the workspace of a named intermediate ("X","Y0","g","GB","VT0","VT1","VT2","F1","F2","JM"),
+ * -1 if unknown — for parity tests of intermediates (after a forward VT1/VT2/VT0 hold the vertices after
+ * coevoblock1/2/3, "g" the GRU feature y[8]). */
+long long pmce_model_workspace_offset(const pmce_model* m, int batch, const char* name);
+
+/* GraphormerNet.forward: pose2d[B,16,J,2], img_feat[B,16,2048] -> pose3d[B,J,3] (mm). */
+int pmce_lifter_forward(pmce_model* m, const float* pose2d, const float* img_feat, float* pose3d, int batch, void* ws,
+                        size_t ws_bytes, pmce_stream_t stream);
+/* Pose2Mesh.forward: joints[B,J,3] (m), img_feat[B,16,2048] -> cam_pose[B,J,3], cam_mesh[B,6890,3] (m). */
+int pmce_decoder_forward(pmce_model* m, const float* joints, const float* img_feat, float* cam_pose, float* cam_mesh,
+                         int batch, void* ws, size_t ws_bytes, pmce_stream_t stream);
+/* PMCE.forward: -> cam_mesh[B,6890,3] (m), cam_pose[B,J,3] (m), pose3d[B,J,3] (mm);
+ * if pred_pose != NULL also the caller's projection pred_pose[B,R,3] = J_regressor @ (cam_mesh*1000) (mm). */
+int pmce_forward(pmce_model* m, const float* pose2d, const float* img_feat, float* cam_mesh, float* cam_pose,
+                 float* pose3d, float* pred_pose, int batch, void* ws, size_t ws_bytes, pmce_stream_t stream);
+
+/* Per-kernel-class timing of the forwards above (HIP events on the caller's stream).  enable != 0 starts
+ * accumulating; pmce_model_profile_read synchronises the recorded events and returns, for class i, its
+ * name, accumulated milliseconds and launch count; returns the number of classes. */
+int pmce_model_profile(pmce_model* m, int enable);
+int pmce_model_profile_read(pmce_model* m, int i, const char** name, double* ms, long long* launches);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Individual operators (what the model object launches; exported for the parity tests and for callers that
+ * want one stage).  Shapes in comments; B = clips.
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* C[m,n] = act(sum_k A[m,k] W[n,k] + bias[n]) + R[m,n]  — every nn.Linear / the packed GRU, AdaLN and upsample
+ * products (timm Mlp/Attention Linear layers; CoevoDecoder.py:19-20,214-224).  K % 32 == 0.  act: 0 none,
+ * 1 exact GELU.  Row maps: if a_div > 0 row r of A is at A + (r % a_div)*a_lo + (r / a_div)*a_hi, else r*lda;
+ * same for C and R with c_*.  batch > 1 adds bs* element offsets per batch index (grid.z). */
+int pmce_gemm_nt_f32(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N, int K,
+                     long long lda, int ldw, long long ldc, int act, int a_div, long long a_lo, long long a_hi, int c_div,
+                     long long c_lo, long long c_hi, int batch, long long bsA, long long bsW, long long bsBias,
+                     long long bsC, pmce_stream_t stream);
+
+/* PoseEstimation.py:78-81 — x[tok] = joint_embed(pose2d) + imgfeat_embed(img_feat)[b,t] + spatial_pos[j]. */
+int pmce_embed_tokens_f32(const float* pose2d, const float* E, const float* Wje, const float* bje, const float* spos,
+                          float* x, long long ntok, int J, int C, pmce_stream_t stream);
+/* nn.LayerNorm chain over rows of C channels: y1 = (w1 ? LN(x;w1,b1,eps1) : x) + add[(row/add_div)%add_mod];
+ * out1 = y1 (optional); out2 = LN(y1;w2,b2,eps2) (optional).  norm1/norm2/norm_s/norm_t (PoseEstimation.py:17,23,58-59). */
+int pmce_ln_chain_f32(const float* x, long long rows, int C, const float* w1, const float* b1, float eps1,
+                      const float* add, int add_div, int add_mod, float* out1, const float* w2, const float* b2,
+                      float eps2, float* out2, pmce_stream_t stream);
+/* timm Attention core on qkv[tok][3C] for sequences of N <= 32 tokens, 8 heads (PoseEstimation.py:19 / CoevoDecoder.py:118-131).
+ * sequence s, position i -> token (s % seq_div)*seq_lo + (s / seq_div)*seq_hi + i*tok_stride. */
+int pmce_seq_attention_f32(const float* qkv, float* out, int nseq, int N, int C, int seq_div, long long seq_lo,
+                           long long seq_hi, long long tok_stride, pmce_stream_t stream);
+/* PoseEstimation.py:62-66,109-113 — LayerNorm(1e-5) + Linear(C->3) + Conv2d(T->1) frame fusion. */
+int pmce_lifter_head_f32(const float* x, const float* lnw, const float* lnb, const float* Wr, const float* br,
+                         const float* wf, const float* bf, float* pose3d, int B, int T, int J, int C, pmce_stream_t stream);
+
+/* nn.GRU gate update of one time step for ndir directions (CoevoDecoder.py:216-221). */
+int pmce_gru_gates_f32(const float* gi0, const float* gi1, const float* gh0, const float* gh1, const float* hp0,
+                       const float* hp1, float* ho0, float* ho1, long long gi_rs, long long gh_rs0, long long gh_rs1,
+                       long long hp_rs, long long ho_rs, int B, int H, int ndir, pmce_stream_t stream);
+/* y = x / denom (PMCE.py:18). */
+int pmce_div_scalar_f32(const float* x, float* y, long long n, float denom, pmce_stream_t stream);
+
+/* CoevoDecoder.py:232 — vertxs[b][v][:] = joints[b][vj[v]][:]; vj int32[431].  Bit-exact copy. */
+int pmce_vertex_init_gather_f32(const float* joints, const int* vj, float* vt, int B, int J, pmce_stream_t stream);
+/* CoevoDecoder.py:177-180,184 — jf = joint_proj(jt)+joint_pos_embed; xk = proj_j2v_dim(jf)+j2v_K_embed. */
+int pmce_joint_embed_f32(const float* jt, const float* Wj, const float* bj, const float* jpos, const float* Wj2v,
+                         const float* bj2v, const float* j2vK, float* jf, float* xk, int B, int J, pmce_stream_t stream);
+/* Key/value side of the vertex<-joint CrossAttention (CoevoDecoder.py:47-62,83) with Wq / proj folded in:
+ * GB[b][inst*128 + (gamma 0..63 | beta 64..127)] are the AdaLN parameters; Kf,Vf [B,64,64], s0 [B,64]. */
+int pmce_ca_fold_f32(const float* xk, const float* xv, const float* GB, int gb_stride, int iq, int ik, int iv,
+                     const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv, const float* bv,
+                     const float* Wp, float* Kf, float* s0, float* Vf, int B, int J, pmce_stream_t stream);
+/* THE north-star kernel: fused AdaLN + vertex<-joint cross-attention + residual for 431 query tokens
+ * (first line of CrossAttentionBlock.forward, CoevoDecoder.py:83).  xq[B,431,64], or xq == NULL and
+ * xq := Wv3*vt + Eq formed on the fly from vt[B,431,3]. */
+int pmce_vertex_ca_f32(const float* xq, const float* vt, const float* Wv3, const float* Eq, const float* Kf,
+                       const float* s0, const float* Vf, const float* bp, float* out, int B, int J, pmce_stream_t stream);
+/* x + Mlp(AdaLN(x)) on [B,431,64] (CoevoDecoder.py:85-86,104); optional Linear(64->3)+coordinate residual (:189). */
+int pmce_adaln_mlp_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* W1, const float* b1,
+                       const float* W2, const float* b2, float* yout, const float* Wc, const float* bc, const float* vt_in,
+                       float* vt_out, int B, pmce_stream_t stream);
+/* qkv = Linear(64->192)(AdaLN(x)) on [B,431,64] (CoevoDecoder.py:103,120). */
+int pmce_adaln_qkv_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* Wqkv, const float* bqkv,
+                       float* qkv, int B, pmce_stream_t stream);
+/* y = x + proj(softmax(q k^T/sqrt(32)) v), 2 heads, 431x431 per clip (CoevoDecoder.py:118-131,103). */
+int pmce_vertex_sa_f32(const float* xin, const float* qkv, const float* Wp, const float* bp, float* yout, int B,
+                       pmce_stream_t stream);
+/* k|v of the joint<-vertex CrossAttention for the 431 vertex tokens: kv[B,431,128] (CoevoDecoder.py:52-53,83,183). */
+int pmce_tokens_kv_f32(const float* xk, const float* xv, const float* vt, const float* Wv3, const float* Ev,
+                       const float* Wv2j, const float* Ek, const float* GB, int gb_stride, int ik, int iv, const float* Wk,
+                       const float* bk, const float* Wv, const float* bv, float* kv, int B, pmce_stream_t stream);
+/* Joint stream of a CoevoBlock (CoevoDecoder.py:183,187,189): stage 1 = joint<-vertex cross-attention +
+ * residual only, 2 = + FFN, 3 = + self-attention block + coordinate head.  wptr: 18 weight pointers
+ * (wq,bq,proj_w,proj_b,fc1_w,fc1_b,fc2_w,fc2_b,qkv_w,qkv_b,sproj_w,sproj_b,sfc1_w,sfc1_b,sfc2_w,sfc2_b,coor_w,coor_b);
+ * inst: AdaLN instance ids (normq, norm2, SA.norm1, SA.norm2). */
+int pmce_joint_stream_f32(const float* xq, const float* jQ, const float* kv, const float* GB, int gb_stride,
+                          const float* const* wptr, const int* inst, const float* jt, float* y_out, float* pose_out, int B,
+                          int J, int stage, pmce_stream_t stream);
+/* Operand of the packed upsample+residual product: A[b] = [relu(g[b]) | vt[b] flattened | 0-pad] (CoevoDecoder.py:238-244). */
+int pmce_build_final_operand_f32(const float* g, const float* vt, float* A, int B, int KP, pmce_stream_t stream);
+/* lib/core/base.py:223-225 — out[b][r][:] = sum_nz data * (mesh[b][col][:] * scale); CSR regressor [R,6890]. */
+int pmce_j_regress_f32(const float* mesh, const int* indptr, const int* indices, const float* data, float* out, int B,
+                       int R, int NVF, float scale, pmce_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMCE_HIP_H */

@@ -211,6 +211,7 @@ def vertex_init_gather(joints, vj_relation):
 
 def upsample_and_residual(vertxs, g_mid, sd, prefix, dtype=torch.float32):
     """CoevoDecoder.py:238-244: Conv1d(431->6890,k=3,pad=1) along xyz + cat of 3 Linear(relu(y[8]))."""
+    vertxs, g_mid = vertxs.to(dtype), g_mid.to(dtype)
     up = F.conv1d(vertxs, _g(sd, prefix + "upsample_conv.weight", dtype), _g(sd, prefix + "upsample_conv.bias", dtype),
                   padding=1)                                       # [B,6890,3]
     rg = F.relu(g_mid)

@@ -1,0 +1,105 @@
+"""ctypes binding of libpmce_hip.so (include/pmce_hip.h).  There is no fallback: if the library is missing or
+a symbol is absent, importing / calling fails loudly.  The product path never touches oracle/."""
+from __future__ import annotations
+
+import ctypes as C
+import os.path as osp
+
+HERE = osp.dirname(osp.abspath(__file__))
+LIB_PATH = osp.join(HERE, "libpmce_hip.so")
+
+_f = C.c_void_p      # device pointer (float*/int*)
+_i = C.c_int
+_l = C.c_longlong
+_s = C.c_void_p      # hipStream_t
+_fl = C.c_float
+
+# name -> argtypes  (restype is int unless listed in _RESTYPES); mirrors include/pmce_hip.h one-to-one
+PROTOTYPES = {
+    "pmce_version": [],
+    "pmce_last_error_string": [],
+    "pmce_model_create": [_i, _i, _i, C.POINTER(C.c_void_p)],
+    "pmce_model_destroy": [C.c_void_p],
+    "pmce_model_set_tensor": [C.c_void_p, C.c_char_p, _f],
+    "pmce_model_tensor_count": [C.c_void_p],
+    "pmce_model_tensor_name": [C.c_void_p, _i],
+    "pmce_model_set_regressor_rows": [C.c_void_p, _i],
+    "pmce_model_finalize": [C.c_void_p],
+    "pmce_model_workspace_bytes": [C.c_void_p, _i],
+    "pmce_model_workspace_offset": [C.c_void_p, _i, C.c_char_p],
+    "pmce_lifter_forward": [C.c_void_p, _f, _f, _f, _i, _f, C.c_size_t, _s],
+    "pmce_decoder_forward": [C.c_void_p, _f, _f, _f, _f, _i, _f, C.c_size_t, _s],
+    "pmce_forward": [C.c_void_p, _f, _f, _f, _f, _f, _f, _i, _f, C.c_size_t, _s],
+    "pmce_model_profile": [C.c_void_p, _i],
+    "pmce_model_profile_read": [C.c_void_p, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_longlong)],
+    "pmce_gemm_nt_f32": [_f, _f, _f, _f, _f, _i, _i, _i, _l, _i, _l, _i, _i, _l, _l, _i, _l, _l, _i, _l, _l, _l, _l, _s],
+    "pmce_embed_tokens_f32": [_f, _f, _f, _f, _f, _f, _l, _i, _i, _s],
+    "pmce_ln_chain_f32": [_f, _l, _i, _f, _f, _fl, _f, _i, _i, _f, _f, _f, _fl, _f, _s],
+    "pmce_seq_attention_f32": [_f, _f, _i, _i, _i, _i, _l, _l, _l, _s],
+    "pmce_lifter_head_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _s],
+    "pmce_gru_gates_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _l, _l, _l, _l, _l, _i, _i, _i, _s],
+    "pmce_div_scalar_f32": [_f, _f, _l, _fl, _s],
+    "pmce_vertex_init_gather_f32": [_f, _f, _f, _i, _i, _s],
+    "pmce_joint_embed_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],
+    "pmce_ca_fold_f32": [_f, _f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],
+    "pmce_vertex_ca_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],
+    "pmce_adaln_mlp_f32": [_f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _s],
+    "pmce_adaln_qkv_f32": [_f, _f, _i, _i, _f, _f, _f, _i, _s],
+    "pmce_vertex_sa_f32": [_f, _f, _f, _f, _f, _i, _s],
+    "pmce_tokens_kv_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _f, _f, _f, _i, _s],
+    "pmce_joint_stream_f32": [_f, _f, _f, _f, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_int), _f, _f, _f, _i, _i, _i, _s],
+    "pmce_build_final_operand_f32": [_f, _f, _f, _i, _i, _s],
+    "pmce_j_regress_f32": [_f, _f, _f, _f, _f, _i, _i, _i, _fl, _s],
+}
+_RESTYPES = {
+    "pmce_last_error_string": C.c_char_p,
+    "pmce_model_destroy": None,
+    "pmce_model_tensor_name": C.c_char_p,
+    "pmce_model_workspace_bytes": C.c_size_t,
+    "pmce_model_workspace_offset": C.c_longlong,
+}
+
+_lib = None
+
+
+class PmceError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built — no CPU fallback exists."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not osp.exists(LIB_PATH):
+        raise PmceError(f"{LIB_PATH} not found: build it first (python -m pmce_amd.build, or __graft_entry__.build()). "
+                        "There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing: loud by design
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return (load().pmce_last_error_string() or b"").decode()
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise PmceError(f"{what or 'libpmce_hip'} failed (rc={rc}): {last_error()}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "libpmce_hip needs contiguous device tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,59 @@
+"""Build libpmce_hip.so (hand-written HIP for gfx950) in-tree with hipcc.  No torch extension machinery: the
+library is a plain C-ABI shared object loaded with ctypes (pmce_amd/_lib.py)."""
+from __future__ import annotations
+
+import os
+import os.path as osp
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = osp.dirname(osp.abspath(__file__))
+CSRC = osp.join(HERE, "csrc")
+LIB = osp.join(HERE, "libpmce_hip.so")
+SOURCES = ["common.cpp", "gemm_f32.hip", "lifter.hip", "gru.hip", "coevo.hip", "model.cpp"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (osp.isabs(c) and osp.exists(c) or not osp.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build() -> bool:
+    if not osp.exists(LIB):
+        return True
+    t = osp.getmtime(LIB)
+    deps = [osp.join(CSRC, f) for f in os.listdir(CSRC)] + [osp.join(HERE, "..", "include", "pmce_hip.h")]
+    return any(osp.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return LIB
+    hipcc = _hipcc()
+    objdir = osp.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = osp.join(objdir, osp.splitext(src)[0] + ".o")
+        cmd = [hipcc, *FLAGS, "-x", "hip", "-c", osp.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            sys.stderr.write(r.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,971 @@
+// Pose–mesh co-evolution decoder kernels (reference lib/models/CoevoDecoder.py), gfx950 only.
+//
+// All 64-channel token work is "token-local": a wavefront owns 32 tokens, the lane pair (l, l+32) holds one
+// token's 64 channels in the slot layout of common.hpp, every Linear is a swapped-operand
+// v_mfma_f32_32x32x2_f32 product  Y^T[n, tok] = W[n, k] * X^T[k, tok]  whose D registers are again the slot
+// layout, so AdaLN -> Linear -> softmax -> Linear -> residual chains never leave registers and softmax /
+// LayerNorm reductions are 16..32 in-lane ops plus one cross-half shuffle.
+//
+// Kernels (V = 431 vertices, D = 64 channels, J <= 32 joints):
+//   vertex_init_gather   integer gather  vertxs = joints[:, vj_relation]                (CoevoDecoder.py:232)
+//   joint_embed          jf = joint_proj(jt)+pos ; xk = proj_j2v_dim(jf)+j2v_K_embed     (:177-180,:184)
+//   ca_fold              per clip: fold Wq into K and Wproj into V of the vertex<-joint cross-attention
+//   vertex_ca            fused AdaLN + vertex<-joint cross-attention + residual          (:83, :47-62, :23-29)
+//   adaln_mlp            x + Mlp(AdaLN(x)) (+ Linear(64->3) + coordinate residual)       (:85-86,:104,:189)
+//   adaln_qkv            qkv = Linear(64->192)(AdaLN(x))                                 (:103,:120)
+//   vertex_sa            flash-style 431x431 self-attention (2 heads) + proj + residual  (:118-131,:103)
+//   tokens_kv            k = Wk*AdaLN_k(xk)+bk, v = Wv*AdaLN_v(xv)+bv for the joint<-vertex direction
+//   joint_stream         block-3 joint stream: joint<-vertex CA + FFN + SA + FFN + coords (:183,:187,:189)
+#include "common.hpp"
+
+#define NV 431   // down-sampled mesh vertices
+#define ND 64    // joint_dim == vertx_dim (cfg.MODEL.joint_dim / vertx_dim)
+#define NTILE 14 // ceil(431 / 32) wave tiles per clip
+#define LDW64 68
+#define LDW256 260
+
+// ======================================================================================================
+// vertex init gather — integer index path, bit-exact copy
+// ======================================================================================================
+__global__ __launch_bounds__(256) void vertex_init_gather_kernel(const float* __restrict__ joints,
+                                                                 const int* __restrict__ vj, float* __restrict__ vt, int B,
+                                                                 int J) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * NV * 3) return;
+  const int l = idx % 3, v = (idx / 3) % NV, b = idx / (3 * NV);
+  vt[idx] = joints[((long long)b * J + vj[v]) * 3 + l];
+}
+
+// ======================================================================================================
+// small per-clip helpers for J-token work (VALU; J <= 32 tokens, tiny FLOPs)
+// ======================================================================================================
+#define JLD 65  // LDS row stride for [J][64] buffers
+
+// out[i][n] = act(b[n] + sum_k W[n*KIN+k] * in[i*ild + k]) for i < J, n < NOUT (all 256 threads cooperate)
+template <int KIN, int NOUT>
+__device__ __forceinline__ void lin_small(const float* in, int ild, const float* __restrict__ W, const float* __restrict__ b,
+                                          float* out, int old, int J, int tid, bool gelu) {
+  for (int idx = tid; idx < J * NOUT; idx += 256) {
+    const int i = idx / NOUT, n = idx % NOUT;
+    const float* w = W + (long long)n * KIN;
+    const float* x = in + i * ild;
+    float s = 0.f;
+#pragma unroll 8
+    for (int k4 = 0; k4 < KIN / 4; ++k4) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w + 4 * k4);
+      s += wv.x * x[4 * k4] + wv.y * x[4 * k4 + 1] + wv.z * x[4 * k4 + 2] + wv.w * x[4 * k4 + 3];
+    }
+    s += b[n];
+    out[i * old + n] = gelu ? gelu_erf(s) : s;
+  }
+}
+
+// AdaLN over J tokens of 64 channels held in LDS: one wavefront per token, lane = channel.
+__device__ __forceinline__ void adaln_small(const float* in, float* out, const float* __restrict__ gb, int J, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int i = wave; i < J; i += 4) {
+    const float x = in[i * JLD + lane];
+    const float mean = wave_sum(x) * (1.0f / 64.0f);
+    const float d = x - mean;
+    const float var = wave_sum(d * d) * (1.0f / 63.0f);
+    out[i * JLD + lane] = gb[lane] * d / (sqrtf(var) + 1e-6f) + gb[64 + lane];
+  }
+}
+
+// ======================================================================================================
+// joint_embed: jf[b][i][:] = Wj*jt + bj + jpos[i] ; xk[b][i][:] = Wj2v*jf + bj2v + j2vK[i]
+// ======================================================================================================
+__global__ __launch_bounds__(256) void joint_embed_kernel(const float* __restrict__ jt, const float* __restrict__ Wj,
+                                                          const float* __restrict__ bj, const float* __restrict__ jpos,
+                                                          const float* __restrict__ Wj2v, const float* __restrict__ bj2v,
+                                                          const float* __restrict__ j2vK, float* __restrict__ jf,
+                                                          float* __restrict__ xk, int J) {
+  __shared__ float s_jf[32 * JLD];
+  __shared__ float s_xk[32 * JLD];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int idx = tid; idx < J * 64; idx += 256) {
+    const int i = idx >> 6, c = idx & 63;
+    const float* p = jt + ((long long)b * J + i) * 3;
+    const float v = ((Wj[c * 3] * p[0] + Wj[c * 3 + 1] * p[1] + Wj[c * 3 + 2] * p[2]) + bj[c]) + jpos[i * 64 + c];
+    s_jf[i * JLD + c] = v;
+    jf[((long long)b * J + i) * 64 + c] = v;
+  }
+  __syncthreads();
+  lin_small<64, 64>(s_jf, JLD, Wj2v, bj2v, s_xk, JLD, J, tid, false);
+  __syncthreads();
+  for (int idx = tid; idx < J * 64; idx += 256) {
+    const int i = idx >> 6, c = idx & 63;
+    xk[((long long)b * J + i) * 64 + c] = s_xk[i * JLD + c] + j2vK[i * 64 + c];
+  }
+}
+
+// ======================================================================================================
+// ca_fold: per clip, fold the query/output projections of the vertex<-joint cross-attention into its (tiny)
+// key/value side.  With a = gamma_q*n + beta_q (n = normalised query token), k = Wk*AdaLN_k(xk)+bk,
+// v = Wv*AdaLN_v(xv)+bv, head h = channels [32h,32h+32):
+//   score[h][i] = scale * (Wq a + bq)_h . k_i,h  =  n . Kf[h*32+i][:] + s0[h*32+i]
+//   out         = sum_h P_h (v_h Wp_h^T) + bp     =  Vf[:, h*32+i] P[h*32+i] + bp
+//   Kf[h*32+i][c] = scale*gamma_q[c]*M ; s0 = scale*(sum_c beta_q[c]*M + bq_h.k_i,h) ; M = sum_d Wq[32h+d][c]*k_i[32h+d]
+//   Vf[c][h*32+i] = sum_d v_i[32h+d]*Wp[c][32h+d]
+// Rows/columns i >= J are zero (masked to -inf in vertex_ca).  Algebraically identical to
+// CrossAttention.forward (CoevoDecoder.py:47-62) after AdaLN (:83); only the summation order differs.
+// gbq/gbk/gbv: this clip's [gamma|beta] (128 floats) of normq/normk/normv.
+// ======================================================================================================
+__global__ __launch_bounds__(256) void ca_fold_kernel(const float* __restrict__ xk, const float* __restrict__ xv,
+                                                      const float* __restrict__ GB, int gb_stride, int iq, int ik, int iv,
+                                                      const float* __restrict__ Wq, const float* __restrict__ bq,
+                                                      const float* __restrict__ Wk, const float* __restrict__ bk,
+                                                      const float* __restrict__ Wv, const float* __restrict__ bv,
+                                                      const float* __restrict__ Wp, float* __restrict__ Kf,
+                                                      float* __restrict__ s0, float* __restrict__ Vf, int J) {
+  __shared__ float s_a[32 * JLD];
+  __shared__ float s_b[32 * JLD];
+  __shared__ float s_k[32 * JLD];
+  __shared__ float s_v[32 * JLD];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* gb = GB + (long long)b * gb_stride;
+  for (int idx = tid; idx < J * 64; idx += 256) {
+    const int i = idx >> 6, c = idx & 63;
+    s_a[i * JLD + c] = xk[((long long)b * J + i) * 64 + c];
+    s_b[i * JLD + c] = xv[((long long)b * J + i) * 64 + c];
+  }
+  __syncthreads();
+  adaln_small(s_a, s_k, gb + ik * 128, J, tid);  // s_k = AdaLN_k(xk)
+  adaln_small(s_b, s_v, gb + iv * 128, J, tid);  // s_v = AdaLN_v(xv)
+  __syncthreads();
+  lin_small<64, 64>(s_k, JLD, Wk, bk, s_a, JLD, J, tid, false);  // s_a = k
+  lin_small<64, 64>(s_v, JLD, Wv, bv, s_b, JLD, J, tid, false);  // s_b = v
+  __syncthreads();
+  const float scale = 0.17677669529663688110f;  // 32^-0.5 (vertx heads = 2, head_dim 32; CoevoDecoder.py:140,37-38)
+  const float gq = gb[iq * 128 + lane], bqv = gb[iq * 128 + 64 + lane];
+  float* Kfb = Kf + (long long)b * 64 * 64;
+  float* Vfb = Vf + (long long)b * 64 * 64;
+  float* s0b = s0 + (long long)b * 64;
+  // one wavefront per (h,i) row, lane = channel c
+  for (int row = wave; row < 64; row += 4) {
+    const int h = row >> 5, i = row & 31;
+    float kf = 0.f, vf = 0.f, sc = 0.f;
+    if (i < J) {
+      float M = 0.f;
+#pragma unroll 8
+      for (int d = 0; d < 32; ++d) {
+        const float kd = s_a[i * JLD + 32 * h + d];
+        M += Wq[(32 * h + d) * 64 + lane] * kd;
+        vf += s_b[i * JLD + 32 * h + d] * Wp[lane * 64 + 32 * h + d];
+      }
+      kf = scale * gq * M;
+      float t = bqv * M;
+      if (lane < 32) t += bq[32 * h + lane] * s_a[i * JLD + 32 * h + lane];
+      sc = scale * wave_sum(t);
+    }
+    Kfb[row * 64 + lane] = kf;
+    Vfb[lane * 64 + row] = vf;
+    if (lane == 0) s0b[row] = sc;
+  }
+}
+
+// ======================================================================================================
+// vertex_ca — the north-star kernel: fused AdaLN + vertex<-joint cross-attention + residual.
+//   out[b][v][:] = xq + proj(softmax((Wq AdaLN_q(xq))(Wk AdaLN_k(xk))^T / sqrt(32)) (Wv AdaLN_v(xv)))
+// with the key/value side pre-folded by ca_fold.  xq is either read ([B,431,64]) or, when xq == nullptr,
+// formed on the fly from the 3-D vertex coordinates: xq = Wv3*vt + Eq[v]  (Eq = vertx_proj.bias +
+// vertx_pos_embed + v_Q_embed, CoevoDecoder.py:177-180,184).
+// grid (2, B), 512 threads: 8 waves stage the clip's folded operands into LDS, waves 0..6 each own 32 vertices.
+// Per 32 vertices: 8 x 16-B loads/lane, 128 MFMAs (64 scores + 64 output), masked softmax over <= 32 keys as
+// 16 in-lane values + one shuffle, 8 x 16-B stores/lane.
+// ======================================================================================================
+__global__ __launch_bounds__(512) void vertex_ca_kernel(const float* __restrict__ xq, const float* __restrict__ vt,
+                                                        const float* __restrict__ Wv3, const float* __restrict__ Eq,
+                                                        const float* __restrict__ Kf, const float* __restrict__ s0,
+                                                        const float* __restrict__ Vf, const float* __restrict__ bp,
+                                                        float* __restrict__ out, int J) {
+  __shared__ __attribute__((aligned(16))) float sK[64 * LDW64];
+  __shared__ __attribute__((aligned(16))) float sV[64 * LDW64];
+  __shared__ float sS0[64];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  stage_weight<64>(sK, Kf + (long long)b * 4096, 64, tid, 512);
+  stage_weight<64>(sV, Vf + (long long)b * 4096, 64, tid, 512);
+  if (tid < 64) sS0[tid] = s0[(long long)b * 64 + tid];
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  if (wave >= 7) return;
+  const int n0 = lane & 31, hb = lane >> 5;
+  const int tile = blockIdx.x * 7 + wave;
+  const int v = tile * 32 + n0;
+  const bool valid = v < NV;
+  const int vc = valid ? v : NV - 1;
+
+  float x[32];
+  if (xq) {
+    load_slots(xq + ((long long)b * NV + vc) * 64, x, hb);
+  } else {
+    const float* p = vt + ((long long)b * NV + vc) * 3;
+    const float p0 = p[0], p1 = p[1], p2 = p[2];
+    load_slots(Eq + (long long)vc * 64, x, hb);
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const int c = slot_channel(s, hb);
+      x[s] = (Wv3[c * 3] * p0 + Wv3[c * 3 + 1] * p1 + Wv3[c * 3 + 2] * p2) + x[s];
+    }
+  }
+  // normalise (gamma/beta are folded into Kf/s0)
+  float n[32];
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += x[i];
+    const float mean = pair_sum(s) * (1.0f / 64.0f);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const float d = x[i] - mean;
+      ss += d * d;
+    }
+    const float inv = 1.0f / (sqrtf(pair_sum(ss) * (1.0f / 63.0f)) + 1e-6f);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) n[i] = (x[i] - mean) * inv;
+  }
+  // scores^T[h*32+i, tok]
+  f32x16 sc[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[h][r] = sS0[h * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb];
+  tl_gemm<8, 2, LDW64>(sK, n, sc, n0, hb);
+  // masked softmax over the joints of each head: 16 in-lane rows + the partner lane's 16
+  float p[32];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * hb;
+      const float sv = (i < J) ? sc[h][r] : -INFINITY;
+      sc[h][r] = sv;
+      m = fmaxf(m, sv);
+    }
+    m = pair_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = expf(sc[h][r] - m);
+      p[16 * h + r] = e;
+      sum += e;
+    }
+    const float inv = 1.0f / pair_sum(sum);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[16 * h + r] *= inv;
+  }
+  // out^T[c, tok] = Vf[c, :] P + bp[c] + xq
+  f32x16 o[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[nt][r] = bp[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb];
+  tl_gemm<8, 2, LDW64>(sV, p, o, n0, hb);
+  if (valid) {
+    float y[32];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y[16 * nt + r] = x[16 * nt + r] + o[nt][r];
+    store_slots(out + ((long long)b * NV + v) * 64, y, hb);
+  }
+}
+
+// ======================================================================================================
+// adaln_mlp:  y = x + fc2(gelu(fc1(AdaLN(x))))   (hidden 256), optionally followed by the coordinate head
+//   vt_out = Wc*y + bc + vt_in  (proj_vertx_feat2coor + residual, CoevoDecoder.py:189).
+// Persistent workgroups (4 waves); fc1/fc2 weights live in LDS (137 KB) for the whole kernel; each wave walks
+// over 32-token tiles; the 256-wide hidden activation exists only as 16 registers at a time.
+// ======================================================================================================
+__global__ __launch_bounds__(256) void adaln_mlp_kernel(const float* __restrict__ xin, const float* __restrict__ GB,
+                                                        int gb_stride, int inst, const float* __restrict__ W1,
+                                                        const float* __restrict__ b1, const float* __restrict__ W2,
+                                                        const float* __restrict__ b2, float* __restrict__ yout,
+                                                        const float* __restrict__ Wc, const float* __restrict__ bc,
+                                                        const float* __restrict__ vt_in, float* __restrict__ vt_out, int B) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sW1 = smem;                    // [256][68]
+  float* sW2 = sW1 + 256 * LDW64;       // [64][260]
+  float* sB1 = sW2 + 64 * LDW256;       // [256]
+  float* sB2 = sB1 + 256;               // [64]
+  const int tid = threadIdx.x;
+  stage_weight<64>(sW1, W1, 256, tid, 256);
+  stage_weight<256>(sW2, W2, 64, tid, 256);
+  sB1[tid] = b1[tid];
+  if (tid < 64) sB2[tid] = b2[tid];
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n0 = lane & 31, hb = lane >> 5;
+  const int ntiles = B * NTILE;
+  for (int wt = blockIdx.x * 4 + wave; wt < ntiles; wt += gridDim.x * 4) {
+    const int b = wt / NTILE, tile = wt % NTILE;
+    const int v = tile * 32 + n0;
+    const bool valid = v < NV;
+    const long long tok = (long long)b * NV + (valid ? v : NV - 1);
+    float x[32], a[32];
+    load_slots(xin + tok * 64, x, hb);
+    adaln_slots(x, a, GB + (long long)b * gb_stride + inst * 128, hb);
+    f32x16 acc2[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[nt][r] = sB2[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb] + x[16 * nt + r];
+#pragma unroll 1
+    for (int ht = 0; ht < 8; ++ht) {
+      f32x16 acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[r] = sB1[ht * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb];
+      tl_gemm<8, 1, LDW64>(sW1 + ht * 32 * LDW64, a, &acc1, n0, hb);
+      float hreg[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hreg[r] = gelu_erf(acc1[r]);
+      tl_gemm<4, 2, LDW256>(sW2 + ht * 32, hreg, acc2, n0, hb);
+    }
+    if (yout && valid) {
+      float y[32];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[16 * nt + r] = acc2[nt][r];
+      store_slots(yout + tok * 64, y, hb);
+    }
+    if (vt_out) {
+      float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc + 8 * q + 4 * hb);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wc + 64 + 8 * q + 4 * hb);
+        const f32x4 w2 = *reinterpret_cast<const f32x4*>(Wc + 128 + 8 * q + 4 * hb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int s = 4 * q + i;
+          const float yv = acc2[s >> 4][s & 15];
+          d0 += w0[i] * yv;
+          d1 += w1[i] * yv;
+          d2 += w2[i] * yv;
+        }
+      }
+      d0 = pair_sum(d0);
+      d1 = pair_sum(d1);
+      d2 = pair_sum(d2);
+      if (valid && hb == 0) {
+        const float* pi = vt_in + tok * 3;
+        float* po = vt_out + tok * 3;
+        po[0] = (d0 + bc[0]) + pi[0];
+        po[1] = (d1 + bc[1]) + pi[1];
+        po[2] = (d2 + bc[2]) + pi[2];
+      }
+    }
+  }
+}
+
+// ======================================================================================================
+// adaln_qkv: qkv[tok][0:192] = Wqkv * AdaLN(x) + bqkv   (vertex self-attention input, CoevoDecoder.py:103,120)
+// ======================================================================================================
+__global__ __launch_bounds__(256) void adaln_qkv_kernel(const float* __restrict__ xin, const float* __restrict__ GB,
+                                                        int gb_stride, int inst, const float* __restrict__ Wqkv,
+                                                        const float* __restrict__ bqkv, float* __restrict__ qkv, int B) {
+  __shared__ __attribute__((aligned(16))) float sW[192 * LDW64];
+  __shared__ float sB[192];
+  const int tid = threadIdx.x;
+  stage_weight<64>(sW, Wqkv, 192, tid, 256);
+  if (tid < 192) sB[tid] = bqkv[tid];
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n0 = lane & 31, hb = lane >> 5;
+  const int ntiles = B * NTILE;
+  for (int wt = blockIdx.x * 4 + wave; wt < ntiles; wt += gridDim.x * 4) {
+    const int b = wt / NTILE, tile = wt % NTILE;
+    const int v = tile * 32 + n0;
+    const bool valid = v < NV;
+    const long long tok = (long long)b * NV + (valid ? v : NV - 1);
+    float x[32], a[32];
+    load_slots(xin + tok * 64, x, hb);
+    adaln_slots(x, a, GB + (long long)b * gb_stride + inst * 128, hb);
+    f32x16 acc[6];
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = sB[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb];
+    tl_gemm<8, 6, LDW64>(sW, a, acc, n0, hb);
+    if (valid) {
+      float* dst = qkv + tok * 192;
+#pragma unroll
+      for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 t;
+          t.x = acc[nt][4 * g + 0];
+          t.y = acc[nt][4 * g + 1];
+          t.z = acc[nt][4 * g + 2];
+          t.w = acc[nt][4 * g + 3];
+          *reinterpret_cast<f32x4*>(dst + nt * 32 + 8 * g + 4 * hb) = t;
+        }
+    }
+  }
+}
+
+// ======================================================================================================
+// vertex_sa: y = x + proj(softmax(q k^T / sqrt(32)) v), 2 heads x 32, 431 x 431 per clip (CoevoDecoder.py:118-131).
+// grid (2, B) x 448 threads: wave w owns query tile blockIdx.x*7+w for BOTH heads; the 14 key tiles (32 keys x
+// {k,v} x 64 ch) stream through a double-buffered LDS ring shared by the 7 waves.  S^T = K Q^T puts one query
+// per lane pair, so the online softmax is in-lane; P^T is reused directly as the B operand of O^T += V^T P^T.
+// ======================================================================================================
+#define SA_KLD 68
+#define SA_VLD 64
+__global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict__ xin, const float* __restrict__ qkv,
+                                                        const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                        float* __restrict__ yout) {
+  __shared__ __attribute__((aligned(16))) float sK[2][32 * SA_KLD];
+  __shared__ __attribute__((aligned(16))) float sVv[2][32 * SA_VLD];
+  __shared__ __attribute__((aligned(16))) float sWp[64 * LDW64];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n0 = lane & 31, hb = lane >> 5;
+  const float* qkv_b = qkv + (long long)b * NV * 192;
+  stage_weight<64>(sWp, Wp, 64, tid, 448);
+
+  // staging assignment: 32 rows x 32 float4 (16 of k, 16 of v) = 1024 float4 per key tile
+  f32x4 pre[3];
+  auto gload = [&](int jt) {
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int idx = tid + it * 448;
+      if (idx < 1024) {
+        const int rr = idx >> 5, c4 = idx & 31;
+        const int j = jt * 32 + rr;
+        pre[it] = (j < NV) ? *reinterpret_cast<const f32x4*>(qkv_b + (long long)j * 192 + 64 + 4 * c4)
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int idx = tid + it * 448;
+      if (idx < 1024) {
+        const int rr = idx >> 5, c4 = idx & 31;
+        if (c4 < 16)
+          *reinterpret_cast<f32x4*>(&sK[buf][rr * SA_KLD + 4 * c4]) = pre[it];
+        else
+          *reinterpret_cast<f32x4*>(&sVv[buf][rr * SA_VLD + 4 * (c4 - 16)]) = pre[it];
+      }
+    }
+  };
+
+  const int qtile = blockIdx.x * 7 + wave;
+  const int v = qtile * 32 + n0;
+  const bool valid = v < NV;
+  const long long tok = (long long)b * NV + (valid ? v : NV - 1);
+  float q[32];
+  load_slots(qkv + tok * 192, q, hb);
+  const float scale = 0.17677669529663688110f;  // 32^-0.5
+#pragma unroll
+  for (int s = 0; s < 32; ++s) q[s] *= scale;
+
+  f32x16 O[2];
+  float mrun[2], lrun[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    mrun[h] = -INFINITY;
+    lrun[h] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[h][r] = 0.f;
+  }
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int jt = 0; jt < NTILE; ++jt) {
+    const int buf = jt & 1;
+    if (jt + 1 < NTILE) gload(jt + 1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x16 S;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[r] = 0.f;
+      tl_gemm<4, 1, SA_KLD>(&sK[buf][32 * h], q + 16 * h, &S, n0, hb);
+      float mt = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
+        const float sv = (j < NV) ? S[r] : -INFINITY;
+        S[r] = sv;
+        mt = fmaxf(mt, sv);
+      }
+      mt = pair_max(mt);
+      const float mn = fmaxf(mrun[h], mt);
+      const float corr = expf(mrun[h] - mn);
+      float pr[16], sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pr[r] = expf(S[r] - mn);
+        sum += pr[r];
+      }
+      lrun[h] = lrun[h] * corr + pair_sum(sum);
+      mrun[h] = mn;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[h][r] *= corr;
+      const float* vb = &sVv[buf][4 * hb * SA_VLD + 32 * h + n0];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float a = vb[((s & 3) + 8 * (s >> 2)) * SA_VLD];
+        O[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pr[s], O[h], 0, 0, 0);
+      }
+    }
+    if (jt + 1 < NTILE) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  float att[32];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float inv = 1.0f / lrun[h];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) att[16 * h + r] = O[h][r] * inv;
+  }
+  float x[32];
+  load_slots(xin + tok * 64, x, hb);
+  f32x16 acc[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = bp[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb] + x[16 * nt + r];
+  tl_gemm<8, 2, LDW64>(sWp, att, acc, n0, hb);
+  if (valid) {
+    float y[32];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y[16 * nt + r] = acc[nt][r];
+    store_slots(yout + tok * 64, y, hb);
+  }
+}
+
+// ======================================================================================================
+// tokens_kv (joint<-vertex direction, live in coevoblock3 only):
+//   kv[tok][0:64]   = Wk * AdaLN_k(xk) + bk     xk = proj_v2j_dim(vf) + v2j_K_embed   (CoevoDecoder.py:183)
+//   kv[tok][64:128] = Wv * AdaLN_v(xv) + bv     xv = vf
+// Generic form: xk/xv given ([B,431,64]).  Fused form (xk == nullptr): vf = Wv3*vt + Ev[v] formed on the fly
+// (Ev = vertx_proj.bias + vertx_pos_embed) and xk = Wv2j*vf + Ek[v] (Ek = proj_v2j_dim.bias + v2j_K_embed).
+// ======================================================================================================
+__global__ __launch_bounds__(256) void tokens_kv_kernel(const float* __restrict__ xk_in, const float* __restrict__ xv_in,
+                                                        const float* __restrict__ vt, const float* __restrict__ Wv3,
+                                                        const float* __restrict__ Ev, const float* __restrict__ Wv2j,
+                                                        const float* __restrict__ Ek, const float* __restrict__ GB,
+                                                        int gb_stride, int ik, int iv, const float* __restrict__ Wk,
+                                                        const float* __restrict__ bk, const float* __restrict__ Wv,
+                                                        const float* __restrict__ bv, float* __restrict__ kv, int B) {
+  __shared__ __attribute__((aligned(16))) float sWk[64 * LDW64];
+  __shared__ __attribute__((aligned(16))) float sWv[64 * LDW64];
+  __shared__ __attribute__((aligned(16))) float sW2[64 * LDW64];
+  const int tid = threadIdx.x;
+  stage_weight<64>(sWk, Wk, 64, tid, 256);
+  stage_weight<64>(sWv, Wv, 64, tid, 256);
+  if (!xk_in) stage_weight<64>(sW2, Wv2j, 64, tid, 256);
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n0 = lane & 31, hb = lane >> 5;
+  const int ntiles = B * NTILE;
+  for (int wt = blockIdx.x * 4 + wave; wt < ntiles; wt += gridDim.x * 4) {
+    const int b = wt / NTILE, tile = wt % NTILE;
+    const int v = tile * 32 + n0;
+    const bool valid = v < NV;
+    const int vc = valid ? v : NV - 1;
+    const long long tok = (long long)b * NV + vc;
+    float xk[32], xv[32];
+    if (xk_in) {
+      load_slots(xk_in + tok * 64, xk, hb);
+      load_slots(xv_in + tok * 64, xv, hb);
+    } else {
+      const float* p = vt + tok * 3;
+      const float p0 = p[0], p1 = p[1], p2 = p[2];
+      load_slots(Ev + (long long)vc * 64, xv, hb);
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        const int c = slot_channel(s, hb);
+        xv[s] = (Wv3[c * 3] * p0 + Wv3[c * 3 + 1] * p1 + Wv3[c * 3 + 2] * p2) + xv[s];
+      }
+      float e[32];
+      load_slots(Ek + (long long)vc * 64, e, hb);
+      f32x16 t[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[nt][r] = e[16 * nt + r];
+      tl_gemm<8, 2, LDW64>(sW2, xv, t, n0, hb);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xk[16 * nt + r] = t[nt][r];
+    }
+    const float* gb = GB + (long long)b * gb_stride;
+    float a[32];
+    f32x16 acc[2];
+    // k
+    adaln_slots(xk, a, gb + ik * 128, hb);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = bk[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb];
+    tl_gemm<8, 2, LDW64>(sWk, a, acc, n0, hb);
+    if (valid) {
+      float y[32];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[16 * nt + r] = acc[nt][r];
+      store_slots(kv + tok * 128, y, hb);
+    }
+    // v
+    adaln_slots(xv, a, gb + iv * 128, hb);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = bv[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb];
+    tl_gemm<8, 2, LDW64>(sWv, a, acc, n0, hb);
+    if (valid) {
+      float y[32];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[16 * nt + r] = acc[nt][r];
+      store_slots(kv + tok * 128 + 64, y, hb);
+    }
+  }
+}
+
+// ======================================================================================================
+// joint_stream: the joint side of coevoblock3, one workgroup per clip (J <= 32 tokens; ~4 MFLOP, VALU).
+//   y = xq + proj(softmax(q K^T / sqrt(8)) V) over the 431 vertex keys, 8 heads of 8     (joint_CA_FFN, :83)
+//   stage 1 stops here (standalone cross-attention op).  Otherwise:
+//   y += Mlp(AdaLN(y)) ; y += SA(AdaLN(y)) (8 heads over J) ; y += Mlp(AdaLN(y)) ; cam_pose = Wc*y + bc + jt
+// ======================================================================================================
+struct JointStreamW {
+  const float *wq, *bq, *proj_w, *proj_b;                       // joint_CA_FFN.attn
+  const float *fc1_w, *fc1_b, *fc2_w, *fc2_b;                   // joint_CA_FFN.mlp
+  const float *qkv_w, *qkv_b, *sproj_w, *sproj_b;               // joint_SA_FFN.attn
+  const float *sfc1_w, *sfc1_b, *sfc2_w, *sfc2_b;               // joint_SA_FFN.mlp
+  const float *coor_w, *coor_b;                                 // proj_joint_feat2coor
+  int i_normq, i_norm2, i_snorm1, i_snorm2;                     // AdaLN instance indices into GB
+};
+
+__global__ __launch_bounds__(256) void joint_stream_kernel(const float* __restrict__ xq_in, const float* __restrict__ jQ,
+                                                           const float* __restrict__ kv, const float* __restrict__ GB,
+                                                           int gb_stride, JointStreamW w, const float* __restrict__ jt,
+                                                           float* __restrict__ y_out, float* __restrict__ pose_out, int J,
+                                                           int stage) {
+  __shared__ float s_y[32 * JLD];
+  __shared__ float s_a[32 * JLD];
+  __shared__ float s_q[32 * JLD];
+  __shared__ __attribute__((aligned(16))) float s_h[32 * 257];   // MLP hidden / qkv scratch (>= 32*193)
+  __shared__ __attribute__((aligned(16))) float s_kv[64 * 128];  // one tile of 64 vertex keys: k | v
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* gb = GB + (long long)b * gb_stride;
+  for (int idx = tid; idx < J * 64; idx += 256) {
+    const int i = idx >> 6, c = idx & 63;
+    float v = xq_in[((long long)b * J + i) * 64 + c];
+    if (jQ) v += jQ[i * 64 + c];
+    s_y[i * JLD + c] = v;
+  }
+  __syncthreads();
+  adaln_small(s_y, s_a, gb + w.i_normq * 128, J, tid);
+  __syncthreads();
+  lin_small<64, 64>(s_a, JLD, w.wq, w.bq, s_q, JLD, J, tid, false);
+  __syncthreads();
+  // ---- attention over 431 keys: thread (i,h) for i<J, h<8 (J*8 <= 256) ----
+  {
+    const int i = tid >> 3, h = tid & 7;
+    const bool act = i < J;
+    float qv[8], o[8];
+    const float scale = 0.35355339059327376220f;  // 8^-0.5 (joint heads = 8, head_dim 8)
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      qv[d] = act ? s_q[i * JLD + 8 * h + d] * scale : 0.f;
+      o[d] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+    const float* kvb = kv + (long long)b * NV * 128;
+    for (int j0 = 0; j0 < NV; j0 += 64) {
+      const int nj = min(64, NV - j0);
+      __syncthreads();
+      for (int idx = tid; idx < nj * 32; idx += 256) {
+        const int r = idx >> 5, c4 = idx & 31;
+        *reinterpret_cast<f32x4*>(&s_kv[r * 128 + 4 * c4]) =
+            *reinterpret_cast<const f32x4*>(kvb + (long long)(j0 + r) * 128 + 4 * c4);
+      }
+      __syncthreads();
+      if (act) {
+        for (int r = 0; r < nj; ++r) {
+          const f32x4 k0 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 8 * h]);
+          const f32x4 k1 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 8 * h + 4]);
+          const float sc = qv[0] * k0.x + qv[1] * k0.y + qv[2] * k0.z + qv[3] * k0.w + qv[4] * k1.x + qv[5] * k1.y +
+                           qv[6] * k1.z + qv[7] * k1.w;
+          const float mn = fmaxf(m, sc);
+          const float corr = expf(m - mn), pj = expf(sc - mn);
+          l = l * corr + pj;
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 64 + 8 * h]);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 64 + 8 * h + 4]);
+          o[0] = o[0] * corr + pj * v0.x;
+          o[1] = o[1] * corr + pj * v0.y;
+          o[2] = o[2] * corr + pj * v0.z;
+          o[3] = o[3] * corr + pj * v0.w;
+          o[4] = o[4] * corr + pj * v1.x;
+          o[5] = o[5] * corr + pj * v1.y;
+          o[6] = o[6] * corr + pj * v1.z;
+          o[7] = o[7] * corr + pj * v1.w;
+          m = mn;
+        }
+      }
+    }
+    if (act) {
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) s_a[i * JLD + 8 * h + d] = o[d] * inv;
+    }
+  }
+  __syncthreads();
+  lin_small<64, 64>(s_a, JLD, w.proj_w, w.proj_b, s_q, JLD, J, tid, false);
+  __syncthreads();
+  for (int idx = tid; idx < J * 64; idx += 256) {
+    const int i = idx >> 6, c = idx & 63;
+    s_y[i * JLD + c] += s_q[i * JLD + c];
+  }
+  __syncthreads();
+  if (stage == 1) {
+    for (int idx = tid; idx < J * 64; idx += 256) y_out[(long long)b * J * 64 + idx] = s_y[(idx >> 6) * JLD + (idx & 63)];
+    return;
+  }
+  // ---- FFN of the cross-attention block ----
+  adaln_small(s_y, s_a, gb + w.i_norm2 * 128, J, tid);
+  __syncthreads();
+  lin_small<64, 256>(s_a, JLD, w.fc1_w, w.fc1_b, s_h, 257, J, tid, true);
+  __syncthreads();
+  lin_small<256, 64>(s_h, 257, w.fc2_w, w.fc2_b, s_q, JLD, J, tid, false);
+  __syncthreads();
+  for (int idx = tid; idx < J * 64; idx += 256) {
+    const int i = idx >> 6, c = idx & 63;
+    s_y[i * JLD + c] += s_q[i * JLD + c];
+  }
+  __syncthreads();
+  if (stage == 2) {
+    for (int idx = tid; idx < J * 64; idx += 256) y_out[(long long)b * J * 64 + idx] = s_y[(idx >> 6) * JLD + (idx & 63)];
+    return;
+  }
+  // ---- self-attention block over the J joint tokens (8 heads of 8) ----
+  adaln_small(s_y, s_a, gb + w.i_snorm1 * 128, J, tid);
+  __syncthreads();
+  lin_small<64, 192>(s_a, JLD, w.qkv_w, w.qkv_b, s_h, 193, J, tid, false);
+  __syncthreads();
+  {
+    const int i = tid >> 3, h = tid & 7;
+    if (i < J) {
+      const float scale = 0.35355339059327376220f;
+      float qv[8], o[8];
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        qv[d] = s_h[i * 193 + 8 * h + d] * scale;
+        o[d] = 0.f;
+      }
+      float m = -INFINITY, l = 0.f;
+      for (int j = 0; j < J; ++j) {
+        float sc = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) sc += qv[d] * s_h[j * 193 + 64 + 8 * h + d];
+        const float mn = fmaxf(m, sc);
+        const float corr = expf(m - mn), pj = expf(sc - mn);
+        l = l * corr + pj;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) o[d] = o[d] * corr + pj * s_h[j * 193 + 128 + 8 * h + d];
+        m = mn;
+      }
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) s_a[i * JLD + 8 * h + d] = o[d] * inv;
+    }
+  }
+  __syncthreads();
+  lin_small<64, 64>(s_a, JLD, w.sproj_w, w.sproj_b, s_q, JLD, J, tid, false);
+  __syncthreads();
+  for (int idx = tid; idx < J * 64; idx += 256) {
+    const int i = idx >> 6, c = idx & 63;
+    s_y[i * JLD + c] += s_q[i * JLD + c];
+  }
+  __syncthreads();
+  adaln_small(s_y, s_a, gb + w.i_snorm2 * 128, J, tid);
+  __syncthreads();
+  lin_small<64, 256>(s_a, JLD, w.sfc1_w, w.sfc1_b, s_h, 257, J, tid, true);
+  __syncthreads();
+  lin_small<256, 64>(s_h, 257, w.sfc2_w, w.sfc2_b, s_q, JLD, J, tid, false);
+  __syncthreads();
+  for (int idx = tid; idx < J * 64; idx += 256) {
+    const int i = idx >> 6, c = idx & 63;
+    s_y[i * JLD + c] += s_q[i * JLD + c];
+  }
+  __syncthreads();
+  if (y_out)
+    for (int idx = tid; idx < J * 64; idx += 256) y_out[(long long)b * J * 64 + idx] = s_y[(idx >> 6) * JLD + (idx & 63)];
+  // ---- proj_joint_feat2coor + residual on the ORIGINAL joints (CoevoDecoder.py:189) ----
+  if (pose_out) {
+    for (int idx = tid; idx < J * 3; idx += 256) {
+      const int i = idx / 3, k = idx % 3;
+      float s = 0.f;
+      for (int c = 0; c < 64; ++c) s += w.coor_w[k * 64 + c] * s_y[i * JLD + c];
+      pose_out[((long long)b * J + i) * 3 + k] = (s + w.coor_b[k]) + jt[((long long)b * J + i) * 3 + k];
+    }
+  }
+}
+
+// ======================================================================================================
+// tail: build the packed operand of the final GEMM and the J_regressor projection
+// ======================================================================================================
+// A'[b][0:2048] = relu(g[b]) ; A'[b][2048 + 3v + l] = vt[b][v][l] ; A'[b][3341:KP] = 0   (CoevoDecoder.py:238-244)
+__global__ __launch_bounds__(256) void build_final_operand_kernel(const float* __restrict__ g, const float* __restrict__ vt,
+                                                                  float* __restrict__ A, int B, int KP) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * KP) return;
+  const int b = (int)(idx / KP), k = (int)(idx % KP);
+  float v = 0.f;
+  if (k < 2048)
+    v = fmaxf(g[(long long)b * 2048 + k], 0.f);
+  else if (k < 2048 + NV * 3)
+    v = vt[(long long)b * NV * 3 + (k - 2048)];
+  A[idx] = v;
+}
+
+// joints_mm[b][j][l] = sum_nz data * (mesh[b][col][l] * 1000)   (lib/core/base.py:223-225), CSR regressor
+__global__ __launch_bounds__(256) void j_regress_kernel(const float* __restrict__ mesh, const int* __restrict__ indptr,
+                                                        const int* __restrict__ indices, const float* __restrict__ data,
+                                                        float* __restrict__ out, int B, int R, int NVF, float scale) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * R * 3) return;
+  const int l = idx % 3, j = (idx / 3) % R, b = idx / (3 * R);
+  const float* m = mesh + (long long)b * NVF * 3;
+  float s = 0.f;
+  for (int e = indptr[j]; e < indptr[j + 1]; ++e) s += data[e] * (m[(long long)indices[e] * 3 + l] * scale);
+  out[idx] = s;
+}
+
+// ======================================================================================================
+// C-ABI launchers
+// ======================================================================================================
+static int mlp_grid(int B) {
+  const int tiles = B * NTILE;
+  int g = (tiles + 3) / 4;
+  return g < 256 ? g : 256;
+}
+static int tl_grid(int B, int per_cu) {
+  const int tiles = B * NTILE;
+  int g = (tiles + 3) / 4;
+  const int cap = 256 * per_cu;
+  return g < cap ? g : cap;
+}
+
+extern "C" int pmce_vertex_init_gather_f32(const float* joints, const int* vj, float* vt, int B, int J, hipStream_t stream) {
+  PMCE_REQUIRE(joints && vj && vt && B > 0 && J > 0, "vertex_init_gather: bad args");
+  const int n = B * NV * 3;
+  hipLaunchKernelGGL(vertex_init_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, joints, vj, vt, B, J);
+  return pmce_check_launch("vertex_init_gather");
+}
+
+extern "C" int pmce_joint_embed_f32(const float* jt, const float* Wj, const float* bj, const float* jpos, const float* Wj2v,
+                                    const float* bj2v, const float* j2vK, float* jf, float* xk, int B, int J,
+                                    hipStream_t stream) {
+  PMCE_REQUIRE(J >= 1 && J <= 32 && B > 0, "joint_embed: J must be in 1..32");
+  hipLaunchKernelGGL(joint_embed_kernel, dim3(B), dim3(256), 0, stream, jt, Wj, bj, jpos, Wj2v, bj2v, j2vK, jf, xk, J);
+  return pmce_check_launch("joint_embed");
+}
+
+extern "C" int pmce_ca_fold_f32(const float* xk, const float* xv, const float* GB, int gb_stride, int iq, int ik, int iv,
+                                const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv,
+                                const float* bv, const float* Wp, float* Kf, float* s0, float* Vf, int B, int J,
+                                hipStream_t stream) {
+  PMCE_REQUIRE(J >= 1 && J <= 32 && B > 0, "ca_fold: J must be in 1..32");
+  hipLaunchKernelGGL(ca_fold_kernel, dim3(B), dim3(256), 0, stream, xk, xv, GB, gb_stride, iq, ik, iv, Wq, bq, Wk, bk, Wv, bv,
+                     Wp, Kf, s0, Vf, J);
+  return pmce_check_launch("ca_fold");
+}
+
+extern "C" int pmce_vertex_ca_f32(const float* xq, const float* vt, const float* Wv3, const float* Eq, const float* Kf,
+                                  const float* s0, const float* Vf, const float* bp, float* out, int B, int J,
+                                  hipStream_t stream) {
+  PMCE_REQUIRE((xq || (vt && Wv3 && Eq)) && Kf && s0 && Vf && bp && out, "vertex_ca: null pointer");
+  PMCE_REQUIRE(J >= 1 && J <= 32 && B > 0, "vertex_ca: J must be in 1..32");
+  hipLaunchKernelGGL(vertex_ca_kernel, dim3(2, B), dim3(512), 0, stream, xq, vt, Wv3, Eq, Kf, s0, Vf, bp, out, J);
+  return pmce_check_launch("vertex_ca");
+}
+
+extern "C" int pmce_adaln_mlp_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* W1,
+                                  const float* b1, const float* W2, const float* b2, float* yout, const float* Wc,
+                                  const float* bc, const float* vt_in, float* vt_out, int B, hipStream_t stream) {
+  PMCE_REQUIRE(xin && GB && W1 && b1 && W2 && b2 && (yout || vt_out), "adaln_mlp: null pointer");
+  PMCE_REQUIRE(!vt_out || (Wc && bc && vt_in), "adaln_mlp: coordinate head needs Wc, bc, vt_in");
+  const size_t lds = (size_t)(256 * LDW64 + 64 * LDW256 + 256 + 64) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)adaln_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(adaln_mlp_kernel, dim3(mlp_grid(B)), dim3(256), lds, stream, xin, GB, gb_stride, inst, W1, b1, W2, b2,
+                     yout, Wc, bc, vt_in, vt_out, B);
+  return pmce_check_launch("adaln_mlp");
+}
+
+extern "C" int pmce_adaln_qkv_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* Wqkv,
+                                  const float* bqkv, float* qkv, int B, hipStream_t stream) {
+  PMCE_REQUIRE(xin && GB && Wqkv && bqkv && qkv && B > 0, "adaln_qkv: null pointer");
+  hipLaunchKernelGGL(adaln_qkv_kernel, dim3(tl_grid(B, 2)), dim3(256), 0, stream, xin, GB, gb_stride, inst, Wqkv, bqkv, qkv, B);
+  return pmce_check_launch("adaln_qkv");
+}
+
+extern "C" int pmce_vertex_sa_f32(const float* xin, const float* qkv, const float* Wp, const float* bp, float* yout, int B,
+                                  hipStream_t stream) {
+  PMCE_REQUIRE(xin && qkv && Wp && bp && yout && B > 0, "vertex_sa: null pointer");
+  hipLaunchKernelGGL(vertex_sa_kernel, dim3(2, B), dim3(448), 0, stream, xin, qkv, Wp, bp, yout);
+  return pmce_check_launch("vertex_sa");
+}
+
+extern "C" int pmce_tokens_kv_f32(const float* xk, const float* xv, const float* vt, const float* Wv3, const float* Ev,
+                                  const float* Wv2j, const float* Ek, const float* GB, int gb_stride, int ik, int iv,
+                                  const float* Wk, const float* bk, const float* Wv, const float* bv, float* kv, int B,
+                                  hipStream_t stream) {
+  PMCE_REQUIRE(((xk && xv) || (vt && Wv3 && Ev && Wv2j && Ek)) && GB && Wk && bk && Wv && bv && kv, "tokens_kv: null pointer");
+  hipLaunchKernelGGL(tokens_kv_kernel, dim3(tl_grid(B, 2)), dim3(256), 0, stream, xk, xv, vt, Wv3, Ev, Wv2j, Ek, GB, gb_stride,
+                     ik, iv, Wk, bk, Wv, bv, kv, B);
+  return pmce_check_launch("tokens_kv");
+}
+
+extern "C" int pmce_joint_stream_f32(const float* xq, const float* jQ, const float* kv, const float* GB, int gb_stride,
+                                     const float* const* wptr, const int* inst, const float* jt, float* y_out,
+                                     float* pose_out, int B, int J, int stage, hipStream_t stream) {
+  PMCE_REQUIRE(xq && kv && GB && wptr && inst, "joint_stream: null pointer");
+  PMCE_REQUIRE(J >= 1 && J <= 32 && B > 0, "joint_stream: J must be in 1..32");
+  PMCE_REQUIRE(stage >= 1 && stage <= 3, "joint_stream: stage must be 1 (CA), 2 (CA+FFN) or 3 (full)");
+  JointStreamW w;
+  w.wq = wptr[0]; w.bq = wptr[1]; w.proj_w = wptr[2]; w.proj_b = wptr[3];
+  w.fc1_w = wptr[4]; w.fc1_b = wptr[5]; w.fc2_w = wptr[6]; w.fc2_b = wptr[7];
+  w.qkv_w = wptr[8]; w.qkv_b = wptr[9]; w.sproj_w = wptr[10]; w.sproj_b = wptr[11];
+  w.sfc1_w = wptr[12]; w.sfc1_b = wptr[13]; w.sfc2_w = wptr[14]; w.sfc2_b = wptr[15];
+  w.coor_w = wptr[16]; w.coor_b = wptr[17];
+  w.i_normq = inst[0]; w.i_norm2 = inst[1]; w.i_snorm1 = inst[2]; w.i_snorm2 = inst[3];
+  hipLaunchKernelGGL(joint_stream_kernel, dim3(B), dim3(256), 0, stream, xq, jQ, kv, GB, gb_stride, w, jt, y_out, pose_out, J,
+                     stage);
+  return pmce_check_launch("joint_stream");
+}
+
+extern "C" int pmce_build_final_operand_f32(const float* g, const float* vt, float* A, int B, int KP, hipStream_t stream) {
+  PMCE_REQUIRE(g && vt && A && KP >= 2048 + NV * 3, "build_final_operand: bad args");
+  const long long n = (long long)B * KP;
+  hipLaunchKernelGGL(build_final_operand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, vt, A, B, KP);
+  return pmce_check_launch("build_final_operand");
+}
+
+extern "C" int pmce_j_regress_f32(const float* mesh, const int* indptr, const int* indices, const float* data, float* out,
+                                  int B, int R, int NVF, float scale, hipStream_t stream) {
+  PMCE_REQUIRE(mesh && indptr && indices && data && out && B > 0 && R > 0, "j_regress: bad args");
+  const int n = B * R * 3;
+  hipLaunchKernelGGL(j_regress_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, mesh, indptr, indices, data, out, B, R, NVF,
+                     scale);
+  return pmce_check_launch("j_regress");
+}

@@ -1,0 +1,26 @@
+// Host-side error slot + version for libpmce_hip.so (no global mutable state besides a thread-local string).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.hpp"
+
+static thread_local char g_err[512] = "";
+
+void pmce_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int pmce_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    pmce_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return PMCE_ERR_LAUNCH;
+  }
+  return PMCE_OK;
+}
+
+extern "C" const char* pmce_last_error_string(void) { return g_err; }
+extern "C" int pmce_version(void) { return 100; }  // 0.1.0

@@ -1,0 +1,137 @@
+// Shared device/host helpers for the PMCE hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PMCE_OK 0
+#define PMCE_ERR_ARG (-1)
+#define PMCE_ERR_LAUNCH (-2)
+#define PMCE_ERR_WORKSPACE (-3)
+
+// host-side error slot (thread-local; pmce_last_error_string() returns it)
+void pmce_set_error(const char* fmt, ...);
+int pmce_check_launch(const char* what);
+
+#define PMCE_REQUIRE(cond, ...)                \
+  do {                                         \
+    if (!(cond)) {                             \
+      pmce_set_error(__VA_ARGS__);             \
+      return PMCE_ERR_ARG;                     \
+    }                                          \
+  } while (0)
+
+#define PMCE_TRY(expr)              \
+  do {                              \
+    int _rc = (expr);               \
+    if (_rc != PMCE_OK) return _rc; \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// "slot layout" of a 64-channel token held by a lane PAIR (l, l+32) of one wavefront
+// ---------------------------------------------------------------------------------------------
+// lane = (tok = lane & 31, hb = lane >> 5).  Register slot s in [0,32) of lane (tok,hb) holds channel
+//     c = 8*(s>>2) + 4*hb + (s&3)
+// i.e. the lane owns the eight 16-byte chunks {8q+4hb .. 8q+4hb+3}, q = 0..7, of the token's 256-byte
+// row; the pair covers the row.  This is at once
+//   * the B-operand order of v_mfma_f32_32x32x2_f32 for a K=64 contraction (step s uses slot s of both
+//     halves: k-pair = {slot s of hb=0, slot s of hb=1}), and
+//   * the C/D layout of a 32-row output tile whose rows are channels and whose columns are tokens
+//     (row = (r&3) + 8*(r>>2) + 4*hb for accumulator register r; tile nt, register r == slot 16*nt+r),
+// so the output of one token-local GEMM is directly the B operand of the next: no LDS round trip.
+__device__ __forceinline__ int slot_channel(int s, int hb) { return 8 * (s >> 2) + 4 * hb + (s & 3); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float pair_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+
+// One token-local GEMM step group: acc[nt] += W[nt*32 + n0][k-slots] * x[slots], K = 8*KQ.
+// Wl: LDS, row-major [rows][LDW] floats with LDW = K + 4 (conflict-free ds_read_b128).
+template <int KQ, int NT, int LDW>
+__device__ __forceinline__ void tl_gemm(const float* __restrict__ Wl, const float* x, f32x16* acc, int n0, int hb) {
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(Wl + (nt * 32 + n0) * LDW + 8 * q + 4 * hb);
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, x[4 * q + 0], acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, x[4 * q + 1], acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, x[4 * q + 2], acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, x[4 * q + 3], acc[nt], 0, 0, 0);
+    }
+  }
+}
+
+// Cooperative copy of a row-major [rows][K] global matrix into LDS [rows][K+4].
+template <int K>
+__device__ __forceinline__ void stage_weight(float* __restrict__ dst, const float* __restrict__ src, int rows, int tid,
+                                             int nthreads) {
+  constexpr int C4 = K / 4;
+  for (int i = tid; i < rows * C4; i += nthreads) {
+    const int r = i / C4, c = i % C4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)r * K + 4 * c);
+    *reinterpret_cast<f32x4*>(dst + r * (K + 4) + 4 * c) = v;
+  }
+}
+
+// AdaLayerNorm on a slot-layout token (reference CoevoDecoder.py:23-29): unbiased std, eps on the std.
+// gb points at this clip's [gamma(64) | beta(64)] for the instance.
+__device__ __forceinline__ void adaln_slots(const float* x, float* y, const float* __restrict__ gb, int hb) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) s += x[i];
+  const float mean = pair_sum(s) * (1.0f / 64.0f);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const float d = x[i] - mean;
+    ss += d * d;
+  }
+  const float var = pair_sum(ss) * (1.0f / 63.0f);
+  const float inv = 1.0f / (sqrtf(var) + 1e-6f);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gb + 8 * q + 4 * hb);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(gb + 64 + 8 * q + 4 * hb);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[4 * q + i] = g[i] * (x[4 * q + i] - mean) * inv + b[i];
+  }
+}
+
+// load / store a 64-channel row in slot layout (8 x 16-byte chunks per lane)
+__device__ __forceinline__ void load_slots(const float* __restrict__ row, float* x, int hb) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + 8 * q + 4 * hb);
+    x[4 * q + 0] = v.x;
+    x[4 * q + 1] = v.y;
+    x[4 * q + 2] = v.z;
+    x[4 * q + 3] = v.w;
+  }
+}
+__device__ __forceinline__ void store_slots(float* __restrict__ row, const float* x, int hb) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    f32x4 v;
+    v.x = x[4 * q + 0];
+    v.y = x[4 * q + 1];
+    v.z = x[4 * q + 2];
+    v.w = x[4 * q + 3];
+    *reinterpret_cast<f32x4*>(row + 8 * q + 4 * hb) = v;
+  }
+}

@@ -1,0 +1,315 @@
+// Temporal pose encoder ("lifter") kernels other than the Linear layers (those are gemm_f32.hip).
+// Reference: lib/models/PoseEstimation.py (GraphormerNet) + timm Attention.
+//
+// Activations keep ONE layout for the whole encoder: x[b][t][j][c] (token = (b*T+t)*J + j).  The reference's
+// '(b t) j c <-> (b j) t c' rearranges (PoseEstimation.py:87,101,104,109; 32 % of its CPU time) never
+// happen: only the attention kernel needs to know which tokens form a sequence, and it gets that as strides.
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------------------------------
+// token embedding  (PoseEstimation.py:78-81)
+//   x[tok][c] = Wje[c][0]*p0 + Wje[c][1]*p1 + bje[c] + E[b*T+t][c] + spos[j][c]
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const float* __restrict__ pose2d, const float* __restrict__ E,
+                                                           const float* __restrict__ Wje, const float* __restrict__ bje,
+                                                           const float* __restrict__ spos, float* __restrict__ x,
+                                                           long long ntok, int J, int C) {
+  const int c4n = C >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ntok * c4n) return;
+  const long long tok = idx / c4n;
+  const int c = (int)(idx % c4n) * 4;
+  const long long bt = tok / J;
+  const int j = (int)(tok % J);
+  const float p0 = pose2d[tok * 2 + 0], p1 = pose2d[tok * 2 + 1];
+  const f32x4 e = *reinterpret_cast<const f32x4*>(E + bt * C + c);
+  const f32x4 sp = *reinterpret_cast<const f32x4*>(spos + (long long)j * C + c);
+  const f32x4 bj = *reinterpret_cast<const f32x4*>(bje + c);
+  f32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // same association as the reference: (joint_embed(x)) + imgfeat_embed + spatial_pos
+    const float je = Wje[(c + i) * 2 + 0] * p0 + Wje[(c + i) * 2 + 1] * p1 + bj[i];
+    o[i] = (je + e[i]) + sp[i];
+  }
+  *reinterpret_cast<f32x4*>(x + tok * C + c) = o;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// LayerNorm chain, one wavefront per token row:
+//   y1 = w1 ? LN(x; w1,b1,eps1) : x ;  y1 += add[(row / add_div) % add_mod]   (temporal_pos_embed, :88)
+//   out1 = y1 (if out1) ;  out2 = LN(y1; w2,b2,eps2) (if out2)
+// covers norm_s/norm_t (shared across depth, eps 1e-6, :38,84,92) fused with the NEXT block's norm1/norm2.
+// ------------------------------------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ void ln_regs(float* v, const float* __restrict__ w, const float* __restrict__ b, float eps,
+                                        int lane) {
+  constexpr int NV = C / 64;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += v[i];
+  const float mean = wave_sum(s) * (1.0f / C);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float d = v[i] - mean;
+    ss += d * d;
+  }
+  const float var = wave_sum(ss) * (1.0f / C);
+  const float inv = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i4 = 0; i4 < NV / 4; ++i4) {
+    const int c = i4 * 256 + lane * 4;
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(b + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i4 * 4 + i] = (v[i4 * 4 + i] - mean) * inv * wv[i] + bv[i];
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__ x, long long rows,
+                                                       const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       float eps1, const float* __restrict__ add, int add_div, int add_mod,
+                                                       float* __restrict__ out1, const float* __restrict__ w2,
+                                                       const float* __restrict__ b2, float eps2, float* __restrict__ out2) {
+  constexpr int NV = C / 64;
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[NV];
+#pragma unroll
+  for (int i4 = 0; i4 < NV / 4; ++i4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(x + row * C + i4 * 256 + lane * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i4 * 4 + i] = t[i];
+  }
+  if (w1) ln_regs<C>(v, w1, b1, eps1, lane);
+  if (add) {
+    const float* a = add + (long long)((row / add_div) % add_mod) * C;
+#pragma unroll
+    for (int i4 = 0; i4 < NV / 4; ++i4) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(a + i4 * 256 + lane * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i4 * 4 + i] += t[i];
+    }
+  }
+  if (out1) {
+#pragma unroll
+    for (int i4 = 0; i4 < NV / 4; ++i4) {
+      f32x4 t;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[i] = v[i4 * 4 + i];
+      *reinterpret_cast<f32x4*>(out1 + row * C + i4 * 256 + lane * 4) = t;
+    }
+  }
+  if (out2) {
+    ln_regs<C>(v, w2, b2, eps2, lane);
+#pragma unroll
+    for (int i4 = 0; i4 < NV / 4; ++i4) {
+      f32x4 t;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[i] = v[i4 * 4 + i];
+      *reinterpret_cast<f32x4*>(out2 + row * C + i4 * 256 + lane * 4) = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// short-sequence multi-head attention (timm Attention == CoevoDecoder.py:118-131), N <= 32 tokens, 8 heads.
+// One workgroup per sequence; K/V of the sequence staged once in LDS; wave w owns heads 2w, 2w+1; lane =
+// (head-in-pair, query).  Online softmax over the <= 32 keys, all in registers; the K/V reads are
+// half-wave broadcasts.  Sequence s, position i -> token (s % seq_div)*seq_lo + (s / seq_div)*seq_hi + i*tok_stride.
+// ------------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void seq_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N,
+                                                            int seq_div, long long seq_lo, long long seq_hi,
+                                                            long long tok_stride) {
+  constexpr int C = HD * 8;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;
+  float* Vs = smem + N * C;
+  const int s = blockIdx.x;
+  const long long base = (long long)(s % seq_div) * seq_lo + (long long)(s / seq_div) * seq_hi;
+  const int tid = threadIdx.x;
+  constexpr int C4 = C / 4;
+  for (int idx = tid; idx < N * C4; idx += 256) {
+    const int i = idx / C4, c = (idx % C4) * 4;
+    const float* src = qkv + (base + i * tok_stride) * (3 * C);
+    *reinterpret_cast<f32x4*>(Ks + i * C + c) = *reinterpret_cast<const f32x4*>(src + C + c);
+    *reinterpret_cast<f32x4*>(Vs + i * C + c) = *reinterpret_cast<const f32x4*>(src + 2 * C + c);
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int head = wave * 2 + (lane >> 5), i = lane & 31;
+  if (i >= N) return;
+  const float scale = 1.0f / sqrtf((float)HD);
+  float q[HD], o[HD];
+  const float* qsrc = qkv + (base + i * tok_stride) * (3 * C) + head * HD;
+#pragma unroll
+  for (int d4 = 0; d4 < HD / 4; ++d4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(qsrc + 4 * d4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      q[4 * d4 + k] = t[k];
+      o[4 * d4 + k] = 0.f;
+    }
+  }
+  float m = -INFINITY, l = 0.f;
+  for (int j = 0; j < N; ++j) {
+    const float* kr = Ks + j * C + head * HD;
+    float sc = 0.f;
+#pragma unroll
+    for (int d4 = 0; d4 < HD / 4; ++d4) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(kr + 4 * d4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sc += q[4 * d4 + k] * t[k];
+    }
+    sc *= scale;
+    const float mn = fmaxf(m, sc);
+    const float corr = expf(m - mn);  // first key: exp(-inf) = 0
+    const float pj = expf(sc - mn);
+    l = l * corr + pj;
+    const float* vr = Vs + j * C + head * HD;
+#pragma unroll
+    for (int d4 = 0; d4 < HD / 4; ++d4) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(vr + 4 * d4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[4 * d4 + k] = o[4 * d4 + k] * corr + pj * t[k];
+    }
+    m = mn;
+  }
+  const float inv = 1.0f / l;
+  float* dst = out + (base + i * tok_stride) * C + head * HD;
+#pragma unroll
+  for (int d4 = 0; d4 < HD / 4; ++d4) {
+    f32x4 t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = o[4 * d4 + k] * inv;
+    *reinterpret_cast<f32x4*>(dst + 4 * d4) = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// regression head + frame fusion (PoseEstimation.py:62-66,109-113): one wavefront per (b, j):
+//   p[t] = Wr * LN_{1e-5}(x[b,t,j,:]) + br ;  pose3d[b,j,:] = sum_t wf[t]*p[t] + bf
+// ------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void lifter_head_kernel(const float* __restrict__ x, const float* __restrict__ lnw,
+                                                          const float* __restrict__ lnb, const float* __restrict__ Wr,
+                                                          const float* __restrict__ br, const float* __restrict__ wf,
+                                                          const float* __restrict__ bf, float* __restrict__ pose3d,
+                                                          int B, int T, int J) {
+  constexpr int NV = C / 64;
+  const int lane = threadIdx.x & 63;
+  const int bj = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bj >= B * J) return;
+  const int b = bj / J, j = bj % J;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const float* row = x + ((long long)(b * T + t) * J + j) * C;
+    float v[NV];
+#pragma unroll
+    for (int i4 = 0; i4 < NV / 4; ++i4) {
+      const f32x4 tt = *reinterpret_cast<const f32x4*>(row + i4 * 256 + lane * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i4 * 4 + i] = tt[i];
+    }
+    ln_regs<C>(v, lnw, lnb, 1e-5f, lane);
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll
+    for (int i4 = 0; i4 < NV / 4; ++i4) {
+      const int c = i4 * 256 + lane * 4;
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wr + c);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wr + C + c);
+      const f32x4 w2 = *reinterpret_cast<const f32x4*>(Wr + 2 * C + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        d0 += v[i4 * 4 + i] * w0[i];
+        d1 += v[i4 * 4 + i] * w1[i];
+        d2 += v[i4 * 4 + i] * w2[i];
+      }
+    }
+    d0 = wave_sum(d0) + br[0];
+    d1 = wave_sum(d1) + br[1];
+    d2 = wave_sum(d2) + br[2];
+    const float w = wf[t];
+    acc0 += w * d0;
+    acc1 += w * d1;
+    acc2 += w * d2;
+  }
+  if (lane == 0) {
+    float* o = pose3d + (long long)bj * 3;
+    o[0] = acc0 + bf[0];
+    o[1] = acc1 + bf[0];
+    o[2] = acc2 + bf[0];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// C-ABI launchers
+// ------------------------------------------------------------------------------------------------------
+extern "C" int pmce_embed_tokens_f32(const float* pose2d, const float* E, const float* Wje, const float* bje,
+                                     const float* spos, float* x, long long ntok, int J, int C, hipStream_t stream) {
+  PMCE_REQUIRE(C % 4 == 0 && J > 0 && ntok > 0, "embed_tokens: bad shape");
+  const long long n = ntok * (C / 4);
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pose2d, E, Wje, bje, spos,
+                     x, ntok, J, C);
+  return pmce_check_launch("embed_tokens");
+}
+
+extern "C" int pmce_ln_chain_f32(const float* x, long long rows, int C, const float* w1, const float* b1, float eps1,
+                                 const float* add, int add_div, int add_mod, float* out1, const float* w2, const float* b2,
+                                 float eps2, float* out2, hipStream_t stream) {
+  PMCE_REQUIRE(C == 256 || C == 512, "ln_chain: C must be 256 or 512 (got %d)", C);
+  PMCE_REQUIRE(rows > 0 && (out1 || out2), "ln_chain: nothing to do");
+  PMCE_REQUIRE(!out2 || (w2 && b2), "ln_chain: out2 needs w2/b2");
+  if (add_div <= 0) add_div = 1;
+  if (add_mod <= 0) add_mod = 1;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  if (C == 256)
+    hipLaunchKernelGGL((ln_chain_kernel<256>), dim3(grid), dim3(256), 0, stream, x, rows, w1, b1, eps1, add, add_div, add_mod,
+                       out1, w2, b2, eps2, out2);
+  else
+    hipLaunchKernelGGL((ln_chain_kernel<512>), dim3(grid), dim3(256), 0, stream, x, rows, w1, b1, eps1, add, add_div, add_mod,
+                       out1, w2, b2, eps2, out2);
+  return pmce_check_launch("ln_chain");
+}
+
+extern "C" int pmce_seq_attention_f32(const float* qkv, float* out, int nseq, int N, int C, int seq_div, long long seq_lo,
+                                      long long seq_hi, long long tok_stride, hipStream_t stream) {
+  PMCE_REQUIRE(C == 256 || C == 512, "seq_attention: C must be 256 or 512 (8 heads of 32/64)");
+  PMCE_REQUIRE(N >= 1 && N <= 32 && nseq > 0, "seq_attention: N must be in 1..32 (got %d)", N);
+  if (seq_div <= 0) seq_div = 0x7fffffff;
+  const size_t lds = (size_t)2 * N * C * sizeof(float);
+  if (C == 256) {
+    static bool attr256 = false;
+    if (!attr256) {
+      (void)hipFuncSetAttribute((const void*)seq_attention_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+      attr256 = true;
+    }
+    hipLaunchKernelGGL((seq_attention_kernel<32>), dim3(nseq), dim3(256), lds, stream, qkv, out, N, seq_div, seq_lo, seq_hi,
+                       tok_stride);
+  } else {
+    static bool attr512 = false;
+    if (!attr512) {
+      (void)hipFuncSetAttribute((const void*)seq_attention_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      attr512 = true;
+    }
+    hipLaunchKernelGGL((seq_attention_kernel<64>), dim3(nseq), dim3(256), lds, stream, qkv, out, N, seq_div, seq_lo, seq_hi,
+                       tok_stride);
+  }
+  return pmce_check_launch("seq_attention");
+}
+
+extern "C" int pmce_lifter_head_f32(const float* x, const float* lnw, const float* lnb, const float* Wr, const float* br,
+                                    const float* wf, const float* bf, float* pose3d, int B, int T, int J, int C,
+                                    hipStream_t stream) {
+  PMCE_REQUIRE(C == 256 || C == 512, "lifter_head: C must be 256 or 512");
+  const unsigned grid = (unsigned)((B * J + 3) / 4);
+  if (C == 256)
+    hipLaunchKernelGGL((lifter_head_kernel<256>), dim3(grid), dim3(256), 0, stream, x, lnw, lnb, Wr, br, wf, bf, pose3d, B, T, J);
+  else
+    hipLaunchKernelGGL((lifter_head_kernel<512>), dim3(grid), dim3(256), 0, stream, x, lnw, lnb, Wr, br, wf, bf, pose3d, B, T, J);
+  return pmce_check_launch("lifter_head");
+}

@@ -1,0 +1,85 @@
+"""Two-stream wrapper façade — drop-in for reference lib/models/PMCE.py."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib, assets, packing, synth
+from ..config import FEAT_DIM, NUM_VERTS_FULL, SEQLEN, cfg
+from ..runtime import HipEngine, HipModuleBase, _check_input, build_param_tree
+
+
+class PMCE(HipModuleBase):
+    """forward(pose2d[B,16,J,2], img_feat[B,16,2048]) -> (cam_mesh[B,6890,3] m, cam_pose[B,J,3] m, pose3d[B,J,3] mm)
+    — same order as the reference (PMCE.py:15-20).  State-dict keys: ``pose_lifter.*``, ``pose_mesh_coevo.*``."""
+
+    def __init__(self, num_joint, embed_dim, depth, base_data_dir=None):
+        super().__init__()
+        self.num_joint, self.embed_dim, self.depth = num_joint, embed_dim, depth
+        build_param_tree(self, synth.pmce_spec(num_joint, embed_dim, depth))
+        v431, vj, src = assets.build_template(base_data_dir)
+        self.pose_mesh_coevo.init_vertices.copy_(torch.from_numpy(v431))
+        self.vj_relation = vj
+        self.base_data_source = src
+        self._j_regressor = None
+        self.eval()
+
+    def set_j_regressor(self, j_regressor):
+        """Register the caller's regressor (``Tester.J_regressor``, lib/core/base.py:196) so that
+        :meth:`forward_with_joints` also returns ``J_regressor @ (cam_mesh*1000)`` (base.py:223-225)."""
+        self._j_regressor = np.asarray(j_regressor)
+        self._dirty = True
+
+    def _build_engine(self, dev):
+        eng = HipEngine(self.num_joint, self.embed_dim, self.depth)
+        sd = self.state_dict()
+        eng.register(packing.pack_lifter(sd, "pose_lifter.", dev, self.num_joint, self.embed_dim, self.depth))
+        eng.register(packing.pack_decoder(sd, "pose_mesh_coevo.", dev, self.num_joint, self.vj_relation))
+        if self._j_regressor is not None:
+            eng.set_regressor(self._j_regressor)
+        eng.finalize()
+        return eng
+
+    def _run(self, pose2d, img_feat, want_joints):
+        eng = self._ensure_packed()
+        pose2d = _check_input(pose2d, (SEQLEN, self.num_joint, 2), "pose2d")
+        img_feat = _check_input(img_feat, (SEQLEN, FEAT_DIM), "img_feat")
+        B = pose2d.shape[0]
+        dev = pose2d.device
+        mesh = torch.empty(B, NUM_VERTS_FULL, 3, device=dev, dtype=torch.float32)
+        pose = torch.empty(B, self.num_joint, 3, device=dev, dtype=torch.float32)
+        pose3d = torch.empty(B, self.num_joint, 3, device=dev, dtype=torch.float32)
+        pred = None
+        if want_joints:
+            if not eng.regressor_rows:
+                raise _lib.PmceError("forward_with_joints needs set_j_regressor(...) first")
+            pred = torch.empty(B, eng.regressor_rows, 3, device=dev, dtype=torch.float32)
+        ws = eng.workspace(B)
+        _lib.check(eng.lib.pmce_forward(eng.handle, _lib.ptr(pose2d), _lib.ptr(img_feat), _lib.ptr(mesh), _lib.ptr(pose),
+                                        _lib.ptr(pose3d), _lib.ptr(pred), B, C.c_void_p(ws.data_ptr()), ws.numel(),
+                                        _lib.current_stream()), "pmce_forward")
+        return mesh, pose, pose3d, pred
+
+    @torch.no_grad()
+    def forward(self, pose2d, img_feat):
+        mesh, pose, pose3d, _ = self._run(pose2d, img_feat, False)
+        return mesh, pose, pose3d
+
+    @torch.no_grad()
+    def forward_with_joints(self, pose2d, img_feat):
+        """(cam_mesh, cam_pose, pose3d, pred_pose_mm) — the forward plus the caller's tail of Tester.test."""
+        return self._run(pose2d, img_feat, True)
+
+    # benchmarking hooks
+    def profile(self, enable=True):
+        self._ensure_packed().profile(enable)
+
+    def profile_read(self):
+        return self._ensure_packed().profile_read()
+
+
+def get_model(num_joint, embed_dim, depth):
+    """Same signature as reference PMCE.get_model (PMCE.py:23-26)."""
+    return PMCE(num_joint, embed_dim, depth)

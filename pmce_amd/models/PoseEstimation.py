@@ -1,0 +1,50 @@
+"""Temporal pose encoder façade — drop-in for reference lib/models/PoseEstimation.py (GraphormerNet)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from .. import _lib, packing, synth
+from ..config import FEAT_DIM, SEQLEN, cfg
+from ..runtime import HipEngine, HipModuleBase, _check_input, build_param_tree
+
+
+class GraphormerNet(HipModuleBase):
+    """forward(x[B,16,J,2], img_feat[B,16,2048]) -> pose3d[B,J,3] in millimetres (PoseEstimation.py:95-115)."""
+
+    def __init__(self, num_frames=16, num_joints=17, embed_dim=256, depth=3, pretrained=False):
+        super().__init__()
+        if num_frames != SEQLEN:
+            raise ValueError("the path is specialised for 16-frame clips (cfg.DATASET.seqlen, config.py:48)")
+        self.num_joints, self.embed_dim, self.depth = num_joints, embed_dim, depth
+        build_param_tree(self, synth.lifter_spec(num_joints, embed_dim, depth))
+        self.eval()
+        if pretrained:   # PoseEstimation.py:71-74
+            ckpt = torch.load(cfg.MODEL.posenet_path, map_location="cpu")
+            self.load_state_dict(ckpt["model_state_dict"])
+
+    def _build_engine(self, dev):
+        eng = HipEngine(self.num_joints, self.embed_dim, self.depth)
+        eng.register(packing.pack_lifter(self.state_dict(), "", dev, self.num_joints, self.embed_dim, self.depth))
+        eng.finalize()
+        return eng
+
+    @torch.no_grad()
+    def forward(self, x, img_feat):
+        eng = self._ensure_packed()
+        x = _check_input(x, (SEQLEN, self.num_joints, 2), "pose2d")
+        img_feat = _check_input(img_feat, (SEQLEN, FEAT_DIM), "img_feat")
+        B = x.shape[0]
+        out = torch.empty(B, self.num_joints, 3, device=x.device, dtype=torch.float32)
+        ws = eng.workspace(B)
+        _lib.check(eng.lib.pmce_lifter_forward(eng.handle, _lib.ptr(x), _lib.ptr(img_feat), _lib.ptr(out), B,
+                                               C.c_void_p(ws.data_ptr()), ws.numel(), _lib.current_stream()),
+                   "pmce_lifter_forward")
+        return out
+
+
+def get_model(num_joint=17, embed_dim=256, depth=3, pretrained=False):
+    """Same signature as reference PoseEstimation.get_model (PoseEstimation.py:118-120)."""
+    return GraphormerNet(num_frames=cfg.DATASET.seqlen, num_joints=num_joint, embed_dim=embed_dim, depth=depth,
+                         pretrained=pretrained)

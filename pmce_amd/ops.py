@@ -1,0 +1,177 @@
+"""Per-operator Python wrappers over the C ABI (include/pmce_hip.h).  Used by the parity tests and by callers that
+want a single stage; the whole-path modules in pmce_amd/models call pmce_forward instead.  All tensors are
+contiguous fp32 CUDA tensors; weights are passed the way the reference's state_dict stores them."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .packing import N_ADA
+
+P = _lib.ptr
+
+
+def _st():
+    return _lib.current_stream()
+
+
+def _c(t):
+    return t.to(torch.float32).contiguous()
+
+
+def gemm_nt(A, W, bias=None, residual=None, act=0, out=None):
+    """out = act(A @ W^T + bias) + residual  (nn.Linear)."""
+    lib = _lib.load()
+    A, W = _c(A), _c(W)
+    M, K = A.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    _lib.check(lib.pmce_gemm_nt_f32(P(A), P(W), P(bias), P(residual), P(out), M, N, K, K, K, N, act, 0, 0, 0, 0, 0, 0, 1,
+                                    0, 0, 0, 0, _st()), "gemm_nt")
+    return out
+
+
+def ln_chain(x, w1=None, b1=None, eps1=1e-6, add=None, add_div=1, add_mod=1, want_out1=True, w2=None, b2=None, eps2=1e-6):
+    lib = _lib.load()
+    x = _c(x)
+    rows, Cc = x.shape
+    out1 = torch.empty_like(x) if want_out1 else None
+    out2 = torch.empty_like(x) if w2 is not None else None
+    _lib.check(lib.pmce_ln_chain_f32(P(x), rows, Cc, P(w1), P(b1), eps1, P(add), add_div, add_mod, P(out1), P(w2), P(b2), eps2,
+                                     P(out2), _st()), "ln_chain")
+    return out1, out2
+
+
+def seq_attention(qkv, nseq, N, Cc, seq_div, seq_lo, seq_hi, tok_stride):
+    lib = _lib.load()
+    qkv = _c(qkv)
+    out = torch.empty(qkv.shape[0], Cc, device=qkv.device, dtype=torch.float32)
+    _lib.check(lib.pmce_seq_attention_f32(P(qkv), P(out), nseq, N, Cc, seq_div, seq_lo, seq_hi, tok_stride, _st()),
+               "seq_attention")
+    return out
+
+
+def vertex_init_gather(joints, vj_relation):
+    lib = _lib.load()
+    joints = _c(joints)
+    B, J, _ = joints.shape
+    vj = torch.as_tensor(np.asarray(vj_relation).astype(np.int32), device=joints.device)
+    out = torch.empty(B, 431, 3, device=joints.device, dtype=torch.float32)
+    _lib.check(lib.pmce_vertex_init_gather_f32(P(joints), P(vj), P(out), B, J, _st()), "vertex_init_gather")
+    return out
+
+
+def adaln_params(g, sd, names):
+    """GB[B, len(names)*128]: [gamma(64)|beta(64)] per AdaLN instance, via the packed GEMM (CoevoDecoder.py:19-20,27-28)."""
+    Wt = torch.cat([torch.cat([sd[n + ".mlp_gamma.weight"], sd[n + ".mlp_beta.weight"]], 0) for n in names], 0)
+    bt = torch.cat([torch.cat([sd[n + ".mlp_gamma.bias"], sd[n + ".mlp_beta.bias"]], 0) for n in names], 0)
+    return gemm_nt(g, _c(Wt), _c(bt))
+
+
+def cross_attn_vertex(xq, xk, xv, g, sd, p):
+    """Fused AdaLN + vertex<-joint cross-attention + residual: xq + CA(AdaLN_q(xq), AdaLN_k(xk), AdaLN_v(xv))
+    (first line of CrossAttentionBlock.forward, CoevoDecoder.py:83) with p = '...vertx_CA_FFN'."""
+    lib = _lib.load()
+    xq, xk, xv = _c(xq), _c(xk), _c(xv)
+    B, Nq, _ = xq.shape
+    J = xk.shape[1]
+    assert Nq == 431
+    GB = adaln_params(g, sd, [p + ".normq", p + ".normk", p + ".normv"])
+    dev = xq.device
+    Kf = torch.empty(B, 64, 64, device=dev)
+    s0 = torch.empty(B, 64, device=dev)
+    Vf = torch.empty(B, 64, 64, device=dev)
+    w = {k: _c(sd[f"{p}.attn.{k}"]) for k in ("wq.weight", "wq.bias", "wk.weight", "wk.bias", "wv.weight", "wv.bias",
+                                              "proj.weight", "proj.bias")}
+    _lib.check(lib.pmce_ca_fold_f32(P(xk), P(xv), P(GB), GB.shape[1], 0, 1, 2, P(w["wq.weight"]), P(w["wq.bias"]),
+                                    P(w["wk.weight"]), P(w["wk.bias"]), P(w["wv.weight"]), P(w["wv.bias"]),
+                                    P(w["proj.weight"]), P(Kf), P(s0), P(Vf), B, J, _st()), "ca_fold")
+    out = torch.empty_like(xq)
+    _lib.check(lib.pmce_vertex_ca_f32(P(xq), None, None, None, P(Kf), P(s0), P(Vf), P(w["proj.bias"]), P(out), B, J, _st()),
+               "vertex_ca")
+    return out
+
+
+def adaln_mlp(x, g, sd, p_norm, p_mlp, coor=None, vt_in=None, want_features=True):
+    """x + Mlp(AdaLN(x)) on [B,431,64]; optional coordinate head (Wc[3,64], bc[3]) + vt_in residual."""
+    lib = _lib.load()
+    x = _c(x)
+    B = x.shape[0]
+    GB = adaln_params(g, sd, [p_norm])
+    w = [_c(sd[p_mlp + k]) for k in (".fc1.weight", ".fc1.bias", ".fc2.weight", ".fc2.bias")]
+    y = torch.empty_like(x) if want_features else None
+    vt_out = None
+    Wc = bc = None
+    if coor is not None:
+        Wc, bc = _c(coor[0]), _c(coor[1])
+        vt_in = _c(vt_in)
+        vt_out = torch.empty_like(vt_in)
+    _lib.check(lib.pmce_adaln_mlp_f32(P(x), P(GB), GB.shape[1], 0, P(w[0]), P(w[1]), P(w[2]), P(w[3]), P(y), P(Wc), P(bc),
+                                      P(vt_in), P(vt_out), B, _st()), "adaln_mlp")
+    return y, vt_out
+
+
+def vertex_self_attn(x, g, sd, p):
+    """x + SA(AdaLN(x)) on [B,431,64], 2 heads (first line of Block.forward, CoevoDecoder.py:103); p = '...vertx_SA_FFN'."""
+    lib = _lib.load()
+    x = _c(x)
+    B = x.shape[0]
+    GB = adaln_params(g, sd, [p + ".norm1"])
+    qkv = torch.empty(B, 431, 192, device=x.device)
+    _lib.check(lib.pmce_adaln_qkv_f32(P(x), P(GB), GB.shape[1], 0, P(_c(sd[p + ".attn.qkv.weight"])),
+                                      P(_c(sd[p + ".attn.qkv.bias"])), P(qkv), B, _st()), "adaln_qkv")
+    y = torch.empty_like(x)
+    _lib.check(lib.pmce_vertex_sa_f32(P(x), P(qkv), P(_c(sd[p + ".attn.proj.weight"])), P(_c(sd[p + ".attn.proj.bias"])),
+                                      P(y), B, _st()), "vertex_sa")
+    return y, qkv
+
+
+def joint_stream(xq, xk, xv, g, sd, blk, stage, jt=None):
+    """Joint stream of a CoevoBlock given explicit q/k/v token sets (xq[B,J,64], xk/xv[B,431,64]):
+    stage 1 = xq + CA (CoevoDecoder.py:83), 2 = + FFN (:85-86), 3 = + joint_SA_FFN (:187) (+ coords if jt)."""
+    lib = _lib.load()
+    xq, xk, xv = _c(xq), _c(xk), _c(xv)
+    B, J, _ = xq.shape
+    ca, sa = blk + ".joint_CA_FFN", blk + ".joint_SA_FFN"
+    GB = adaln_params(g, sd, [ca + ".normq", ca + ".normk", ca + ".normv", ca + ".norm2", sa + ".norm1", sa + ".norm2"])
+    kv = torch.empty(B, 431, 128, device=xq.device)
+    _lib.check(lib.pmce_tokens_kv_f32(P(xk), P(xv), None, None, None, None, None, P(GB), GB.shape[1], 1, 2,
+                                      P(_c(sd[ca + ".attn.wk.weight"])), P(_c(sd[ca + ".attn.wk.bias"])),
+                                      P(_c(sd[ca + ".attn.wv.weight"])), P(_c(sd[ca + ".attn.wv.bias"])), P(kv), B, _st()),
+               "tokens_kv")
+    names = [ca + ".attn.wq.weight", ca + ".attn.wq.bias", ca + ".attn.proj.weight", ca + ".attn.proj.bias",
+             ca + ".mlp.fc1.weight", ca + ".mlp.fc1.bias", ca + ".mlp.fc2.weight", ca + ".mlp.fc2.bias",
+             sa + ".attn.qkv.weight", sa + ".attn.qkv.bias", sa + ".attn.proj.weight", sa + ".attn.proj.bias",
+             sa + ".mlp.fc1.weight", sa + ".mlp.fc1.bias", sa + ".mlp.fc2.weight", sa + ".mlp.fc2.bias",
+             blk + ".proj_joint_feat2coor.weight", blk + ".proj_joint_feat2coor.bias"]
+    ws = [_c(sd[n]) for n in names]
+    wptr = (C.c_void_p * 18)(*[w.data_ptr() for w in ws])
+    inst = (C.c_int * 4)(0, 3, 4, 5)
+    y = torch.empty_like(xq)
+    pose = None
+    if jt is not None:
+        jt = _c(jt)
+        pose = torch.empty_like(jt)
+    _lib.check(lib.pmce_joint_stream_f32(P(xq), None, P(kv), P(GB), GB.shape[1], wptr, inst, P(jt), P(y), P(pose), B, J,
+                                         stage, _st()), "joint_stream")
+    return y, pose, kv
+
+
+def j_regress(cam_mesh_m, j_regressor, scale=1000.0):
+    """J_regressor[None] @ (cam_mesh*1000) (lib/core/base.py:223-225); j_regressor dense [R,6890] (numpy or tensor)."""
+    from .assets import regressor_to_csr
+    lib = _lib.load()
+    mesh = _c(cam_mesh_m)
+    B = mesh.shape[0]
+    jr = j_regressor.detach().cpu().numpy() if isinstance(j_regressor, torch.Tensor) else np.asarray(j_regressor)
+    indptr, indices, data = regressor_to_csr(jr)
+    dev = mesh.device
+    ip, ix, dt = (torch.from_numpy(a).to(dev) for a in (indptr, indices, data))
+    out = torch.empty(B, jr.shape[0], 3, device=dev, dtype=torch.float32)
+    _lib.check(lib.pmce_j_regress_f32(P(mesh), P(ip), P(ix), P(dt), P(out), B, jr.shape[0], mesh.shape[1], scale, _st()),
+               "j_regress")
+    return out

@@ -1,0 +1,159 @@
+"""Host-side runtime shared by the three façade modules: a parameter tree with the reference's state_dict
+keys, lazy packing onto the device, the ``pmce_model`` handle of libpmce_hip.so and its workspace.
+
+PyTorch is plumbing here (device memory, streams, state_dict I/O); every FLOP of the forward runs in
+libpmce_hip.so.  There is no CPU or eager fallback: calling forward on CPU tensors raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, assets, packing
+from .config import NUM_VERTS, NUM_VERTS_FULL, SEQLEN, FEAT_DIM
+
+
+class _Node(nn.Module):
+    """Anonymous container; exists only so that state_dict keys equal the reference's."""
+
+
+def build_param_tree(root: nn.Module, spec: "OrderedDict[str, tuple]", buffers=("init_vertices",)):
+    """Create nested sub-modules/parameters so that ``root.state_dict().keys() == spec.keys()``."""
+    for key, entry in spec.items():
+        shape = entry[0] if isinstance(entry[0], (tuple, list)) else entry   # synth specs are (shape, half, off)
+        parts = key.split(".")
+        mod = root
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, _Node())
+            mod = mod._modules[p]
+        t = torch.zeros(shape, dtype=torch.float32)
+        if parts[-1] in buffers:
+            mod.register_buffer(parts[-1], t)
+        else:
+            mod.register_parameter(parts[-1], nn.Parameter(t, requires_grad=False))
+
+
+class HipEngine:
+    """Owns the C handle, the packed tensors and the workspace for one module instance."""
+
+    def __init__(self, num_joint: int, embed_dim: int, depth: int):
+        self.lib = _lib.load()
+        self.J, self.C, self.depth = num_joint, embed_dim, depth
+        h = C.c_void_p()
+        _lib.check(self.lib.pmce_model_create(num_joint, embed_dim, depth, C.byref(h)), "pmce_model_create")
+        self.handle = h
+        self.packed = OrderedDict()
+        self.ws = None
+        self.ws_batch = 0
+        self.device = None
+        self.regressor_rows = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.pmce_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def tensor_names(self):
+        n = self.lib.pmce_model_tensor_count(self.handle)
+        return [self.lib.pmce_model_tensor_name(self.handle, i).decode() for i in range(n)]
+
+    def register(self, tensors: "OrderedDict[str, torch.Tensor]"):
+        for name, t in tensors.items():
+            assert t.is_cuda and t.is_contiguous(), name
+            self.packed[name] = t      # keep alive
+            _lib.check(self.lib.pmce_model_set_tensor(self.handle, name.encode(), C.c_void_p(t.data_ptr())),
+                       f"set_tensor({name})")
+        self.device = next(iter(tensors.values())).device
+
+    def set_regressor(self, j_regressor):
+        csr, rows = packing.pack_regressor(j_regressor, self.device)
+        self.register(csr)
+        _lib.check(self.lib.pmce_model_set_regressor_rows(self.handle, rows), "set_regressor_rows")
+        self.regressor_rows = rows
+
+    def finalize(self):
+        _lib.check(self.lib.pmce_model_finalize(self.handle), "pmce_model_finalize")
+
+    def workspace(self, batch: int):
+        if self.ws is None or batch > self.ws_batch or self.ws.device != self.device:
+            nbytes = self.lib.pmce_model_workspace_bytes(self.handle, batch)
+            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self.ws_batch = batch
+        return self.ws
+
+    def intermediate(self, name: str, batch: int, shape):
+        """View of a named workspace buffer after a forward of ``batch`` clips (tests only)."""
+        off = self.lib.pmce_model_workspace_offset(self.handle, batch, name.encode())
+        if off < 0:
+            raise KeyError(name)
+        n = int(np.prod(shape))
+        return self.ws[off:off + 4 * n].view(torch.float32).reshape(shape)
+
+    # ---- profiling -------------------------------------------------------------------------------
+    def profile(self, enable: bool):
+        _lib.check(self.lib.pmce_model_profile(self.handle, 1 if enable else 0), "model_profile")
+
+    def profile_read(self):
+        name, ms, n = C.c_char_p(), C.c_double(), C.c_longlong()
+        count = self.lib.pmce_model_profile_read(self.handle, -1, None, None, None)
+        out = OrderedDict()
+        for i in range(count):
+            self.lib.pmce_model_profile_read(self.handle, i, C.byref(name), C.byref(ms), C.byref(n))
+            out[name.value.decode()] = (ms.value, n.value)
+        return out
+
+
+def _check_input(x, shape_tail, name):
+    if not x.is_cuda:
+        raise _lib.PmceError(f"{name} is on {x.device}: the HIP path needs GPU tensors and there is no CPU fallback")
+    if tuple(x.shape[1:]) != tuple(shape_tail):
+        raise ValueError(f"{name} must be [B,{','.join(map(str, shape_tail))}], got {tuple(x.shape)}")
+    return x.to(torch.float32).contiguous()
+
+
+class HipModuleBase(nn.Module):
+    """Common behaviour of the façades: reference-layout parameters, lazy (re)packing, inference only."""
+
+    def __init__(self):
+        super().__init__()
+        self._engine = None
+        self._dirty = True
+
+    # any change of the parameters' storage invalidates the packed copy
+    def _apply(self, fn, *a, **k):
+        self._dirty = True
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """Accepts the reference's checkpoint layout, with or without the checkpoint wrapper / 'module.' prefix."""
+        sd = packing.unwrap_checkpoint(state_dict)
+        self._dirty = True
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("pmce_amd implements the inference hot path only (training is out of scope)")
+        return super().train(False)
+
+    def _device(self):
+        return next(self.parameters()).device
+
+    def _ensure_packed(self):
+        dev = self._device()
+        if dev.type != "cuda":
+            raise _lib.PmceError("model parameters are on CPU: move the model to the GPU (.cuda()); no CPU fallback exists")
+        if self._engine is None or self._dirty or self._engine.device != dev:
+            self._engine = self._build_engine(dev)
+            self._dirty = False
+        return self._engine
+
+    def _build_engine(self, dev):  # pragma: no cover - abstract
+        raise NotImplementedError

@@ -1,0 +1,251 @@
+"""GPU parity tests, operator by operator: HIP kernels (through the C ABI) vs the oracle on the same seeded
+inputs.  Tolerances are max-abs in the operator's own units and are stated per test; the path's contract is
+1e-3 on the final fp32 vertices/joints (north_star) and bit-exact on the integer gather."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import cached_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU (run with -m gpu on the GPU box)"
+    return torch.device("cuda:0")
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def maxabs(a, b):
+    return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
+
+
+def rnd(name, shape, scale=1.0, seed=5):
+    from pmce_amd import synth
+    return T(synth.uniform_pm1(name, int(np.prod(shape)), seed).reshape(shape) * np.float32(scale))
+
+
+def sd_dev(sd, keys_prefix):
+    return {k: v.to(dev()) for k, v in sd.items() if k.startswith(keys_prefix)}
+
+
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,act,res", [
+    (300, 200, 64, 0, False),        # ragged edges, 64x64 tiles
+    (256, 3072, 2048, 0, False),     # small-M (GRU / AdaLN shape)
+    (1000, 768, 256, 0, False),      # 128x128 tiles with ragged M
+    (4352, 512, 256, 1, False),      # fc1 + GELU
+    (4352, 256, 512, 0, True),       # fc2 + residual
+    (130, 20670, 96, 0, False),      # ragged N (final-product shape)
+])
+def test_gemm_nt(M, N, K, act, res):
+    from pmce_amd import ops
+    A = rnd("gemm.A", (M, K)).to(dev())
+    W = rnd("gemm.W", (N, K), scale=K ** -0.5).to(dev())
+    b = rnd("gemm.b", (N,)).to(dev())
+    R = rnd("gemm.R", (M, N)).to(dev()) if res else None
+    out = ops.gemm_nt(A, W, b, R, act)
+    ref = A.double() @ W.double().t() + b.double()
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    if res:
+        ref = ref + R.double()
+    e = maxabs(out, ref)
+    print(f"gemm {M}x{N}x{K} act={act} res={res}: max-abs {e:.2e}")
+    assert e < 2e-5       # fp32 accumulation over K <= 2048 of O(1) terms
+
+
+def test_gemm_row_maps_and_batch():
+    """GI0 form: A rows (b,t) -> C rows (t,b); and a 2-batch launch with independent operands."""
+    from pmce_amd import _lib, ops
+    lib = _lib.load()
+    B, Tn, K, N = 5, 16, 64, 96
+    A = rnd("gemm.rm.A", (B * Tn, K)).to(dev())
+    W = rnd("gemm.rm.W", (N, K)).to(dev())
+    out = torch.zeros(Tn * B, N, device=dev())
+    _lib.check(lib.pmce_gemm_nt_f32(_lib.ptr(A), _lib.ptr(W), None, None, _lib.ptr(out), B * Tn, N, K, K, K, N, 0, 0, 0, 0,
+                                    Tn, B * N, N, 1, 0, 0, 0, 0, _lib.current_stream()))
+    ref = (A.double() @ W.double().t()).reshape(B, Tn, N).permute(1, 0, 2).reshape(Tn * B, N)
+    assert maxabs(out, ref) < 1e-5
+    A2 = rnd("gemm.b.A", (2, 70, K)).to(dev())
+    W2 = rnd("gemm.b.W", (2, N, K)).to(dev())
+    b2 = rnd("gemm.b.b", (2, N)).to(dev())
+    out2 = torch.zeros(2, 70, N, device=dev())
+    _lib.check(lib.pmce_gemm_nt_f32(_lib.ptr(A2), _lib.ptr(W2), _lib.ptr(b2), None, _lib.ptr(out2), 70, N, K, K, K, N, 0, 0, 0,
+                                    0, 0, 0, 0, 2, 70 * K, N * K, N, 70 * N, _lib.current_stream()))
+    ref2 = torch.einsum("bmk,bnk->bmn", A2.double(), W2.double()) + b2.double()[:, None, :]
+    assert maxabs(out2, ref2) < 1e-5
+
+
+@pytest.mark.parametrize("C", [256, 512])
+def test_ln_chain(C):
+    from pmce_amd import ops
+    rows, J, Tn = 2 * 16 * 17, 17, 16
+    x = rnd("ln.x", (rows, C), 2.0).to(dev())
+    w1, b1 = (1 + rnd("ln.w1", (C,), 0.1)).to(dev()), rnd("ln.b1", (C,), 0.1).to(dev())
+    w2, b2 = (1 + rnd("ln.w2", (C,), 0.1)).to(dev()), rnd("ln.b2", (C,), 0.1).to(dev())
+    add = rnd("ln.add", (Tn, C), 0.1).to(dev())
+    o1, o2 = ops.ln_chain(x, w1, b1, 1e-6, add, J, Tn, True, w2, b2, 1e-5)
+    F = torch.nn.functional
+    t = (torch.arange(rows, device=dev()) // J) % Tn
+    r1 = F.layer_norm(x.double(), (C,), w1.double(), b1.double(), 1e-6) + add.double()[t]
+    r2 = F.layer_norm(r1, (C,), w2.double(), b2.double(), 1e-5)
+    assert maxabs(o1, r1) < 5e-6 and maxabs(o2, r2) < 5e-6
+    _, o3 = ops.ln_chain(x, None, None, 0.0, None, 1, 1, False, w2, b2, 1e-6)
+    assert maxabs(o3, F.layer_norm(x.double(), (C,), w2.double(), b2.double(), 1e-6)) < 5e-6
+
+
+@pytest.mark.parametrize("C,J", [(256, 17), (256, 19), (512, 17)])
+def test_seq_attention(C, J):
+    from pmce_amd import ops
+    B, Tn, H = 2, 16, 8
+    hd = C // H
+    M = B * Tn * J
+    qkv = rnd("attn.qkv", (M, 3 * C)).to(dev())
+
+    def ref(seq_first):  # tokens laid out [b,t,j]; sequences over j (spatial) or t (temporal)
+        x = qkv.double().reshape(B, Tn, J, 3, H, hd)
+        x = x if seq_first == "s" else x.permute(0, 2, 1, 3, 4, 5)           # -> [B, outer, N, 3, H, hd]
+        q, k, v = x[..., 0, :, :], x[..., 1, :, :], x[..., 2, :, :]
+        q, k, v = (z.permute(0, 1, 3, 2, 4) for z in (q, k, v))             # [B, outer, H, N, hd]
+        a = ((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(-1) @ v         # [B, outer, H, N, hd]
+        a = a.permute(0, 1, 3, 2, 4).reshape(*a.shape[:2], a.shape[3], C)    # [B, outer, N, C]
+        return (a if seq_first == "s" else a.permute(0, 2, 1, 3)).reshape(M, C)
+
+    out_s = ops.seq_attention(qkv, B * Tn, J, C, 0, J, 0, 1)
+    out_t = ops.seq_attention(qkv, B * J, Tn, C, J, 1, Tn * J, J)
+    es, et = maxabs(out_s, ref("s")), maxabs(out_t, ref("t"))
+    print(f"seq_attention C={C} J={J}: spatial {es:.2e} temporal {et:.2e}")
+    assert es < 5e-6 and et < 5e-6
+
+
+def test_vertex_init_gather_bit_exact(golden):
+    from pmce_amd import ops
+    z = golden("e2e_J17_C256_B2.npz")
+    joints = (T(z["pose3d"]) / 1000).to(dev())
+    out = ops.vertex_init_gather(joints, z["vj_relation"])
+    assert np.array_equal(out.cpu().numpy(), z["vert0"])           # integer gather: bit-exact vs the reference
+    j19 = rnd("gather.j", (3, 19, 3)).to(dev())
+    out19 = ops.vertex_init_gather(j19, z["vj_relation"])
+    assert torch.equal(out19.cpu(), j19.cpu()[:, T(z["vj_relation"]), :])
+
+
+# ------------------------------------------------------------------------------------------------------------
+# decoder operators vs oracle and vs the reference's own module outputs (tests/golden/modules_J17_C256.npz)
+# ------------------------------------------------------------------------------------------------------------
+def _mod_inputs():
+    from pmce_amd import synth
+    u = synth.uniform_pm1
+    B = 1
+    g = T(u("mod.g", B * 2048, 11).reshape(B, 2048) * 0.8)
+    xv = T(u("mod.xv", B * 431 * 64, 11).reshape(B, 431, 64) * 1.5 + 0.1)
+    xj = T(u("mod.xj", B * 17 * 64, 11).reshape(B, 17, 64) * 1.5 - 0.2)
+    return g, xv, xj
+
+
+BLK = "pose_mesh_coevo.coevoblock3"
+
+
+def test_cross_attn_vertex(golden):
+    """North-star kernel: fused AdaLN + vertex<-joint cross-attention + residual."""
+    from oracle import pmce_oracle as O
+    from pmce_amd import ops
+    sd = cached_state_dict(17, 256)
+    sdd = sd_dev(sd, BLK + ".vertx_CA_FFN")
+    g, xv, xj = _mod_inputs()
+    out = ops.cross_attn_vertex(xv.to(dev()), xj.to(dev()), xj.to(dev()), g.to(dev()), sdd, BLK + ".vertx_CA_FFN")
+    with torch.no_grad():
+        ref = O.cross_attention_only(xv, xj, xj, g, sd, BLK + ".vertx_CA_FFN", 2)
+    e_or, e_ref = maxabs(out, ref), maxabs(out, T(golden("modules_J17_C256.npz")["ca_v_from_j"]))
+    print(f"vertex_ca: vs oracle {e_or:.2e}, vs reference fixture {e_ref:.2e}")
+    assert e_or < 2e-5 and e_ref < 2e-5
+    # batch of 3 different clips, J=19 style key count is covered in test_e2e; here: batch > 1 and ragged tail
+    B = 3
+    g3, xq3, xk3 = rnd("ca.g", (B, 2048), 0.8), rnd("ca.xq", (B, 431, 64), 1.5), rnd("ca.xk", (B, 17, 64), 1.5)
+    out3 = ops.cross_attn_vertex(xq3.to(dev()), xk3.to(dev()), xk3.to(dev()), g3.to(dev()), sdd, BLK + ".vertx_CA_FFN")
+    with torch.no_grad():
+        ref3 = O.cross_attention_only(xq3, xk3, xk3, g3, sd, BLK + ".vertx_CA_FFN", 2)
+    assert maxabs(out3, ref3) < 2e-5
+
+
+def test_adaln_mlp(golden):
+    from oracle import pmce_oracle as O
+    from pmce_amd import ops
+    sd = cached_state_dict(17, 256)
+    p = BLK + ".vertx_CA_FFN"
+    sdd = sd_dev(sd, BLK)
+    B = 2
+    g, x = rnd("mlp.g", (B, 2048), 0.8), rnd("mlp.x", (B, 431, 64), 1.5)
+    vt = rnd("mlp.vt", (B, 431, 3), 0.5)
+    y, vt_out = ops.adaln_mlp(x.to(dev()), g.to(dev()), sdd, p + ".norm2", p + ".mlp",
+                              coor=(sdd[BLK + ".proj_vertx_feat2coor.weight"], sdd[BLK + ".proj_vertx_feat2coor.bias"]),
+                              vt_in=vt.to(dev()))
+    with torch.no_grad():
+        ref = x + O.mlp(O.ada_layer_norm(x, g, sd, p + ".norm2", torch.float32), sd, p + ".mlp", torch.float32)
+        ref_vt = O.linear(ref, sd, BLK + ".proj_vertx_feat2coor", torch.float32) + vt
+    e1, e2 = maxabs(y, ref), maxabs(vt_out, ref_vt)
+    print(f"adaln_mlp: features {e1:.2e}, coords {e2:.2e}")
+    assert e1 < 2e-5 and e2 < 2e-5
+
+
+def test_vertex_self_attn(golden):
+    from oracle import pmce_oracle as O
+    from pmce_amd import ops
+    sd = cached_state_dict(17, 256)
+    p = BLK + ".vertx_SA_FFN"
+    sdd = sd_dev(sd, p)
+    g, xv, _ = _mod_inputs()
+    y, qkv = ops.vertex_self_attn(xv.to(dev()), g.to(dev()), sdd, p)
+    with torch.no_grad():
+        a = O.ada_layer_norm(xv, g, sd, p + ".norm1", torch.float32)
+        ref_qkv = O.linear(a, sd, p + ".attn.qkv", torch.float32)
+        ref = xv + O.self_attention(a, sd, p + ".attn", 2, torch.float32)
+    e1, e2 = maxabs(qkv, ref_qkv), maxabs(y, ref)
+    print(f"adaln_qkv {e1:.2e}, vertex_sa {e2:.2e}")
+    assert e1 < 2e-5 and e2 < 2e-5
+    # full SA block = SA + MLP vs the reference's own Block output
+    y2, _ = ops.adaln_mlp(y, g.to(dev()), sd_dev(sd, p), p + ".norm2", p + ".mlp")
+    e3 = maxabs(y2, T(golden("modules_J17_C256.npz")["sab_v"]))
+    print(f"vertex SA block vs reference fixture {e3:.2e}")
+    assert e3 < 3e-5
+
+
+@pytest.mark.parametrize("stage", [1, 2, 3])
+def test_joint_stream(golden, stage):
+    from oracle import pmce_oracle as O
+    from pmce_amd import ops
+    sd = cached_state_dict(17, 256)
+    sdd = sd_dev(sd, BLK)
+    g, xv, xj = _mod_inputs()
+    jt = rnd("js.jt", (1, 17, 3), 0.5)
+    y, pose, kv = ops.joint_stream(xj.to(dev()), xv.to(dev()), xv.to(dev()), g.to(dev()), sdd, BLK, stage,
+                                   jt=jt.to(dev()) if stage == 3 else None)
+    ca = BLK + ".joint_CA_FFN"
+    z = golden("modules_J17_C256.npz")
+    with torch.no_grad():
+        if stage == 1:
+            ref = O.cross_attention_only(xj, xv, xv, g, sd, ca, 8)
+            assert maxabs(y, T(z["ca_j_from_v"])) < 2e-5
+        elif stage == 2:
+            ref = O.cross_attention_block(xj, xv, xv, g, sd, ca, 8)
+            assert maxabs(y, T(z["cab_j_from_v"])) < 2e-5
+        else:
+            ref = O.ada_block(O.cross_attention_block(xj, xv, xv, g, sd, ca, 8), g, sd, BLK + ".joint_SA_FFN", 8)
+            ref_pose = O.linear(ref, sd, BLK + ".proj_joint_feat2coor", torch.float32) + jt
+            assert maxabs(pose, ref_pose) < 2e-5
+    e = maxabs(y, ref)
+    print(f"joint_stream stage {stage}: {e:.2e}")
+    assert e < 2e-5
+
+
+def test_j_regress(golden):
+    from pmce_amd import assets, ops
+    z = golden("e2e_J17_C256_B2.npz")
+    jr = assets.load_j_regressor("h36m")
+    out = ops.j_regress(T(z["cam_mesh"]).to(dev()), jr)
+    e = maxabs(out, T(z["pred_pose"]))
+    print(f"j_regress vs reference: {e:.2e} mm")
+    assert e < 2e-3           # millimetres (values ~1e3); 1e-3 m contract == 1 mm

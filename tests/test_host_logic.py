@@ -1,0 +1,145 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports every declared symbol, argument
+validation works without a GPU, the façade modules keep the reference's checkpoint layout, and the load-time
+weight packing is equivalent to the reference arithmetic it replaces."""
+import os.path as osp
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, cached_state_dict
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pmce_amd import _lib, build
+    build.build()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    import ctypes
+    from pmce_amd import _lib
+    hdr = open(osp.join(REPO, "include", "pmce_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pmce_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"{name} declared in include/pmce_hip.h but not exported"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert lib.pmce_version() == 100
+
+
+def test_argument_validation_without_gpu(lib):
+    from pmce_amd import _lib
+    rc = lib.pmce_gemm_nt_f32(1, 1, None, None, 1, 8, 8, 33, 33, 36, 8, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, None)
+    assert rc == -1 and "K%32" in _lib.last_error()
+    rc = lib.pmce_seq_attention_f32(1, 1, 4, 40, 256, 0, 1, 0, 1, None)
+    assert rc == -1 and "1..32" in _lib.last_error()
+    import ctypes as C
+    h = C.c_void_p()
+    assert lib.pmce_model_create(17, 300, 3, C.byref(h)) == -1
+    assert lib.pmce_model_create(19, 512, 3, C.byref(h)) == 0
+    names = [lib.pmce_model_tensor_name(h, i).decode() for i in range(lib.pmce_model_tensor_count(h))]
+    assert "dec.final.weight" in names and "lifter.SpatialBlocks.2.mlp.fc2.bias" in names
+    assert lib.pmce_model_set_tensor(h, b"nope", 16) == -1
+    assert lib.pmce_model_finalize(h) == -1                      # nothing registered
+    assert lib.pmce_model_workspace_bytes(h, 64) > 0
+    assert lib.pmce_forward(h, 16, 16, 16, 16, 16, None, 1, 256, 1 << 40, None) == -1   # not finalized
+    lib.pmce_model_destroy(h)
+
+
+def test_facade_keeps_reference_checkpoint_layout():
+    from pmce_amd import _lib, models, synth
+    spec = synth.pmce_spec(19, 256, 3)
+    m = models.PMCE.get_model(19, 256, 3)
+    sd = m.state_dict()
+    assert set(sd.keys()) == set(spec.keys()) and len(sd) == len(spec)
+    assert all(tuple(sd[k].shape) == tuple(spec[k][0]) for k in spec)
+    assert m.vj_relation.shape == (431,) and m.vj_relation.max() <= 16
+    assert not m.training
+    with pytest.raises(_lib.PmceError):
+        m(torch.zeros(1, 16, 19, 2), torch.zeros(1, 16, 2048))     # no CPU fallback
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({"model_state_dict": {"pose_lifter.joint_embed.weight": torch.zeros(256, 2)}})  # strict
+    lifter = models.PoseEstimation.get_model(17, 256, 3)
+    assert set(lifter.state_dict().keys()) == set(synth.lifter_spec(17, 256, 3).keys())
+    dec = models.CoevoDecoder.get_model(17, 256)
+    assert set(dec.state_dict().keys()) == set(synth.decoder_spec(17).keys())
+
+
+def test_packed_final_product_equals_conv_plus_linears():
+    """pack_final: Conv1d(431->6890,k=3,pad=1) + 3 Linear(2048->6890) == one [.,3360] x [3360,20670] product."""
+    from oracle import pmce_oracle as O
+    from pmce_amd import packing
+    sd = cached_state_dict(17, 256)
+    W, b = packing.pack_final(sd, "pose_mesh_coevo.", torch.device("cpu"))
+    assert W.shape == (20670, packing.FINAL_K) and b.shape == (20670,)
+    B = 2
+    g = T(np.random.default_rng(0).standard_normal((B, 2048)).astype(np.float32))
+    vt = T(np.random.default_rng(1).standard_normal((B, 431, 3)).astype(np.float32))
+    A = torch.zeros(B, packing.FINAL_K)
+    A[:, :2048] = torch.relu(g)
+    A[:, 2048:2048 + 1293] = vt.reshape(B, -1)
+    got = (A.double() @ W.double().t() + b.double()).reshape(B, 6890, 3)
+    with torch.no_grad():
+        ref = O.upsample_and_residual(vt, g, sd, "pose_mesh_coevo.", torch.float64)
+    assert float((got - ref).abs().max()) < 1e-6
+
+
+def test_packed_adaln_and_gru_layout():
+    from oracle import pmce_oracle as O
+    from pmce_amd import assets, packing
+    sd = cached_state_dict(17, 256)
+    _, vj, _ = assets.build_template("/nonexistent")
+    pk = packing.pack_decoder(sd, "pose_mesh_coevo.", torch.device("cpu"), 17, vj)
+    g = T(np.random.default_rng(2).standard_normal((3, 2048)).astype(np.float32))
+    GB = g @ pk["dec.ada.weight"].t() + pk["dec.ada.bias"]
+    assert GB.shape == (3, packing.N_ADA * 128)
+    for i, name in enumerate(packing.ADA_ORDER):
+        p = "pose_mesh_coevo." + name
+        gam = torch.nn.functional.linear(g, sd[p + ".mlp_gamma.weight"], sd[p + ".mlp_gamma.bias"])
+        bet = torch.nn.functional.linear(g, sd[p + ".mlp_beta.weight"], sd[p + ".mlp_beta.bias"])
+        assert torch.allclose(GB[:, i * 128:i * 128 + 64], gam, atol=1e-5)
+        assert torch.allclose(GB[:, i * 128 + 64:(i + 1) * 128], bet, atol=1e-5)
+    assert pk["dec.gru.w_ih_l0"].shape == (6144, 2048) and pk["dec.gru.w_hh_l1"].shape == (2, 3072, 1024)
+    assert torch.equal(pk["dec.gru.w_ih_l0"][3072:], sd["pose_mesh_coevo.gru_cur.weight_ih_l0_reverse"])
+    assert pk["dec.vj_relation"].dtype == torch.int32
+    k3 = "pose_mesh_coevo.coevoblock3."
+    eq = sd[k3 + "vertx_proj.bias"][None] + sd[k3 + "vertx_pos_embed"][0] + sd[k3 + "v_Q_embed"][0]
+    assert torch.allclose(pk["dec.b3.Eq"], eq, atol=1e-6)
+    # every tensor the C model asks for is produced by the packers, and nothing else
+    import ctypes as C
+    from pmce_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.pmce_model_create(17, 256, 3, C.byref(h)) == 0
+    names = {lib.pmce_model_tensor_name(h, i).decode() for i in range(lib.pmce_model_tensor_count(h))}
+    lib.pmce_model_destroy(h)
+    lk = set(packing.pack_lifter(sd, "pose_lifter.", torch.device("cpu"), 17, 256, 3).keys())
+    assert names == lk | set(pk.keys()), names ^ (lk | set(pk.keys()))
+
+
+def test_regressor_csr_roundtrip():
+    from pmce_amd import assets
+    for name, nnz in (("h36m", 107), ("coco", 105)):
+        jr = assets.load_j_regressor(name)
+        indptr, indices, data = assets.regressor_to_csr(jr)
+        assert jr.shape == (17, 6890) and len(data) == nnz and indptr[-1] == nnz
+        dense = np.zeros_like(jr, dtype=np.float32)
+        for r in range(17):
+            dense[r, indices[indptr[r]:indptr[r + 1]]] = data[indptr[r]:indptr[r + 1]]
+        assert np.array_equal(dense, jr.astype(np.float32))
+
+
+def test_build_verts_joints_relation_ties_first_index():
+    from pmce_amd import assets
+    joints = np.array([[0, 0, 0], [2, 0, 0], [0, 0, 0]], dtype=np.float32)       # joint 2 duplicates joint 0
+    verts = np.array([[0.1, 0, 0], [1.0, 0, 0], [1.9, 0, 0]], dtype=np.float32)  # middle vertex equidistant
+    assert assets.build_verts_joints_relation(joints, verts).tolist() == [0, 0, 1]
