@@ -279,7 +279,7 @@ __global__ __launch_bounds__(512) void vertex_ca_kernel(const float* __restrict_
 // Persistent workgroups (4 waves); fc1/fc2 weights live in LDS (137 KB) for the whole kernel; each wave walks
 // over 32-token tiles; the 256-wide hidden activation exists only as 16 registers at a time.
 // ======================================================================================================
-__global__ __launch_bounds__(256) void adaln_mlp_kernel(const float* __restrict__ xin, const float* __restrict__ GB,
+__global__ __launch_bounds__(512) void adaln_mlp_kernel(const float* __restrict__ xin, const float* __restrict__ GB,
                                                         int gb_stride, int inst, const float* __restrict__ W1,
                                                         const float* __restrict__ b1, const float* __restrict__ W2,
                                                         const float* __restrict__ b2, float* __restrict__ yout,
@@ -291,15 +291,15 @@ __global__ __launch_bounds__(256) void adaln_mlp_kernel(const float* __restrict_
   float* sB1 = sW2 + 64 * LDW256;       // [256]
   float* sB2 = sB1 + 256;               // [64]
   const int tid = threadIdx.x;
-  stage_weight<64>(sW1, W1, 256, tid, 256);
-  stage_weight<256>(sW2, W2, 64, tid, 256);
-  sB1[tid] = b1[tid];
+  stage_weight<64>(sW1, W1, 256, tid, 512);
+  stage_weight<256>(sW2, W2, 64, tid, 512);
+  if (tid < 256) sB1[tid] = b1[tid];
   if (tid < 64) sB2[tid] = b2[tid];
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   const int n0 = lane & 31, hb = lane >> 5;
   const int ntiles = B * NTILE;
-  for (int wt = blockIdx.x * 4 + wave; wt < ntiles; wt += gridDim.x * 4) {
+  for (int wt = blockIdx.x * 8 + wave; wt < ntiles; wt += gridDim.x * 8) {
     const int b = wt / NTILE, tile = wt % NTILE;
     const int v = tile * 32 + n0;
     const bool valid = v < NV;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void adaln_qkv_kernel(const float* __restrict_
 // ======================================================================================================
 #define SA_KLD 68
 #define SA_VLD 64
-__global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict__ xin, const float* __restrict__ qkv,
+__global__ __launch_bounds__(448, 4) void vertex_sa_kernel(const float* __restrict__ xin, const float* __restrict__ qkv,
                                                         const float* __restrict__ Wp, const float* __restrict__ bp,
                                                         float* __restrict__ yout) {
   __shared__ __attribute__((aligned(16))) float sK[2][32 * SA_KLD];
@@ -852,7 +852,7 @@ __global__ __launch_bounds__(256) void j_regress_kernel(const float* __restrict_
 // ======================================================================================================
 static int mlp_grid(int B) {
   const int tiles = B * NTILE;
-  int g = (tiles + 3) / 4;
+  int g = (tiles + 7) / 8;
   return g < 256 ? g : 256;
 }
 static int tl_grid(int B, int per_cu) {
@@ -907,7 +907,7 @@ extern "C" int pmce_adaln_mlp_f32(const float* xin, const float* GB, int gb_stri
     (void)hipFuncSetAttribute((const void*)adaln_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL(adaln_mlp_kernel, dim3(mlp_grid(B)), dim3(256), lds, stream, xin, GB, gb_stride, inst, W1, b1, W2, b2,
+  hipLaunchKernelGGL(adaln_mlp_kernel, dim3(mlp_grid(B)), dim3(512), lds, stream, xin, GB, gb_stride, inst, W1, b1, W2, b2,
                      yout, Wc, bc, vt_in, vt_out, B);
   return pmce_check_launch("adaln_mlp");
 }

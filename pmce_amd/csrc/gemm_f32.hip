@@ -31,8 +31,8 @@ struct GemmParams {
   int ntm, ntn;                     // tile counts
 };
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
+template <int BM, int BN, int ACT, bool RES, bool CMAP>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
   constexpr int LD = 36;
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -64,28 +64,29 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
   const float* __restrict__ A = p.A + (long long)blockIdx.z * p.bsA;
   const float* __restrict__ W = p.W + (long long)blockIdx.z * p.bsW;
 
-  // ---- per-thread global source pointers (fixed rows, advancing k) ----
+  // ---- per-thread global source pointers (fixed rows, advancing k).  Rows past the edge are CLAMPED to the
+  // last valid row (their products are never stored), so the k-loop has no predicated loads or branches. ----
   const int kc = (tid & 7) * 4, r0 = tid >> 3;
   const float* aptr[LA];
   const float* bptr[LB];
 #pragma unroll
   for (int i = 0; i < LA; ++i) {
-    const int r = m_base + r0 + 32 * i;
-    aptr[i] = (r < p.M) ? A + (long long)(r % p.a_div) * p.a_lo + (long long)(r / p.a_div) * p.a_hi + kc : nullptr;
+    const int r = min(m_base + r0 + 32 * i, p.M - 1);
+    aptr[i] = A + (long long)(r % p.a_div) * p.a_lo + (long long)(r / p.a_div) * p.a_hi + kc;
   }
 #pragma unroll
   for (int i = 0; i < LB; ++i) {
-    const int r = n_base + r0 + 32 * i;
-    bptr[i] = (r < p.N) ? W + (long long)r * p.ldw + kc : nullptr;
+    const int r = min(n_base + r0 + 32 * i, p.N - 1);
+    bptr[i] = W + (long long)r * p.ldw + kc;
   }
 
   f32x4 ra[LA], rb[LB];
   auto gload = [&](int kt) {
     const int ko = kt * 32;
 #pragma unroll
-    for (int i = 0; i < LA; ++i) ra[i] = aptr[i] ? *reinterpret_cast<const f32x4*>(aptr[i] + ko) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < LA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(aptr[i] + ko);
 #pragma unroll
-    for (int i = 0; i < LB; ++i) rb[i] = bptr[i] ? *reinterpret_cast<const f32x4*>(bptr[i] + ko) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < LB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bptr[i] + ko);
   };
   auto lstore = [&](int buf) {
 #pragma unroll
@@ -129,10 +130,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: bias, activation, residual; D layout: col = lane&31, row = (r&3)+8*(r>>2)+4*hb ----
+  // ---- epilogue: bias, activation, residual; D layout: col = lane&31, row = (r&3)+8*(r>>2)+4*hb.
+  // Interior tiles take a branch-free path: the 16 residual loads of a 32x32 sub-tile are issued back to back,
+  // then the 16 stores (each a 128-byte row segment per half-wave). ----
   float* __restrict__ C = p.C + (long long)blockIdx.z * p.bsC;
-  const float* __restrict__ R = p.R ? p.R + (long long)blockIdx.z * p.bsC : nullptr;
+  const float* __restrict__ R = RES ? p.R + (long long)blockIdx.z * p.bsC : nullptr;
   const float* __restrict__ bias = p.bias ? p.bias + (long long)blockIdx.z * p.bsBias : nullptr;
+  const bool full = (m_base + BM <= p.M) && (n_base + BN <= p.N);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n_base + wn * WN + j * 32 + n0;
@@ -140,18 +144,60 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
     const float bv = (bias && nok) ? bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      const int mrow = m_base + wm * WM + i * 32 + 4 * hb;
+      if (CMAP) {  // mapped rows (GRU layer-0 input projection: (b,t) rows -> time-major); never with act/residual
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m_base + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
-        if (nok && m < p.M) {
-          const long long off = (long long)(m % p.c_div) * p.c_lo + (long long)(m / p.c_div) * p.c_hi + n;
-          float v = acc[i][j][r] + bv;
-          if (p.act == 1) v = gelu_erf(v);
-          if (R) v += R[off];
-          C[off] = v;
+        for (int r = 0; r < 16; ++r) {
+          const int m = mrow + (r & 3) + 8 * (r >> 2);
+          if (nok && m < p.M)
+            C[(long long)(m % p.c_div) * p.c_lo + (long long)(m / p.c_div) * p.c_hi + n] = acc[i][j][r] + bv;
+        }
+      } else {
+        const int ldc = (int)p.c_lo;
+        float* __restrict__ Cp = C + (long long)mrow * ldc + n;   // 32-bit offsets from here on
+        const float* __restrict__ Rp = RES ? R + (long long)mrow * ldc + n : nullptr;
+        if (full) {
+          float rv[16];
+          if (RES) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = Rp[((r & 3) + 8 * (r >> 2)) * ldc];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[i][j][r] + bv;
+            if (ACT == 1) v = gelu_erf(v);
+            if (RES) v += rv[r];
+            Cp[((r & 3) + 8 * (r >> 2)) * ldc] = v;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2);
+            if (nok && mrow + rr < p.M) {
+              float v = acc[i][j][r] + bv;
+              if (ACT == 1) v = gelu_erf(v);
+              if (RES) v += Rp[rr * ldc];
+              Cp[rr * ldc] = v;
+            }
+          }
         }
       }
     }
+  }
+}
+
+template <int BM, int BN>
+static void launch_gemm(const GemmParams& p, int batch, bool cmap, hipStream_t stream) {
+  const dim3 grid(p.ntm * p.ntn, 1, batch), block(256);
+  const bool res = p.R != nullptr;
+  if (cmap) {
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, 0, false, true>), grid, block, 0, stream, p);
+  } else if (p.act == 1) {
+    if (res) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, 1, true, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, 1, false, false>), grid, block, 0, stream, p);
+  } else {
+    if (res) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, 0, true, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, 0, false, false>), grid, block, 0, stream, p);
   }
 }
 
@@ -170,16 +216,19 @@ extern "C" int pmce_gemm_nt_f32(const float* A, const float* W, const float* bia
   if (a_div <= 0) { p.a_div = 0x7fffffff; p.a_lo = lda; p.a_hi = 0; } else { p.a_div = a_div; p.a_lo = a_lo; p.a_hi = a_hi; }
   if (c_div <= 0) { p.c_div = 0x7fffffff; p.c_lo = ldc; p.c_hi = 0; } else { p.c_div = c_div; p.c_lo = c_lo; p.c_hi = c_hi; }
   PMCE_REQUIRE(p.a_lo % 4 == 0 && p.a_hi % 4 == 0, "gemm: A row strides must be multiples of 4 floats (16-byte loads)");
+  const bool cmap = c_div > 0;
+  PMCE_REQUIRE(!cmap || (act == 0 && R == nullptr), "gemm: a C row map cannot be combined with act/residual");
+  PMCE_REQUIRE(cmap || p.c_lo < (1ll << 26), "gemm: ldc too large");
   p.act = act;
   p.bsA = bsA; p.bsW = bsW; p.bsBias = bsBias; p.bsC = bsC;
   // tile choice: big tiles when they still fill the chip (>= 1 block per CU), else 64x64
   const long long big = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch;
   if (big >= 256) {
     p.ntm = (M + 127) / 128; p.ntn = (N + 127) / 128;
-    hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), dim3(p.ntm * p.ntn, 1, batch), dim3(256), 0, stream, p);
+    launch_gemm<128, 128>(p, batch, cmap, stream);
   } else {
     p.ntm = (M + 63) / 64; p.ntn = (N + 63) / 64;
-    hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), dim3(p.ntm * p.ntn, 1, batch), dim3(256), 0, stream, p);
+    launch_gemm<64, 64>(p, batch, cmap, stream);
   }
   return pmce_check_launch("gemm_nt_f32");
 }

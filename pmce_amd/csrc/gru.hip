@@ -56,6 +56,152 @@ extern "C" int pmce_gru_gates_f32(const float* gi0, const float* gi1, const floa
   return pmce_check_launch("gru_gates");
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Fused GRU time step: gh = h_prev W_hh^T (fp32 MFMA) + gate update, one launch for up to two directions.
+// Block = 64 batch rows x 32 hidden units x {r,z,n}; 4 waves = 2 row blocks x 2 K-halves (K = 1024 split in two so
+// that B = 256 gives 4 x 32 x 2 = 256 blocks, one per CU, all four SIMDs busy); the K-halves meet in LDS and
+// the gate math runs on the accumulator layout (col = unit, row = batch), so gh never touches HBM.
+// ------------------------------------------------------------------------------------------------------
+struct GruStepArgs {
+  const float* gi[2];     // + row*gi_rs + gate*H + unit   (b_ih already added by the input-projection GEMM)
+  const float* whh[2];    // [3H][H]
+  const float* bhh[2];    // [3H]
+  const float* hprev[2];  // + row*h_rs + unit ; null -> h = 0 (first step)
+  float* hout[2];         // + row*h_rs + unit
+  long long gi_rs, h_rs;
+  int B, H;
+};
+
+__global__ __launch_bounds__(256) void gru_step_kernel(GruStepArgs a) {
+  constexpr int LD = 36, KH = 16;  // 16 k per half per iteration
+  __shared__ __attribute__((aligned(16))) float smem[2 * (64 + 96) * LD];
+  const int d = blockIdx.z;
+  const int u0 = blockIdx.x * 32, m0 = blockIdx.y * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = lane & 31, hb = lane >> 5;
+  const int rb = wave & 1, kh = wave >> 1;
+  const int H = a.H, Khalf = H / 2;
+  const float* __restrict__ hp = a.hprev[d];
+  const float* __restrict__ W = a.whh[d];
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+
+  if (hp) {
+    // per-thread staging assignment: A 64 rows x 8 float4, W 96 rows x 8 float4 per iteration
+    const float* ap[2];
+    const float* wp[3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 3, c4 = idx & 7;
+      const int m = min(m0 + row, a.B - 1);
+      ap[i] = hp + (long long)m * a.h_rs + (c4 >> 2) * Khalf + (c4 & 3) * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 3, c4 = idx & 7;
+      const int gate = row >> 5, u = row & 31;
+      wp[i] = W + (long long)(gate * H + u0 + u) * H + (c4 >> 2) * Khalf + (c4 & 3) * 4;
+    }
+    f32x4 ra[2], rw[3];
+    auto gload = [&](int kt) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * KH);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) rw[i] = *reinterpret_cast<const f32x4*>(wp[i] + kt * KH);
+    };
+    auto lstore = [&](int buf) {
+      float* As = smem + buf * (64 + 96) * LD;
+      float* Bs = As + 64 * LD;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i;
+        *reinterpret_cast<f32x4*>(As + (idx >> 3) * LD + (idx & 7) * 4) = ra[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int idx = tid + 256 * i;
+        *reinterpret_cast<f32x4*>(Bs + (idx >> 3) * LD + (idx & 7) * 4) = rw[i];
+      }
+    };
+    const int nk = Khalf / KH;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) gload(kt + 1);
+      const float* As = smem + buf * (64 + 96) * LD + (rb * 32 + n0) * LD + kh * 16 + 4 * hb;
+      const float* Bs = smem + buf * (64 + 96) * LD + 64 * LD + n0 * LD + kh * 16 + 4 * hb;
+#pragma unroll
+      for (int g8 = 0; g8 < 2; ++g8) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(As + 8 * g8);
+        f32x4 bv[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) bv[g] = *reinterpret_cast<const f32x4*>(Bs + g * 32 * LD + 8 * g8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[g][s], acc[g], 0, 0, 0);
+      }
+      if (kt + 1 < nk) lstore(buf ^ 1);
+      __syncthreads();
+    }
+    // meet the two K-halves: waves kh=1 publish, waves kh=0 accumulate
+    float* red = smem;  // [rb][gate][r][lane] = 2*3*16*64 floats = 24.6 KB (tiles are dead now)
+    if (kh == 1) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((rb * 3 + g) * 16 + r) * 64 + lane] = acc[g][r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] += red[((rb * 3 + g) * 16 + r) * 64 + lane];
+    }
+  }
+  if (kh != 0) return;
+  // gate update on the D layout: unit = u0 + (lane & 31), batch row = m0 + rb*32 + (r&3) + 8*(r>>2) + 4*hb
+  const int u = u0 + n0;
+  const float* __restrict__ bh = a.bhh[d];
+  const float bhr = bh[u], bhz = bh[H + u], bhn = bh[2 * H + u];
+  const float* __restrict__ gi = a.gi[d];
+  float* __restrict__ ho = a.hout[d];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
+    if (m < a.B) {
+      const float* g = gi + (long long)m * a.gi_rs + u;
+      const float hprev = hp ? hp[(long long)m * a.h_rs + u] : 0.f;
+      const float rr = sigmoidf_acc(g[0] + (acc[0][r] + bhr));
+      const float zz = sigmoidf_acc(g[H] + (acc[1][r] + bhz));
+      const float nn = tanhf(g[2 * H] + rr * (acc[2][r] + bhn));
+      ho[(long long)m * a.h_rs + u] = (1.0f - zz) * nn + zz * hprev;
+    }
+  }
+}
+
+extern "C" int pmce_gru_step_f32(const float* gi0, const float* gi1, const float* whh0, const float* whh1, const float* bhh0,
+                                 const float* bhh1, const float* hp0, const float* hp1, float* ho0, float* ho1,
+                                 long long gi_rs, long long h_rs, int B, int H, int ndir, hipStream_t stream) {
+  PMCE_REQUIRE(ndir == 1 || ndir == 2, "gru_step: ndir must be 1 or 2");
+  PMCE_REQUIRE(gi0 && whh0 && bhh0 && ho0 && B > 0, "gru_step: null pointer");
+  PMCE_REQUIRE(ndir == 1 || (gi1 && whh1 && bhh1 && ho1), "gru_step: second direction pointers missing");
+  PMCE_REQUIRE(H > 0 && H % 64 == 0 && h_rs % 4 == 0, "gru_step: H must be a multiple of 64, h_rs of 4");
+  GruStepArgs a;
+  a.gi[0] = gi0; a.gi[1] = gi1; a.whh[0] = whh0; a.whh[1] = whh1; a.bhh[0] = bhh0; a.bhh[1] = bhh1;
+  a.hprev[0] = hp0; a.hprev[1] = hp1; a.hout[0] = ho0; a.hout[1] = ho1;
+  a.gi_rs = gi_rs; a.h_rs = h_rs; a.B = B; a.H = H;
+  hipLaunchKernelGGL(gru_step_kernel, dim3(H / 32, (B + 63) / 64, ndir), dim3(256), 0, stream, a);
+  return pmce_check_launch("gru_step");
+}
+
 // joints(m) = pose3d(mm) / 1000   (reference PMCE.py:18 — a true division, kept as one)
 __global__ __launch_bounds__(256) void scale_div_kernel(const float* __restrict__ x, float* __restrict__ y, long long n,
                                                         float denom) {

@@ -20,13 +20,13 @@ constexpr int FINAL_K = 3360;  // 2048 + 1293 = 3341 rounded up to a multiple of
 constexpr int N_ADA = 24;      // live AdaLN instances (joint stream of blocks 1-2 is dead at inference)
 
 enum ProfClass {
-  P_GEMM_LIFTER, P_GEMM_GRU_IN, P_GEMM_GRU_REC, P_GEMM_ADA, P_GEMM_FINAL, P_LN, P_SEQ_ATTN, P_EMBED, P_HEAD, P_GRU_GATES,
+  P_GEMM_LIFTER, P_GEMM_GRU_IN, P_GRU_STEP, P_GEMM_ADA, P_GEMM_FINAL, P_LN, P_SEQ_ATTN, P_EMBED, P_HEAD, P_GRU_GATES_UNUSED,
   P_GATHER, P_JOINT_EMBED, P_CA_FOLD, P_VERTEX_CA, P_ADALN_MLP, P_ADALN_QKV, P_VERTEX_SA, P_TOKENS_KV, P_JOINT_STREAM,
   P_FINAL_OP, P_JREG, P_MISC, P_COUNT
 };
 const char* kProfNames[P_COUNT] = {
-    "gemm_lifter", "gemm_gru_in", "gemm_gru_rec", "gemm_ada", "gemm_final", "ln_chain", "seq_attention", "embed_tokens",
-    "lifter_head", "gru_gates", "vertex_init_gather", "joint_embed", "ca_fold", "vertex_ca", "adaln_mlp", "adaln_qkv",
+    "gemm_lifter", "gemm_gru_in", "gru_step", "gemm_ada", "gemm_final", "ln_chain", "seq_attention", "embed_tokens",
+    "lifter_head", "gru_gates_unused", "vertex_init_gather", "joint_embed", "ca_fold", "vertex_ca", "adaln_mlp", "adaln_qkv",
     "vertex_sa", "tokens_kv", "joint_stream", "build_final_operand", "j_regress", "misc"};
 
 struct Ev {
@@ -240,7 +240,7 @@ int lifter_impl(pmce_model* m, const float* pose2d, const float* img_feat, float
 
 // ---- Pose2Mesh.forward ------------------------------------------------------------------------------------
 int gru_layer(pmce_model* m, int layer, const float* gi_f, const float* gi_b, long long gi_rs, int t_f0, int t_b0,
-              int nsteps_f, int nsteps_b, float* Y, float* GHb, int B, hipStream_t stream) {
+              int nsteps_f, int nsteps_b, float* Y, int B, hipStream_t stream) {
   // direction 0 walks t = t_f0, t_f0+1, ...; direction 1 walks t = t_b0, t_b0-1, ...  Y is [T][B][2*GH].
   const std::string l = std::to_string(layer);
   const float* whh = m->f("dec.gru.w_hh_l" + l);
@@ -252,37 +252,20 @@ int gru_layer(pmce_model* m, int layer, const float* gi_f, const float* gi_b, lo
     const int tf = t_f0 + s, tb = t_b0 - s;
     const float* hp_f = (s > 0 && af) ? Y + (long long)(tf - 1) * YS : nullptr;
     const float* hp_b = (s > 0 && ab) ? Y + (long long)(tb + 1) * YS + GH : nullptr;
-    float* gh_f = GHb;
-    float* gh_b = GHb + (long long)B * 3 * GH;
-    if (s > 0) {
-      if (af && ab) {
-        RUN(P_GEMM_GRU_REC, pmce_gemm_nt_f32(hp_f, whh, bhh, nullptr, gh_f, B, 3 * GH, GH, 2 * GH, GH, 3 * GH, 0, 0, 0, 0, 0,
-                                             0, 0, 2, hp_b - hp_f, (long long)3 * GH * GH, 3 * GH, (long long)B * 3 * GH,
-                                             stream));
-      } else if (af) {
-        RUN(P_GEMM_GRU_REC, gemm(hp_f, whh, bhh, nullptr, gh_f, B, 3 * GH, GH, 2 * GH, 3 * GH, 0, stream));
-      } else {
-        RUN(P_GEMM_GRU_REC, gemm(hp_b, whh + (long long)3 * GH * GH, bhh + 3 * GH, nullptr, gh_b, B, 3 * GH, GH, 2 * GH,
-                                 3 * GH, 0, stream));
-      }
-    }
-    // gate update; on the first step gh = b_hh broadcast (row stride 0) and h = 0
-    const float* ghp_f = s > 0 ? gh_f : bhh;
-    const float* ghp_b = s > 0 ? gh_b : bhh + 3 * GH;
-    const long long ghrs = s > 0 ? 3 * GH : 0;
-    const float* gif = gi_f + (long long)s * B * gi_rs;                 // slab of time tf
+    const float* gif = gi_f + (long long)s * B * gi_rs;                   // slab of time tf
     const float* gib = gi_b + (long long)(nsteps_b - 1 - s) * B * gi_rs;  // slab of time tb (slabs stored ascending in t)
     float* ho_f = Y + (long long)tf * YS;
     float* ho_b = Y + (long long)tb * YS + GH;
+    const float* whh_b = whh + (long long)3 * GH * GH;
+    const float* bhh_b = bhh + 3 * GH;
     if (af && ab)
-      RUN(P_GRU_GATES, pmce_gru_gates_f32(gif, gib, ghp_f, ghp_b, hp_f, hp_b, ho_f, ho_b, gi_rs, ghrs, ghrs, 2 * GH, 2 * GH, B,
-                                          GH, 2, stream));
+      RUN(P_GRU_STEP, pmce_gru_step_f32(gif, gib, whh, whh_b, bhh, bhh_b, hp_f, hp_b, ho_f, ho_b, gi_rs, 2 * GH, B, GH, 2, stream));
     else if (af)
-      RUN(P_GRU_GATES, pmce_gru_gates_f32(gif, nullptr, ghp_f, nullptr, hp_f, nullptr, ho_f, nullptr, gi_rs, ghrs, ghrs, 2 * GH,
-                                          2 * GH, B, GH, 1, stream));
+      RUN(P_GRU_STEP, pmce_gru_step_f32(gif, nullptr, whh, nullptr, bhh, nullptr, hp_f, nullptr, ho_f, nullptr, gi_rs, 2 * GH, B, GH,
+                                        1, stream));
     else
-      RUN(P_GRU_GATES, pmce_gru_gates_f32(gib, nullptr, ghp_b, nullptr, hp_b, nullptr, ho_b, nullptr, gi_rs, ghrs, ghrs, 2 * GH,
-                                          2 * GH, B, GH, 1, stream));
+      RUN(P_GRU_STEP, pmce_gru_step_f32(gib, nullptr, whh_b, nullptr, bhh_b, nullptr, hp_b, nullptr, ho_b, nullptr, gi_rs, 2 * GH, B,
+                                        GH, 1, stream));
   }
   return PMCE_OK;
 }
@@ -296,7 +279,7 @@ int decoder_impl(pmce_model* m, const float* joints, const float* img_feat, floa
                                       6 * GH, F, F, F, 6 * GH, 0, 0, 0, 0, T, (long long)B * 6 * GH, 6 * GH, 1, 0, 0, 0, 0,
                                       stream));
   // layer 0: both directions over all 16 steps.  gi slabs: fwd reads column block 0, bwd column block 1 of GI0.
-  PMCE_TRY(gru_layer(m, 0, w.GI0, w.GI0 + 3 * GH, 6 * GH, 0, T - 1, T, T, w.Y0, w.GHb, B, stream));
+  PMCE_TRY(gru_layer(m, 0, w.GI0, w.GI0 + 3 * GH, 6 * GH, 0, T - 1, T, T, w.Y0, B, stream));
   // layer 1: only y[8] is consumed (CoevoDecoder.py:229,241-243) -> fwd needs t = 0..8, bwd t = 15..8.
   float* GI1f = w.GI1;
   float* GI1b = w.GI1 + (long long)9 * B * 3 * GH;
@@ -304,7 +287,7 @@ int decoder_impl(pmce_model* m, const float* joints, const float* img_feat, floa
                           3 * GH, 0, stream));
   RUN(P_GEMM_GRU_IN, gemm(w.Y0 + (long long)8 * B * 2 * GH, m->f("dec.gru.w_ih_l1") + (long long)3 * GH * 2 * GH,
                           m->f("dec.gru.b_ih_l1") + 3 * GH, nullptr, GI1b, 8 * B, 3 * GH, 2 * GH, 2 * GH, 3 * GH, 0, stream));
-  PMCE_TRY(gru_layer(m, 1, GI1f, GI1b, 3 * GH, 0, T - 1, 9, 8, w.Y1, w.GHb, B, stream));
+  PMCE_TRY(gru_layer(m, 1, GI1f, GI1b, 3 * GH, 0, T - 1, 9, 8, w.Y1, B, stream));
   const float* g = w.Y1 + (long long)8 * B * 2 * GH;  // img_feat = y[seqlen // 2], [B, 2048]
 
   // ---- all live AdaLN gamma/beta in one product (CoevoDecoder.py:19-20,27-28) ----
