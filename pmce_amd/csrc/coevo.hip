@@ -461,7 +461,8 @@ __global__ __launch_bounds__(448, 4) void vertex_sa_kernel(const float* __restri
   const long long tok = (long long)b * NV + (valid ? v : NV - 1);
   float q[32];
   load_slots(qkv + tok * 192, q, hb);
-  const float scale = 0.17677669529663688110f;  // 32^-0.5
+  // 32^-0.5 * log2(e): scores are kept in log2 units so the softmax uses the native v_exp_f32 (2^x)
+  const float scale = 0.17677669529663688110f * 1.44269504088896340736f;
 #pragma unroll
   for (int s = 0; s < 32; ++s) q[s] *= scale;
 
@@ -497,11 +498,11 @@ __global__ __launch_bounds__(448, 4) void vertex_sa_kernel(const float* __restri
       }
       mt = pair_max(mt);
       const float mn = fmaxf(mrun[h], mt);
-      const float corr = expf(mrun[h] - mn);
+      const float corr = __builtin_amdgcn_exp2f(mrun[h] - mn);
       float pr[16], sum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        pr[r] = expf(S[r] - mn);
+        pr[r] = __builtin_amdgcn_exp2f(S[r] - mn);
         sum += pr[r];
       }
       lrun[h] = lrun[h] * corr + pair_sum(sum);

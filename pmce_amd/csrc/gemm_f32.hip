@@ -12,6 +12,8 @@
 // (8 lanes x 16 B per row), register-prefetched one tile ahead, double-buffered in LDS with a 36-float row
 // stride (conflict-free ds_read_b128).  The k order inside each group of 8 is permuted (lanes 0-31 take
 // k..k+3, lanes 32-63 take k+4..k+7) so that one ds_read_b128 per operand feeds four MFMAs.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 struct GemmParams {
@@ -29,12 +31,15 @@ struct GemmParams {
   int act;  // 0 none, 1 exact-erf GELU
   long long bsA, bsW, bsBias, bsC;  // per-blockIdx.z offsets (elements)
   int ntm, ntn;                     // tile counts
+  int grid_cap;                     // persistent workgroups per batch entry
 };
 
-template <int BM, int BN, int ACT, bool RES, bool CMAP>
+template <int BM, int BN, int WGM, int ACT, bool RES, bool CMAP>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
   constexpr int LD = 36;
-  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int WGN = 4 / WGM;  // 4 waves arranged WGM x WGN
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int LA = BM / 32, LB = BN / 32;  // float4 loads per thread per tile
   __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
@@ -43,42 +48,49 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int n0 = lane & 31, hb = lane >> 5;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WGM, wn = wave / WGM;
 
-  // ---- XCD-aware, grouped tile order: consecutive tile ids of one XCD share A/W panels in its L2 ----
+  // ---- persistent workgroups.  The hardware places workgroup b on XCD b % 8; XCD x owns a contiguous chunk of
+  // the (grouped) tile order and its resident workgroups walk that chunk round-robin, so the tiles in flight on
+  // one XCD share A / W panels in its L2.  Correctness never depends on the placement. ----
   const int nblk = p.ntm * p.ntn;
-  int bid = blockIdx.x;
-  {
-    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective remap
-  }
+  const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, gx = gridDim.x >> 3;
+  const int cq = nblk >> 3, cr = nblk & 7;
+  const int chunk_start = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+  const int chunk_len = cq + (xcd < cr ? 1 : 0);
   constexpr int GROUP_M = 8;
   const int per_group = GROUP_M * p.ntn;
-  const int group = bid / per_group;
-  const int first_m = group * GROUP_M;
-  const int gsz = min(p.ntm - first_m, GROUP_M);
-  const int tile_m = first_m + (bid % per_group) % gsz;
-  const int tile_n = (bid % per_group) / gsz;
-  const int m_base = tile_m * BM, n_base = tile_n * BN;
+  auto tile_coords = [&](int bid, int& m_base, int& n_base) {
+    const int group = bid / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(p.ntm - first_m, GROUP_M);
+    m_base = (first_m + (bid % per_group) % gsz) * BM;
+    n_base = ((bid % per_group) / gsz) * BN;
+  };
 
   const float* __restrict__ A = p.A + (long long)blockIdx.z * p.bsA;
   const float* __restrict__ W = p.W + (long long)blockIdx.z * p.bsW;
+  float* __restrict__ C = p.C + (long long)blockIdx.z * p.bsC;
+  const float* __restrict__ R = RES ? p.R + (long long)blockIdx.z * p.bsC : nullptr;
+  const float* __restrict__ bias = p.bias ? p.bias + (long long)blockIdx.z * p.bsBias : nullptr;
 
   // ---- per-thread global source pointers (fixed rows, advancing k).  Rows past the edge are CLAMPED to the
   // last valid row (their products are never stored), so the k-loop has no predicated loads or branches. ----
   const int kc = (tid & 7) * 4, r0 = tid >> 3;
   const float* aptr[LA];
   const float* bptr[LB];
+  auto set_ptrs = [&](int m_base, int n_base) {
 #pragma unroll
-  for (int i = 0; i < LA; ++i) {
-    const int r = min(m_base + r0 + 32 * i, p.M - 1);
-    aptr[i] = A + (long long)(r % p.a_div) * p.a_lo + (long long)(r / p.a_div) * p.a_hi + kc;
-  }
+    for (int i = 0; i < LA; ++i) {
+      const int r = min(m_base + r0 + 32 * i, p.M - 1);
+      aptr[i] = A + (long long)(r % p.a_div) * p.a_lo + (long long)(r / p.a_div) * p.a_hi + kc;
+    }
 #pragma unroll
-  for (int i = 0; i < LB; ++i) {
-    const int r = min(n_base + r0 + 32 * i, p.N - 1);
-    bptr[i] = W + (long long)r * p.ldw + kc;
-  }
+    for (int i = 0; i < LB; ++i) {
+      const int r = min(n_base + r0 + 32 * i, p.N - 1);
+      bptr[i] = W + (long long)r * p.ldw + kc;
+    }
+  };
 
   f32x4 ra[LA], rb[LB];
   auto gload = [&](int kt) {
@@ -95,110 +107,157 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
     for (int i = 0; i < LB; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][(r0 + 32 * i) * LD + kc]) = rb[i];
   };
 
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   const int nk = p.K / 32;
+  int li = bx;
+  if (li >= chunk_len) return;
+  int m_base, n_base;
+  tile_coords(chunk_start + li, m_base, n_base);
+  set_ptrs(m_base, n_base);
   gload(0);
   lstore(0);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-    const float* as = &As[buf][(wm * WM + n0) * LD + 4 * hb];
-    const float* bs = &Bs[buf][(wn * WN + n0) * LD + 4 * hb];
+  int buf = 0;
+  for (; li < chunk_len; li += gx) {
+    const bool has_next = li + gx < chunk_len;
+    int m_next = 0, n_next = 0;
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 a[TM], b[TN];
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LD + 8 * g);
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LD + 8 * g);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) lstore(buf ^ 1);
-    __syncthreads();
-  }
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // ---- epilogue: bias, activation, residual; D layout: col = lane&31, row = (r&3)+8*(r>>2)+4*hb.
-  // Interior tiles take a branch-free path: the 16 residual loads of a 32x32 sub-tile are issued back to back,
-  // then the 16 stores (each a 128-byte row segment per half-wave). ----
-  float* __restrict__ C = p.C + (long long)blockIdx.z * p.bsC;
-  const float* __restrict__ R = RES ? p.R + (long long)blockIdx.z * p.bsC : nullptr;
-  const float* __restrict__ bias = p.bias ? p.bias + (long long)blockIdx.z * p.bsBias : nullptr;
-  const bool full = (m_base + BM <= p.M) && (n_base + BN <= p.N);
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n_base + wn * WN + j * 32 + n0;
-    const bool nok = n < p.N;
-    const float bv = (bias && nok) ? bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mrow = m_base + wm * WM + i * 32 + 4 * hb;
-      if (CMAP) {  // mapped rows (GRU layer-0 input projection: (b,t) rows -> time-major); never with act/residual
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mrow + (r & 3) + 8 * (r >> 2);
-          if (nok && m < p.M)
-            C[(long long)(m % p.c_div) * p.c_lo + (long long)(m / p.c_div) * p.c_hi + n] = acc[i][j][r] + bv;
-        }
+    for (int kt = 0; kt < nk; ++kt) {
+      bool loaded = true;
+      if (kt + 1 < nk) {
+        gload(kt + 1);
+      } else if (has_next) {  // cross-tile prefetch: the next tile's first k-tile flies under this tile's last MFMAs
+        tile_coords(chunk_start + li + gx, m_next, n_next);
+        set_ptrs(m_next, n_next);
+        gload(0);
       } else {
-        const int ldc = (int)p.c_lo;
-        float* __restrict__ Cp = C + (long long)mrow * ldc + n;   // 32-bit offsets from here on
-        const float* __restrict__ Rp = RES ? R + (long long)mrow * ldc + n : nullptr;
-        if (full) {
-          float rv[16];
-          if (RES) {
+        loaded = false;
+      }
+      const float* as = &As[buf][(wm * WM + n0) * LD + 4 * hb];
+      const float* bs = &Bs[buf][(wn * WN + n0) * LD + 4 * hb];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rv[r] = Rp[((r & 3) + 8 * (r >> 2)) * ldc];
-          }
+      for (int g = 0; g < 4; ++g) {
+        f32x4 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LD + 8 * g);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LD + 8 * g);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+      }
+      if (loaded) lstore(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+
+    // ---- epilogue: bias, activation, residual; D layout: col = lane&31, row = (r&3)+8*(r>>2)+4*hb.
+    // Interior tiles take a branch-free path: the 16 residual loads of a 32x32 sub-tile are issued back to back,
+    // then the 16 stores (each a 128-byte row segment per half-wave). ----
+    const bool full = (m_base + BM <= p.M) && (n_base + BN <= p.N);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n_base + wn * WN + j * 32 + n0;
+      const bool nok = n < p.N;
+      const float bv = (bias && nok) ? bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mrow = m_base + wm * WM + i * 32 + 4 * hb;
+        if (CMAP) {  // mapped rows (GRU layer-0 input projection: (b,t) rows -> time-major); never with act/residual
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            float v = acc[i][j][r] + bv;
-            if (ACT == 1) v = gelu_erf(v);
-            if (RES) v += rv[r];
-            Cp[((r & 3) + 8 * (r >> 2)) * ldc] = v;
+            const int m = mrow + (r & 3) + 8 * (r >> 2);
+            if (nok && m < p.M)
+              C[(long long)(m % p.c_div) * p.c_lo + (long long)(m / p.c_div) * p.c_hi + n] = acc[i][j][r] + bv;
           }
         } else {
+          const int ldc = (int)p.c_lo;
+          float* __restrict__ Cp = C + (long long)mrow * ldc + n;  // 32-bit offsets from here on
+          const float* __restrict__ Rp = RES ? R + (long long)mrow * ldc + n : nullptr;
+          if (full) {
+            float rv[16];
+            if (RES) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int rr = (r & 3) + 8 * (r >> 2);
-            if (nok && mrow + rr < p.M) {
+              for (int r = 0; r < 16; ++r) rv[r] = Rp[((r & 3) + 8 * (r >> 2)) * ldc];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
               float v = acc[i][j][r] + bv;
               if (ACT == 1) v = gelu_erf(v);
-              if (RES) v += Rp[rr * ldc];
-              Cp[rr * ldc] = v;
+              if (RES) v += rv[r];
+              Cp[((r & 3) + 8 * (r >> 2)) * ldc] = v;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int rr = (r & 3) + 8 * (r >> 2);
+              if (nok && mrow + rr < p.M) {
+                float v = acc[i][j][r] + bv;
+                if (ACT == 1) v = gelu_erf(v);
+                if (RES) v += Rp[rr * ldc];
+                Cp[rr * ldc] = v;
+              }
             }
           }
         }
       }
     }
+    m_base = m_next;
+    n_base = n_next;
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WGM>
 static void launch_gemm(const GemmParams& p, int batch, bool cmap, hipStream_t stream) {
-  const dim3 grid(p.ntm * p.ntn, 1, batch), block(256);
+  int g = p.ntm * p.ntn;
+  if (g > p.grid_cap) g = p.grid_cap;
+  g = (g + 7) & ~7;  // the XCD chunking wants a multiple of 8 workgroups
+  const dim3 grid(g, 1, batch), block(256);
   const bool res = p.R != nullptr;
   if (cmap) {
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, 0, false, true>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, 0, false, true>), grid, block, 0, stream, p);
   } else if (p.act == 1) {
-    if (res) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, 1, true, false>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, 1, false, false>), grid, block, 0, stream, p);
+    if (res) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, 1, true, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, 1, false, false>), grid, block, 0, stream, p);
   } else {
-    if (res) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, 0, true, false>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, 0, false, false>), grid, block, 0, stream, p);
+    if (res) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, 0, true, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, 0, false, false>), grid, block, 0, stream, p);
   }
+}
+
+// Tile choice.  All tiles of a launch take the same time, so a launch runs in ceil(tiles / resident slots) rounds;
+// M = B*16*J is rarely a multiple of 128*256 (B=256, J=17: 544 row tiles = 2.125 x 256 CUs), so the tile shape is
+// picked to minimise rounds * (blocks per CU) * tile area.  Blocks per CU are bounded by LDS (2 x (BM+BN) x 144 B).
+struct TileCfg { int bm, bn, bpc; };
+static const TileCfg kTiles[] = {{128, 128, 2}, {96, 128, 2}, {64, 128, 2}, {64, 64, 4}};
+static int pick_tile(int M, int N, int batch) {
+  if (const char* e = getenv("PMCE_GEMM_TILE")) {  // tuning/debug knob: force a tile config (0..3)
+    const int v = atoi(e);
+    if (v >= 0 && v < 4) return v;
+  }
+  int best = 0;
+  double best_cost = 1e300;
+  for (int i = 0; i < 4; ++i) {
+    const TileCfg& t = kTiles[i];
+    const long long tiles = (long long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn) * batch;
+    const long long slots = 256ll * t.bpc;
+    const long long rounds = (tiles + slots - 1) / slots;
+    // a partially filled single round only costs what its busiest CU runs
+    const long long per_cu = rounds > 1 ? rounds * t.bpc : (tiles + 255) / 256;
+    const double cost = (double)per_cu * t.bm * t.bn * (1.0 + 2048.0 / (t.bm * t.bn));  // mild bias to big tiles
+    if (cost < best_cost) { best_cost = cost; best = i; }
+  }
+  return best;
 }
 
 extern "C" int pmce_gemm_nt_f32(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N,
@@ -221,14 +280,19 @@ extern "C" int pmce_gemm_nt_f32(const float* A, const float* W, const float* bia
   PMCE_REQUIRE(cmap || p.c_lo < (1ll << 26), "gemm: ldc too large");
   p.act = act;
   p.bsA = bsA; p.bsW = bsW; p.bsBias = bsBias; p.bsC = bsC;
-  // tile choice: big tiles when they still fill the chip (>= 1 block per CU), else 64x64
-  const long long big = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch;
-  if (big >= 256) {
-    p.ntm = (M + 127) / 128; p.ntn = (N + 127) / 128;
-    launch_gemm<128, 128>(p, batch, cmap, stream);
-  } else {
-    p.ntm = (M + 63) / 64; p.ntn = (N + 63) / 64;
-    launch_gemm<64, 64>(p, batch, cmap, stream);
+  const int ti = pick_tile(M, N, batch);
+  p.ntm = (M + kTiles[ti].bm - 1) / kTiles[ti].bm;
+  p.ntn = (N + kTiles[ti].bn - 1) / kTiles[ti].bn;
+  p.grid_cap = 256 * kTiles[ti].bpc;
+  if (const char* e = getenv("PMCE_GEMM_GRID")) {  // tuning knob: persistent workgroups per CU
+    const int v = atoi(e);
+    if (v >= 1 && v <= 8) p.grid_cap = 256 * v;
+  }
+  switch (ti) {
+    case 0: launch_gemm<128, 128, 2>(p, batch, cmap, stream); break;
+    case 1: launch_gemm<96, 128, 1>(p, batch, cmap, stream); break;
+    case 2: launch_gemm<64, 128, 2>(p, batch, cmap, stream); break;
+    default: launch_gemm<64, 64, 2>(p, batch, cmap, stream); break;
   }
   return pmce_check_launch("gemm_nt_f32");
 }
