@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void adaln_qkv_kernel(const float* __restrict_
 // ======================================================================================================
 #define SA_KLD 68
 #define SA_VLD 64
-__global__ __launch_bounds__(448, 4) void vertex_sa_kernel(const float* __restrict__ xin, const float* __restrict__ qkv,
+__global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict__ xin, const float* __restrict__ qkv,
                                                         const float* __restrict__ Wp, const float* __restrict__ bp,
                                                         float* __restrict__ yout) {
   __shared__ __attribute__((aligned(16))) float sK[2][32 * SA_KLD];

@@ -2,17 +2,26 @@
 //
 // Every dense contraction of the path whose operands do not stay in registers goes through this kernel:
 // the lifter's qkv / proj / fc1 / fc2 Linear layers (reference PoseEstimation.py:13-29 via timm
-// Attention/Mlp), imgfeat_embed (PoseEstimation.py:80), the GRU input and recurrent projections
-// (CoevoDecoder.py:216-221), the 24 live AdaLN gamma/beta Linear(2048->64) layers packed as one
-// [B,2048]x[2048,3072] product (CoevoDecoder.py:19-20), and the final 431->6890 upsample conv + 3 residual
-// Linear(2048->6890) packed as one [B,3360]x[3360,20670] product (CoevoDecoder.py:238-244).
+// Attention/Mlp), imgfeat_embed (PoseEstimation.py:80), the GRU input projections (CoevoDecoder.py:216-221),
+// the 24 live AdaLN gamma/beta Linear(2048->64) layers packed as one [B,2048]x[2048,3072] product
+// (CoevoDecoder.py:19-20), and the final 431->6890 upsample conv + 3 residual Linear(2048->6890) packed as one
+// [B,3360]x[3360,20670] product (CoevoDecoder.py:238-244).
 //
-// Design: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD), 256 threads = 2x2 waves,
-// block tile BMxBNx32, both operands K-contiguous so both tiles are staged with 128-byte-line global loads
-// (8 lanes x 16 B per row), register-prefetched one tile ahead, double-buffered in LDS with a 36-float row
-// stride (conflict-free ds_read_b128).  The k order inside each group of 8 is permuted (lanes 0-31 take
-// k..k+3, lanes 32-63 take k+4..k+7) so that one ds_read_b128 per operand feeds four MFMAs.
+// Design:
+//  * v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD), 256 threads = 4 waves, block tile BMxBNx32, both
+//    operands K-contiguous so both tiles are staged with 128-byte-line global loads (8 lanes x 16 B per row),
+//    register-prefetched one k-tile ahead, double-buffered in LDS with a 36-float row stride (conflict-free
+//    ds_read_b128).  The k order inside each group of 8 is permuted (lanes 0-31 take k..k+3, lanes 32-63 take
+//    k+4..k+7) so that one ds_read_b128 per operand feeds four MFMAs.
+//  * PERSISTENT workgroups walk an XCD-local chunk of the tile order; the next tile's first k-tile is fetched
+//    under the current tile's last MFMAs (no exposed prologue).
+//  * TWO accumulator sets: the finished tile's epilogue (bias / GELU / residual / stores) is cut into 8 slices that
+//    ride inside the first 8 k-iterations of the NEXT tile, so stores, erf and residual loads issue in the shadow
+//    of the matrix pipe.  With K = 256 (8 k-iterations per tile) this is what lifts the lifter's Linear layers
+//    out of the regime where co-resident workgroups run their prologues and epilogues in lockstep.
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -34,6 +43,14 @@ struct GemmParams {
   int grid_cap;                     // persistent workgroups per batch entry
 };
 
+template <int TN>
+struct PendingEpi {  // the finished-but-not-yet-stored tile
+  float* c;          // &C[row0][col0] of this lane's first element
+  const float* r;    // same for the residual
+  float bv[TN];      // bias of this lane's column in each column tile
+  bool valid;        // wave-uniform
+};
+
 template <int BM, int BN, int WGM, int ACT, bool RES, bool CMAP>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
   constexpr int LD = 36;
@@ -42,6 +59,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
   static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int LA = BM / 32, LB = BN / 32;  // float4 loads per thread per tile
+  constexpr int EPS = TM * TN * 2;           // accumulator elements per epilogue slice (8 slices per tile)
   __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
 
@@ -60,12 +78,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
   const int chunk_len = cq + (xcd < cr ? 1 : 0);
   constexpr int GROUP_M = 8;
   const int per_group = GROUP_M * p.ntn;
-  auto tile_coords = [&](int bid, int& m_base, int& n_base) {
+  auto tile_coords = [&](int bid, int& mb, int& nb) {
     const int group = bid / per_group;
     const int first_m = group * GROUP_M;
     const int gsz = min(p.ntm - first_m, GROUP_M);
-    m_base = (first_m + (bid % per_group) % gsz) * BM;
-    n_base = ((bid % per_group) / gsz) * BN;
+    mb = (first_m + (bid % per_group) % gsz) * BM;
+    nb = ((bid % per_group) / gsz) * BN;
   };
 
   const float* __restrict__ A = p.A + (long long)blockIdx.z * p.bsA;
@@ -73,21 +91,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
   float* __restrict__ C = p.C + (long long)blockIdx.z * p.bsC;
   const float* __restrict__ R = RES ? p.R + (long long)blockIdx.z * p.bsC : nullptr;
   const float* __restrict__ bias = p.bias ? p.bias + (long long)blockIdx.z * p.bsBias : nullptr;
+  const int ldc = (int)p.c_lo;
 
   // ---- per-thread global source pointers (fixed rows, advancing k).  Rows past the edge are CLAMPED to the
   // last valid row (their products are never stored), so the k-loop has no predicated loads or branches. ----
   const int kc = (tid & 7) * 4, r0 = tid >> 3;
   const float* aptr[LA];
   const float* bptr[LB];
-  auto set_ptrs = [&](int m_base, int n_base) {
+  auto set_ptrs = [&](int mb, int nb) {
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-      const int r = min(m_base + r0 + 32 * i, p.M - 1);
+      const int r = min(mb + r0 + 32 * i, p.M - 1);
       aptr[i] = A + (long long)(r % p.a_div) * p.a_lo + (long long)(r / p.a_div) * p.a_hi + kc;
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-      const int r = min(n_base + r0 + 32 * i, p.N - 1);
+      const int r = min(nb + r0 + 32 * i, p.N - 1);
       bptr[i] = W + (long long)r * p.ldw + kc;
     }
   };
@@ -108,71 +127,107 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
   };
 
   const int nk = p.K / 32;
+  const bool pipelined = !CMAP && nk >= 8;  // the sliced epilogue needs 8 k-iterations to ride in
   int li = bx;
   if (li >= chunk_len) return;
-  int m_base, n_base;
+  int m_base, n_base, m_next = 0, n_next = 0;
   tile_coords(chunk_start + li, m_base, n_base);
   set_ptrs(m_base, n_base);
   gload(0);
   lstore(0);
   __syncthreads();
   int buf = 0;
-  for (; li < chunk_len; li += gx) {
-    const bool has_next = li + gx < chunk_len;
-    int m_next = 0, n_next = 0;
-    f32x16 acc[TM][TN];
+  bool has_next = false;
+
+  // Element e of a wave tile (e = slice*EPS + u): accumulator register r = e % 16 of sub-tile ij = e / 16
+  // (i = ij % TM, j = ij / TM); its offset from the lane's first element is (i*32 + (r&3) + 8*(r>>2))*ldc + j*32.
+#define EPI_OFF(e) ((((((e) / 16) % TM) * 32 + (((e) % 16) & 3) + 8 * (((e) % 16) >> 2)) * ldc) + (((e) / 16) / TM) * 32)
+
+  // one k-iteration into `cur`; if S >= 0 it also carries slice S of the pending tile's (`prv`) epilogue
+  auto iteration = [&](f32x16(&cur)[TM][TN], const f32x16(&prv)[TM][TN], PendingEpi<TN>& pend, int kt, auto slice_tag) {
+    constexpr int S = decltype(slice_tag)::value;
+    constexpr int SS = S < 0 ? 0 : S;
+    bool loaded = true;
+    if (kt + 1 < nk) {
+      gload(kt + 1);
+    } else if (has_next) {  // cross-tile prefetch: the next tile's first k-tile flies under this tile's last MFMAs
+      set_ptrs(m_next, n_next);
+      gload(0);
+    } else {
+      loaded = false;
+    }
+    float rv[EPS];
+    if (S >= 0 && RES && pend.valid) {
+#pragma unroll
+      for (int u = 0; u < EPS; ++u) rv[u] = pend.r[EPI_OFF(SS * EPS + u)];
+    }
+    const float* as = &As[buf][(wm * WM + n0) * LD + 4 * hb];
+    const float* bs = &Bs[buf][(wn * WN + n0) * LD + 4 * hb];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LD + 8 * g);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LD + 8 * g);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            cur[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], cur[i][j], 0, 0, 0);
+    }
+    if (S >= 0 && pend.valid) {
+#pragma unroll
+      for (int u = 0; u < EPS; ++u) {
+        const int e = SS * EPS + u;
+        float v = prv[(e / 16) % TM][(e / 16) / TM][e % 16] + pend.bv[(e / 16) / TM];
+        if (ACT == 1) v = gelu_erf(v);
+        if (RES) v += rv[u];
+        pend.c[EPI_OFF(e)] = v;
+      }
+    }
+    if (loaded) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  };
+
+  // k-loop of one tile into `cur`, with the pending tile's epilogue slices riding in iterations 0..7
+  auto run_tile = [&](f32x16(&cur)[TM][TN], const f32x16(&prv)[TM][TN], PendingEpi<TN>& pend) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    for (int kt = 0; kt < nk; ++kt) {
-      bool loaded = true;
-      if (kt + 1 < nk) {
-        gload(kt + 1);
-      } else if (has_next) {  // cross-tile prefetch: the next tile's first k-tile flies under this tile's last MFMAs
-        tile_coords(chunk_start + li + gx, m_next, n_next);
-        set_ptrs(m_next, n_next);
-        gload(0);
-      } else {
-        loaded = false;
-      }
-      const float* as = &As[buf][(wm * WM + n0) * LD + 4 * hb];
-      const float* bs = &Bs[buf][(wn * WN + n0) * LD + 4 * hb];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 a[TM], b[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LD + 8 * g);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LD + 8 * g);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-      }
-      if (loaded) lstore(buf ^ 1);
-      __syncthreads();
-      buf ^= 1;
+        for (int r = 0; r < 16; ++r) cur[i][j][r] = 0.f;
+    if (pipelined) {  // nk >= 8: the first eight iterations are straight-line code, each with its own slice
+      iteration(cur, prv, pend, 0, std::integral_constant<int, 0>{});
+      iteration(cur, prv, pend, 1, std::integral_constant<int, 1>{});
+      iteration(cur, prv, pend, 2, std::integral_constant<int, 2>{});
+      iteration(cur, prv, pend, 3, std::integral_constant<int, 3>{});
+      iteration(cur, prv, pend, 4, std::integral_constant<int, 4>{});
+      iteration(cur, prv, pend, 5, std::integral_constant<int, 5>{});
+      iteration(cur, prv, pend, 6, std::integral_constant<int, 6>{});
+      iteration(cur, prv, pend, 7, std::integral_constant<int, 7>{});
+      for (int kt = 8; kt < nk; ++kt) iteration(cur, prv, pend, kt, std::integral_constant<int, -1>{});
+    } else {
+      for (int kt = 0; kt < nk; ++kt) iteration(cur, prv, pend, kt, std::integral_constant<int, -1>{});
     }
+    pend.valid = false;  // all 8 slices of the previous tile are out
+  };
 
-    // ---- epilogue: bias, activation, residual; D layout: col = lane&31, row = (r&3)+8*(r>>2)+4*hb.
-    // Interior tiles take a branch-free path: the 16 residual loads of a 32x32 sub-tile are issued back to back,
-    // then the 16 stores (each a 128-byte row segment per half-wave). ----
-    const bool full = (m_base + BM <= p.M) && (n_base + BN <= p.N);
+  // whole-tile epilogue (edge tiles, mapped rows, K < 256, and the last tile of a workgroup)
+  auto epilogue_now = [&](const f32x16(&acc)[TM][TN], int mb, int nb) {
+    const bool full = (mb + BM <= p.M) && (nb + BN <= p.N);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = n_base + wn * WN + j * 32 + n0;
+      const int n = nb + wn * WN + j * 32 + n0;
       const bool nok = n < p.N;
       const float bv = (bias && nok) ? bias[n] : 0.f;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int mrow = m_base + wm * WM + i * 32 + 4 * hb;
+        const int mrow = mb + wm * WM + i * 32 + 4 * hb;
         if (CMAP) {  // mapped rows (GRU layer-0 input projection: (b,t) rows -> time-major); never with act/residual
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -181,7 +236,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
               C[(long long)(m % p.c_div) * p.c_lo + (long long)(m / p.c_div) * p.c_hi + n] = acc[i][j][r] + bv;
           }
         } else {
-          const int ldc = (int)p.c_lo;
           float* __restrict__ Cp = C + (long long)mrow * ldc + n;  // 32-bit offsets from here on
           const float* __restrict__ Rp = RES ? R + (long long)mrow * ldc + n : nullptr;
           if (full) {
@@ -212,9 +266,52 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
         }
       }
     }
+  };
+
+  // after a tile's k-loop: either park it as pending (interior tile with a successor) or store it now
+  auto finish_tile = [&](const f32x16(&acc)[TM][TN], PendingEpi<TN>& pend) {
+    const bool full = (m_base + BM <= p.M) && (n_base + BN <= p.N);
+    if (pipelined && full && has_next) {
+      const long long o = (long long)(m_base + wm * WM + 4 * hb) * ldc + n_base + wn * WN + n0;
+      pend.c = C + o;
+      pend.r = RES ? R + o : nullptr;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) pend.bv[j] = bias ? bias[n_base + wn * WN + j * 32 + n0] : 0.f;
+      pend.valid = true;
+    } else {
+      epilogue_now(acc, m_base, n_base);
+      pend.valid = false;
+    }
+  };
+
+  f32x16 acc0[TM][TN], acc1[TM][TN];
+  PendingEpi<TN> pend;
+  pend.valid = false;
+  pend.c = nullptr;
+  pend.r = nullptr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) pend.bv[j] = 0.f;
+
+  while (true) {
+    has_next = li + gx < chunk_len;
+    if (has_next) tile_coords(chunk_start + li + gx, m_next, n_next);
+    run_tile(acc0, acc1, pend);
+    finish_tile(acc0, pend);
+    if (!has_next) break;
+    li += gx;
+    m_base = m_next;
+    n_base = n_next;
+
+    has_next = li + gx < chunk_len;
+    if (has_next) tile_coords(chunk_start + li + gx, m_next, n_next);
+    run_tile(acc1, acc0, pend);
+    finish_tile(acc1, pend);
+    if (!has_next) break;
+    li += gx;
     m_base = m_next;
     n_base = n_next;
   }
+#undef EPI_OFF
 }
 
 template <int BM, int BN, int WGM>

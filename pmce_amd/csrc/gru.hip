@@ -73,7 +73,8 @@ struct GruStepArgs {
 };
 
 __global__ __launch_bounds__(256) void gru_step_kernel(GruStepArgs a) {
-  constexpr int LD = 36, KH = 16;  // 16 k per half per iteration
+  constexpr int KH = 32;            // k per K-half per iteration
+  constexpr int LD = 2 * KH + 4;    // LDS row: [half 0: 32 k | half 1: 32 k | pad] = 68 floats (conflict-free b128)
   __shared__ __attribute__((aligned(16))) float smem[2 * (64 + 96) * LD];
   const int d = blockIdx.z;
   const int u0 = blockIdx.x * 32, m0 = blockIdx.y * 64;
@@ -84,6 +85,22 @@ __global__ __launch_bounds__(256) void gru_step_kernel(GruStepArgs a) {
   const float* __restrict__ hp = a.hprev[d];
   const float* __restrict__ W = a.whh[d];
 
+  // This wave finishes 8 of the 16 accumulator rows of its (row block, unit) tile: rows r = 8*kh .. 8*kh+7.
+  // Their gate inputs are fetched NOW so that they are in registers when the K loop ends.
+  const int u = u0 + n0;
+  const float* __restrict__ gi = a.gi[d];
+  float gir[8], giz[8], gin[8], hpv[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int r = 8 * kh + q;
+    const int m = min(m0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb, a.B - 1);
+    const float* g = gi + (long long)m * a.gi_rs + u;
+    gir[q] = g[0];
+    giz[q] = g[H];
+    gin[q] = g[2 * H];
+    hpv[q] = hp ? hp[(long long)m * a.h_rs + u] : 0.f;
+  }
+
   f32x16 acc[3];
 #pragma unroll
   for (int g = 0; g < 3; ++g)
@@ -91,40 +108,40 @@ __global__ __launch_bounds__(256) void gru_step_kernel(GruStepArgs a) {
     for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
 
   if (hp) {
-    // per-thread staging assignment: A 64 rows x 8 float4, W 96 rows x 8 float4 per iteration
-    const float* ap[2];
-    const float* wp[3];
+    // per-thread staging assignment per iteration: A 64 rows x 16 float4 (4 per thread), W 96 rows x 16 float4 (6)
+    const float* ap[4];
+    const float* wp[6];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 256 * i, row = idx >> 3, c4 = idx & 7;
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 4, c4 = idx & 15;
       const int m = min(m0 + row, a.B - 1);
-      ap[i] = hp + (long long)m * a.h_rs + (c4 >> 2) * Khalf + (c4 & 3) * 4;
+      ap[i] = hp + (long long)m * a.h_rs + (c4 >> 3) * Khalf + (c4 & 7) * 4;
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int idx = tid + 256 * i, row = idx >> 3, c4 = idx & 7;
-      const int gate = row >> 5, u = row & 31;
-      wp[i] = W + (long long)(gate * H + u0 + u) * H + (c4 >> 2) * Khalf + (c4 & 3) * 4;
+    for (int i = 0; i < 6; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 4, c4 = idx & 15;
+      const int gate = row >> 5, uu = row & 31;
+      wp[i] = W + (long long)(gate * H + u0 + uu) * H + (c4 >> 3) * Khalf + (c4 & 7) * 4;
     }
-    f32x4 ra[2], rw[3];
+    f32x4 ra[4], rw[6];
     auto gload = [&](int kt) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * KH);
+      for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * KH);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) rw[i] = *reinterpret_cast<const f32x4*>(wp[i] + kt * KH);
+      for (int i = 0; i < 6; ++i) rw[i] = *reinterpret_cast<const f32x4*>(wp[i] + kt * KH);
     };
     auto lstore = [&](int buf) {
       float* As = smem + buf * (64 + 96) * LD;
       float* Bs = As + 64 * LD;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < 4; ++i) {
         const int idx = tid + 256 * i;
-        *reinterpret_cast<f32x4*>(As + (idx >> 3) * LD + (idx & 7) * 4) = ra[i];
+        *reinterpret_cast<f32x4*>(As + (idx >> 4) * LD + (idx & 15) * 4) = ra[i];
       }
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < 6; ++i) {
         const int idx = tid + 256 * i;
-        *reinterpret_cast<f32x4*>(Bs + (idx >> 3) * LD + (idx & 7) * 4) = rw[i];
+        *reinterpret_cast<f32x4*>(Bs + (idx >> 4) * LD + (idx & 15) * 4) = rw[i];
       }
     };
     const int nk = Khalf / KH;
@@ -134,10 +151,10 @@ __global__ __launch_bounds__(256) void gru_step_kernel(GruStepArgs a) {
     for (int kt = 0; kt < nk; ++kt) {
       const int buf = kt & 1;
       if (kt + 1 < nk) gload(kt + 1);
-      const float* As = smem + buf * (64 + 96) * LD + (rb * 32 + n0) * LD + kh * 16 + 4 * hb;
-      const float* Bs = smem + buf * (64 + 96) * LD + 64 * LD + n0 * LD + kh * 16 + 4 * hb;
+      const float* As = smem + buf * (64 + 96) * LD + (rb * 32 + n0) * LD + kh * KH + 4 * hb;
+      const float* Bs = smem + buf * (64 + 96) * LD + 64 * LD + n0 * LD + kh * KH + 4 * hb;
 #pragma unroll
-      for (int g8 = 0; g8 < 2; ++g8) {
+      for (int g8 = 0; g8 < KH / 8; ++g8) {
         const f32x4 av = *reinterpret_cast<const f32x4*>(As + 8 * g8);
         f32x4 bv[3];
 #pragma unroll
@@ -150,39 +167,35 @@ __global__ __launch_bounds__(256) void gru_step_kernel(GruStepArgs a) {
       if (kt + 1 < nk) lstore(buf ^ 1);
       __syncthreads();
     }
-    // meet the two K-halves: waves kh=1 publish, waves kh=0 accumulate
-    float* red = smem;  // [rb][gate][r][lane] = 2*3*16*64 floats = 24.6 KB (tiles are dead now)
-    if (kh == 1) {
+    // meet the two K-halves: each wave publishes the 8 rows its partner finishes, then adds the partner's 8 rows
+    float* red = smem;  // [kh_dst][rb][gate][q][lane] = 2*2*3*8*64 floats = 24.6 KB (the tiles are dead now)
 #pragma unroll
-      for (int g = 0; g < 3; ++g)
+    for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[((rb * 3 + g) * 16 + r) * 64 + lane] = acc[g][r];
-    }
+      for (int q = 0; q < 8; ++q) red[((((1 - kh) * 2 + rb) * 3 + g) * 8 + q) * 64 + lane] = acc[g][8 * (1 - kh) + q];
     __syncthreads();
-    if (kh == 0) {
 #pragma unroll
-      for (int g = 0; g < 3; ++g)
+    for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][r] += red[((rb * 3 + g) * 16 + r) * 64 + lane];
-    }
+      for (int q = 0; q < 8; ++q) acc[g][8 * kh + q] += red[(((kh * 2 + rb) * 3 + g) * 8 + q) * 64 + lane];
   }
-  if (kh != 0) return;
   // gate update on the D layout: unit = u0 + (lane & 31), batch row = m0 + rb*32 + (r&3) + 8*(r>>2) + 4*hb
-  const int u = u0 + n0;
   const float* __restrict__ bh = a.bhh[d];
   const float bhr = bh[u], bhz = bh[H + u], bhn = bh[2 * H + u];
-  const float* __restrict__ gi = a.gi[d];
   float* __restrict__ ho = a.hout[d];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
+  for (int q = 0; q < 8; ++q) {
+    // acc[g][8*kh + q] with a compile-time register index: both halves are written out and selected by kh
+    const float ar = kh ? acc[0][8 + q] : acc[0][q];
+    const float az = kh ? acc[1][8 + q] : acc[1][q];
+    const float an = kh ? acc[2][8 + q] : acc[2][q];
+    const int r = 8 * kh + q;
     const int m = m0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
     if (m < a.B) {
-      const float* g = gi + (long long)m * a.gi_rs + u;
-      const float hprev = hp ? hp[(long long)m * a.h_rs + u] : 0.f;
-      const float rr = sigmoidf_acc(g[0] + (acc[0][r] + bhr));
-      const float zz = sigmoidf_acc(g[H] + (acc[1][r] + bhz));
-      const float nn = tanhf(g[2 * H] + rr * (acc[2][r] + bhn));
-      ho[(long long)m * a.h_rs + u] = (1.0f - zz) * nn + zz * hprev;
+      const float rr = sigmoidf_acc(gir[q] + (ar + bhr));
+      const float zz = sigmoidf_acc(giz[q] + (az + bhz));
+      const float nn = tanhf(gin[q] + rr * (an + bhn));
+      ho[(long long)m * a.h_rs + u] = (1.0f - zz) * nn + zz * hpv[q];
     }
   }
 }
