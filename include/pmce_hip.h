@@ -77,6 +77,11 @@ int pmce_decoder_forward(pmce_model* m, const float* joints, const float* img_fe
 int pmce_forward(pmce_model* m, const float* pose2d, const float* img_feat, float* cam_mesh, float* cam_pose,
                  float* pose3d, float* pred_pose, int batch, void* ws, size_t ws_bytes, pmce_stream_t stream);
 
+/* enable != 0 (default): pmce_forward / pmce_decoder_forward run the image-feature branch (GRU, AdaLN parameters) and the
+ * short joint-side kernels on a second, internally created HIP stream, forked from and joined back into the caller's
+ * stream with events (hipGraph-capturable; results are identical).  0 keeps every launch on the caller's stream. */
+int pmce_model_set_concurrency(pmce_model* m, int enable);
+
 /* Per-kernel-class timing of the forwards above (HIP events on the caller's stream).  enable != 0 starts
  * accumulating; pmce_model_profile_read synchronises the recorded events and returns, for class i, its
  * name, accumulated milliseconds and launch count; returns the number of classes. */

@@ -30,6 +30,7 @@ PROTOTYPES = {
     "pmce_lifter_forward": [C.c_void_p, _f, _f, _f, _i, _f, C.c_size_t, _s],
     "pmce_decoder_forward": [C.c_void_p, _f, _f, _f, _f, _i, _f, C.c_size_t, _s],
     "pmce_forward": [C.c_void_p, _f, _f, _f, _f, _f, _f, _i, _f, C.c_size_t, _s],
+    "pmce_model_set_concurrency": [C.c_void_p, _i],
     "pmce_model_profile": [C.c_void_p, _i],
     "pmce_model_profile_read": [C.c_void_p, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_longlong)],
     "pmce_gemm_nt_f32": [_f, _f, _f, _f, _f, _i, _i, _i, _l, _i, _l, _i, _i, _l, _l, _i, _l, _l, _i, _l, _l, _l, _l, _s],

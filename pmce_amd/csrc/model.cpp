@@ -6,6 +6,8 @@
 // forward is hipGraph-capturable.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -42,6 +44,10 @@ struct pmce_model {
   std::unordered_map<std::string, const void*> ptr;
   bool finalized = false;
   bool has_lifter = false, has_decoder = false;
+  // second stream for the image-feature branch (created on first use, destroyed with the model)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
+  bool concurrent = true;  // pmce_model_set_concurrency
   // regressor (optional)
   const int* jr_indptr = nullptr;
   const int* jr_indices = nullptr;
@@ -149,7 +155,7 @@ struct LifterWs {
   float *E, *X, *XN, *QKV, *AO;
 };
 struct DecoderWs {
-  float *GI0, *Y0, *GHb, *GI1, *Y1, *GB, *VT[3], *JF, *XK, *KF, *S0, *VF, *F1, *F2, *QKV, *KVJ, *FA, *JM;
+  float *GI0, *Y0, *GHb, *GI1, *Y1, *GB, *VT[3], *JF[3], *XK[3], *KF[3], *S0[3], *VF[3], *F1, *F2, *QKV, *KVJ, *FA, *JM;
 };
 
 void carve_lifter(Carver& c, const pmce_model* m, int B, LifterWs& w) {
@@ -168,11 +174,13 @@ void carve_decoder(Carver& c, const pmce_model* m, int B, DecoderWs& w) {
   w.Y1 = c.take((size_t)T * B * 2 * GH);
   w.GB = c.take((size_t)B * N_ADA * 128);
   for (int i = 0; i < 3; ++i) w.VT[i] = c.take((size_t)B * NVC * 3);
-  w.JF = c.take((size_t)B * 32 * D);
-  w.XK = c.take((size_t)B * 32 * D);
-  w.KF = c.take((size_t)B * 4096);
-  w.S0 = c.take((size_t)B * 64);
-  w.VF = c.take((size_t)B * 4096);
+  for (int i = 0; i < 3; ++i) {
+    w.JF[i] = c.take((size_t)B * 32 * D);
+    w.XK[i] = c.take((size_t)B * 32 * D);
+    w.KF[i] = c.take((size_t)B * 4096);
+    w.S0[i] = c.take((size_t)B * 64);
+    w.VF[i] = c.take((size_t)B * 4096);
+  }
   w.F1 = c.take((size_t)B * NVC * D);
   w.F2 = c.take((size_t)B * NVC * D);
   w.QKV = c.take((size_t)B * NVC * 3 * D);
@@ -270,9 +278,9 @@ int gru_layer(pmce_model* m, int layer, const float* gi_f, const float* gi_b, lo
   return PMCE_OK;
 }
 
-int decoder_impl(pmce_model* m, const float* joints, const float* img_feat, float* cam_pose, float* cam_mesh, int B,
-                 DecoderWs& w, hipStream_t stream) {
-  const int J = m->J;
+// image-feature branch of Pose2Mesh.forward: bi-GRU + AdaLN parameters.  Depends only on img_feat, so pmce_forward
+// runs it on a second stream concurrently with the pose lifter.
+int gru_part(pmce_model* m, const float* img_feat, int B, DecoderWs& w, hipStream_t stream) {
   // ---- bi-GRU over the 16 frames (CoevoDecoder.py:228); buffers are time-major [t][b][.] ----
   // layer 0 input projections for both directions in one product: rows (b,t) of img_feat -> rows (t,b) of GI0
   RUN(P_GEMM_GRU_IN, pmce_gemm_nt_f32(img_feat, m->f("dec.gru.w_ih_l0"), m->f("dec.gru.b_ih_l0"), nullptr, w.GI0, B * T,
@@ -293,24 +301,87 @@ int decoder_impl(pmce_model* m, const float* joints, const float* img_feat, floa
   // ---- all live AdaLN gamma/beta in one product (CoevoDecoder.py:19-20,27-28) ----
   RUN(P_GEMM_ADA, gemm(g, m->f("dec.ada.weight"), m->f("dec.ada.bias"), nullptr, w.GB, B, N_ADA * 128, 2 * GH, 2 * GH,
                        N_ADA * 128, 0, stream));
-  const int gbs = N_ADA * 128;
+  return PMCE_OK;
+}
 
+// joint-side preparation of CoevoBlock k (1..3): jf, xk and the folded key/value operands of its vertex<-joint
+// cross-attention.  Depends only on the joints and the AdaLN parameters, not on the vertex stream.
+int joint_prep(pmce_model* m, int k, const float* joints, int B, DecoderWs& w, hipStream_t stream) {
+  const int J = m->J;
+  const std::string p = "dec.b" + std::to_string(k) + ".";
+  const int ib = (k - 1) * 6, gbs = N_ADA * 128;
+  RUN(P_JOINT_EMBED, pmce_joint_embed_f32(joints, m->f(p + "joint_proj.weight"), m->f(p + "joint_proj.bias"),
+                                          m->f(p + "joint_pos_embed"), m->f(p + "proj_j2v_dim.weight"),
+                                          m->f(p + "proj_j2v_dim.bias"), m->f(p + "j2v_K_embed"), w.JF[k - 1], w.XK[k - 1], B,
+                                          J, stream));
+  RUN(P_CA_FOLD, pmce_ca_fold_f32(w.XK[k - 1], w.JF[k - 1], w.GB, gbs, ib + 0, ib + 1, ib + 2, m->f(p + "vca.wq.weight"),
+                                  m->f(p + "vca.wq.bias"), m->f(p + "vca.wk.weight"), m->f(p + "vca.wk.bias"),
+                                  m->f(p + "vca.wv.weight"), m->f(p + "vca.wv.bias"), m->f(p + "vca.proj.weight"),
+                                  w.KF[k - 1], w.S0[k - 1], w.VF[k - 1], B, J, stream));
+  return PMCE_OK;
+}
+
+// joint stream of CoevoBlock 3 (the only live one, CoevoDecoder.py:235-237): needs the block's INPUT vertices.
+int joint_branch(pmce_model* m, const float* joints, const float* vt_in, float* cam_pose, int B, DecoderWs& w,
+                 hipStream_t stream) {
+  const int J = m->J, gbs = N_ADA * 128;
+  const std::string p = "dec.b3.";
+  RUN(P_TOKENS_KV, pmce_tokens_kv_f32(nullptr, nullptr, vt_in, m->f(p + "vertx_proj.weight"), m->f(p + "Ev"),
+                                      m->f(p + "proj_v2j_dim.weight"), m->f(p + "Ek"), w.GB, gbs, 19, 20,
+                                      m->f(p + "jca.wk.weight"), m->f(p + "jca.wk.bias"), m->f(p + "jca.wv.weight"),
+                                      m->f(p + "jca.wv.bias"), w.KVJ, B, stream));
+  const float* wp[18] = {m->f(p + "jca.wq.weight"),      m->f(p + "jca.wq.bias"),      m->f(p + "jca.proj.weight"),
+                         m->f(p + "jca.proj.bias"),      m->f(p + "jca.mlp.fc1.weight"), m->f(p + "jca.mlp.fc1.bias"),
+                         m->f(p + "jca.mlp.fc2.weight"), m->f(p + "jca.mlp.fc2.bias"), m->f(p + "jsa.qkv.weight"),
+                         m->f(p + "jsa.qkv.bias"),       m->f(p + "jsa.proj.weight"),  m->f(p + "jsa.proj.bias"),
+                         m->f(p + "jsa.mlp.fc1.weight"), m->f(p + "jsa.mlp.fc1.bias"), m->f(p + "jsa.mlp.fc2.weight"),
+                         m->f(p + "jsa.mlp.fc2.bias"),   m->f(p + "jcoor.weight"),     m->f(p + "jcoor.bias")};
+  const int inst[4] = {18, 21, 22, 23};
+  RUN(P_JOINT_STREAM, pmce_joint_stream_f32(w.JF[2], m->f(p + "j_Q_embed"), w.KVJ, w.GB, gbs, wp, inst, joints, nullptr,
+                                            cam_pose, B, J, 3, stream));
+  return PMCE_OK;
+}
+
+// joint/vertex branch of Pose2Mesh.forward (needs the joints and the outputs of gru_part).  With a side stream the
+// joint-side work of blocks 2-3 and the joint stream of block 3 run beside the vertex stream (they are short,
+// latency-bound kernels); side == nullptr runs everything in order on `stream`.
+int coevo_part(pmce_model* m, const float* joints, float* cam_pose, float* cam_mesh, int B, DecoderWs& w,
+               hipStream_t stream, hipStream_t side) {
+  const int J = m->J;
+  const float* g = w.Y1 + (long long)8 * B * 2 * GH;
+  const int gbs = N_ADA * 128;
+  if (side) {
+    (void)hipEventRecord(m->ev_a, stream);  // joints and AdaLN parameters are ready
+    (void)hipStreamWaitEvent(side, m->ev_a, 0);
+    PMCE_TRY(joint_prep(m, 2, joints, B, w, side));
+    PMCE_TRY(joint_prep(m, 3, joints, B, w, side));
+    (void)hipEventRecord(m->ev_b, side);
+  }
   // ---- vertex init (CoevoDecoder.py:232) ----
   RUN(P_GATHER, pmce_vertex_init_gather_f32(joints, m->i32("dec.vj_relation"), w.VT[0], B, J, stream));
+  PMCE_TRY(joint_prep(m, 1, joints, B, w, stream));
   float* vt_cur = w.VT[0];
   for (int k = 1; k <= 3; ++k) {
     const std::string p = "dec.b" + std::to_string(k) + ".";
     float* vt_next = w.VT[k % 3];
     const int ib = (k - 1) * 6;  // AdaLN instances: vca.normq,normk,normv,norm2, vsa.norm1,norm2
-    RUN(P_JOINT_EMBED, pmce_joint_embed_f32(joints, m->f(p + "joint_proj.weight"), m->f(p + "joint_proj.bias"),
-                                            m->f(p + "joint_pos_embed"), m->f(p + "proj_j2v_dim.weight"),
-                                            m->f(p + "proj_j2v_dim.bias"), m->f(p + "j2v_K_embed"), w.JF, w.XK, B, J, stream));
-    RUN(P_CA_FOLD, pmce_ca_fold_f32(w.XK, w.JF, w.GB, gbs, ib + 0, ib + 1, ib + 2, m->f(p + "vca.wq.weight"),
-                                    m->f(p + "vca.wq.bias"), m->f(p + "vca.wk.weight"), m->f(p + "vca.wk.bias"),
-                                    m->f(p + "vca.wv.weight"), m->f(p + "vca.wv.bias"), m->f(p + "vca.proj.weight"), w.KF,
-                                    w.S0, w.VF, B, J, stream));
-    RUN(P_VERTEX_CA, pmce_vertex_ca_f32(nullptr, vt_cur, m->f(p + "vertx_proj.weight"), m->f(p + "Eq"), w.KF, w.S0, w.VF,
-                                        m->f(p + "vca.proj.bias"), w.F1, B, J, stream));
+    if (k > 1) {
+      if (side) {
+        if (k == 2) (void)hipStreamWaitEvent(stream, m->ev_b, 0);
+      } else {
+        PMCE_TRY(joint_prep(m, k, joints, B, w, stream));
+      }
+    }
+    if (k == 3) {
+      if (side) {
+        (void)hipEventRecord(m->ev_c, stream);  // block-3 input vertices are ready
+        (void)hipStreamWaitEvent(side, m->ev_c, 0);
+        PMCE_TRY(joint_branch(m, joints, vt_cur, cam_pose, B, w, side));
+        (void)hipEventRecord(m->ev_d, side);
+      }
+    }
+    RUN(P_VERTEX_CA, pmce_vertex_ca_f32(nullptr, vt_cur, m->f(p + "vertx_proj.weight"), m->f(p + "Eq"), w.KF[k - 1],
+                                        w.S0[k - 1], w.VF[k - 1], m->f(p + "vca.proj.bias"), w.F1, B, J, stream));
     RUN(P_ADALN_MLP, pmce_adaln_mlp_f32(w.F1, w.GB, gbs, ib + 3, m->f(p + "vca.mlp.fc1.weight"), m->f(p + "vca.mlp.fc1.bias"),
                                         m->f(p + "vca.mlp.fc2.weight"), m->f(p + "vca.mlp.fc2.bias"), w.F2, nullptr, nullptr,
                                         nullptr, nullptr, B, stream));
@@ -320,28 +391,29 @@ int decoder_impl(pmce_model* m, const float* joints, const float* img_feat, floa
     RUN(P_ADALN_MLP, pmce_adaln_mlp_f32(w.F1, w.GB, gbs, ib + 5, m->f(p + "vsa.mlp.fc1.weight"), m->f(p + "vsa.mlp.fc1.bias"),
                                         m->f(p + "vsa.mlp.fc2.weight"), m->f(p + "vsa.mlp.fc2.bias"), nullptr,
                                         m->f(p + "vcoor.weight"), m->f(p + "vcoor.bias"), vt_cur, vt_next, B, stream));
-    if (k == 3) {
-      // joint stream — live only in coevoblock3 (its outputs in blocks 1-2 are discarded, CoevoDecoder.py:235-237)
-      RUN(P_TOKENS_KV, pmce_tokens_kv_f32(nullptr, nullptr, vt_cur, m->f(p + "vertx_proj.weight"), m->f(p + "Ev"),
-                                          m->f(p + "proj_v2j_dim.weight"), m->f(p + "Ek"), w.GB, gbs, 19, 20,
-                                          m->f(p + "jca.wk.weight"), m->f(p + "jca.wk.bias"), m->f(p + "jca.wv.weight"),
-                                          m->f(p + "jca.wv.bias"), w.KVJ, B, stream));
-      const float* wp[18] = {m->f(p + "jca.wq.weight"),      m->f(p + "jca.wq.bias"),      m->f(p + "jca.proj.weight"),
-                             m->f(p + "jca.proj.bias"),      m->f(p + "jca.mlp.fc1.weight"), m->f(p + "jca.mlp.fc1.bias"),
-                             m->f(p + "jca.mlp.fc2.weight"), m->f(p + "jca.mlp.fc2.bias"), m->f(p + "jsa.qkv.weight"),
-                             m->f(p + "jsa.qkv.bias"),       m->f(p + "jsa.proj.weight"),  m->f(p + "jsa.proj.bias"),
-                             m->f(p + "jsa.mlp.fc1.weight"), m->f(p + "jsa.mlp.fc1.bias"), m->f(p + "jsa.mlp.fc2.weight"),
-                             m->f(p + "jsa.mlp.fc2.bias"),   m->f(p + "jcoor.weight"),     m->f(p + "jcoor.bias")};
-      const int inst[4] = {18, 21, 22, 23};
-      RUN(P_JOINT_STREAM, pmce_joint_stream_f32(w.JF, m->f(p + "j_Q_embed"), w.KVJ, w.GB, gbs, wp, inst, joints, nullptr,
-                                                cam_pose, B, J, 3, stream));
-    }
+    if (k == 3 && !side) PMCE_TRY(joint_branch(m, joints, vt_cur, cam_pose, B, w, stream));
     vt_cur = vt_next;
   }
   // ---- 431 -> 6890 upsample conv + 3 residual Linear(2048->6890) as ONE product (CoevoDecoder.py:238-244) ----
   RUN(P_FINAL_OP, pmce_build_final_operand_f32(g, vt_cur, w.FA, B, FINAL_K, stream));
   RUN(P_GEMM_FINAL, gemm(w.FA, m->f("dec.final.weight"), m->f("dec.final.bias"), nullptr, cam_mesh, B, NVF * 3, FINAL_K,
                          FINAL_K, NVF * 3, 0, stream));
+  if (side) (void)hipStreamWaitEvent(stream, m->ev_d, 0);  // cam_pose is written by the side stream
+  return PMCE_OK;
+}
+
+// second stream + fork/join events, created on first use
+int ensure_side(pmce_model* m) {
+  if (m->side) return PMCE_OK;
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  bool ok = hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, hi) == hipSuccess;
+  for (hipEvent_t* e : {&m->ev_fork, &m->ev_join, &m->ev_a, &m->ev_b, &m->ev_c, &m->ev_d})
+    ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    pmce_set_error("could not create the side stream/events: %s", hipGetErrorString(hipGetLastError()));
+    return PMCE_ERR_LAUNCH;
+  }
   return PMCE_OK;
 }
 
@@ -359,6 +431,7 @@ int pmce_model_create(int num_joint, int embed_dim, int depth, pmce_model** out)
   m->J = num_joint;
   m->C = embed_dim;
   m->depth = depth;
+  m->concurrent = getenv("PMCE_SINGLE_STREAM") == nullptr;
   build_names(m);
   *out = m;
   return PMCE_OK;
@@ -374,6 +447,9 @@ void pmce_model_destroy(pmce_model* m) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
   }
+  for (hipEvent_t e : {m->ev_fork, m->ev_join, m->ev_a, m->ev_b, m->ev_c, m->ev_d})
+    if (e) (void)hipEventDestroy(e);
+  if (m->side) (void)hipStreamDestroy(m->side);
   delete m;
 }
 
@@ -495,7 +571,9 @@ int pmce_decoder_forward(pmce_model* m, const float* joints, const float* img_fe
   DecoderWs dw;
   carve_lifter(c, m, batch, lw);
   carve_decoder(c, m, batch, dw);
-  return decoder_impl(m, joints, img_feat, cam_pose, cam_mesh, batch, dw, stream);
+  PMCE_TRY(gru_part(m, img_feat, batch, dw, stream));
+  if (m->concurrent) PMCE_TRY(ensure_side(m));
+  return coevo_part(m, joints, cam_pose, cam_mesh, batch, dw, stream, m->concurrent ? m->side : nullptr);
 }
 
 int pmce_forward(pmce_model* m, const float* pose2d, const float* img_feat, float* cam_mesh, float* cam_pose,
@@ -508,16 +586,36 @@ int pmce_forward(pmce_model* m, const float* pose2d, const float* img_feat, floa
   DecoderWs dw;
   carve_lifter(c, m, batch, lw);
   carve_decoder(c, m, batch, dw);
+  // Fork: the GRU / AdaLN-parameter branch depends only on img_feat; it runs on a second (high-priority) stream
+  // under the pose lifter, whose long matrix-core kernels leave the gaps its 25 short dependent steps need.
+  // pmce_model_set_concurrency(m, 0) (or PMCE_SINGLE_STREAM=1 at create time) keeps everything on one stream.
+  const bool single = !m->concurrent;
+  if (!single) PMCE_TRY(ensure_side(m));
+  if (!single) {
+    (void)hipEventRecord(m->ev_fork, stream);
+    (void)hipStreamWaitEvent(m->side, m->ev_fork, 0);
+    PMCE_TRY(gru_part(m, img_feat, batch, dw, m->side));
+    (void)hipEventRecord(m->ev_join, m->side);
+  } else {
+    PMCE_TRY(gru_part(m, img_feat, batch, dw, stream));
+  }
   PMCE_TRY(lifter_impl(m, pose2d, img_feat, pose3d, batch, lw, stream));
   // pose3d.reshape(-1, J, 3) / 1000  (PMCE.py:17-18)
   RUN(P_MISC, pmce_div_scalar_f32(pose3d, dw.JM, (long long)batch * m->J * 3, 1000.0f, stream));
-  PMCE_TRY(decoder_impl(m, dw.JM, img_feat, cam_pose, cam_mesh, batch, dw, stream));
+  if (!single) (void)hipStreamWaitEvent(stream, m->ev_join, 0);  // join
+  PMCE_TRY(coevo_part(m, dw.JM, cam_pose, cam_mesh, batch, dw, stream, single ? nullptr : m->side));
   if (pred_pose) {
     PMCE_REQUIRE(m->jr_indptr && m->jr_indices && m->jr_data && m->jr_rows > 0,
                  "forward: pred_pose requested but no J_regressor registered (jreg.indptr/indices/data + rows)");
     RUN(P_JREG, pmce_j_regress_f32(cam_mesh, m->jr_indptr, m->jr_indices, m->jr_data, pred_pose, batch, m->jr_rows, NVF,
                                    1000.0f, stream));
   }
+  return PMCE_OK;
+}
+
+int pmce_model_set_concurrency(pmce_model* m, int enable) {
+  PMCE_REQUIRE(m, "model_set_concurrency: null model");
+  m->concurrent = enable != 0;
   return PMCE_OK;
 }
 

@@ -73,8 +73,16 @@ class PMCE(HipModuleBase):
         return self._run(pose2d, img_feat, True)
 
     # benchmarking hooks
+    def set_concurrency(self, enable=True):
+        """Two-stream execution of independent branches inside one forward (default on)."""
+        self._ensure_packed().set_concurrency(enable)
+
     def profile(self, enable=True):
-        self._ensure_packed().profile(enable)
+        """Per-kernel-class HIP-event timing; kernels are serialised on one stream while it is on so that each
+        launch is priced alone."""
+        eng = self._ensure_packed()
+        eng.set_concurrency(not enable)
+        eng.profile(enable)
 
     def profile_read(self):
         return self._ensure_packed().profile_read()

@@ -97,6 +97,9 @@ class HipEngine:
         n = int(np.prod(shape))
         return self.ws[off:off + 4 * n].view(torch.float32).reshape(shape)
 
+    def set_concurrency(self, enable: bool):
+        _lib.check(self.lib.pmce_model_set_concurrency(self.handle, 1 if enable else 0), "model_set_concurrency")
+
     # ---- profiling -------------------------------------------------------------------------------
     def profile(self, enable: bool):
         _lib.check(self.lib.pmce_model_profile(self.handle, 1 if enable else 0), "model_profile")
