@@ -170,11 +170,11 @@ __global__ __launch_bounds__(256) void ca_fold_kernel(const float* __restrict__ 
 // with the key/value side pre-folded by ca_fold.  xq is either read ([B,431,64]) or, when xq == nullptr,
 // formed on the fly from the 3-D vertex coordinates: xq = Wv3*vt + Eq[v]  (Eq = vertx_proj.bias +
 // vertx_pos_embed + v_Q_embed, CoevoDecoder.py:177-180,184).
-// grid (2, B), 512 threads: 8 waves stage the clip's folded operands into LDS, waves 0..6 each own 32 vertices.
+// grid (2, B), 448 threads: 7 waves stage the clip's folded operands into LDS and each own 32 vertices.
 // Per 32 vertices: 8 x 16-B loads/lane, 128 MFMAs (64 scores + 64 output), masked softmax over <= 32 keys as
 // 16 in-lane values + one shuffle, 8 x 16-B stores/lane.
 // ======================================================================================================
-__global__ __launch_bounds__(512) void vertex_ca_kernel(const float* __restrict__ xq, const float* __restrict__ vt,
+__global__ __launch_bounds__(448, 4) void vertex_ca_kernel(const float* __restrict__ xq, const float* __restrict__ vt,
                                                         const float* __restrict__ Wv3, const float* __restrict__ Eq,
                                                         const float* __restrict__ Kf, const float* __restrict__ s0,
                                                         const float* __restrict__ Vf, const float* __restrict__ bp,
@@ -183,18 +183,14 @@ __global__ __launch_bounds__(512) void vertex_ca_kernel(const float* __restrict_
   __shared__ __attribute__((aligned(16))) float sV[64 * LDW64];
   __shared__ float sS0[64];
   const int b = blockIdx.y, tid = threadIdx.x;
-  stage_weight<64>(sK, Kf + (long long)b * 4096, 64, tid, 512);
-  stage_weight<64>(sV, Vf + (long long)b * 4096, 64, tid, 512);
-  if (tid < 64) sS0[tid] = s0[(long long)b * 64 + tid];
-  __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
-  if (wave >= 7) return;
   const int n0 = lane & 31, hb = lane >> 5;
   const int tile = blockIdx.x * 7 + wave;
   const int v = tile * 32 + n0;
   const bool valid = v < NV;
   const int vc = valid ? v : NV - 1;
 
+  // this wave's 32 query tokens first: their HBM latency hides under the staging of the clip's folded operands
   float x[32];
   if (xq) {
     load_slots(xq + ((long long)b * NV + vc) * 64, x, hb);
@@ -208,6 +204,9 @@ __global__ __launch_bounds__(512) void vertex_ca_kernel(const float* __restrict_
       x[s] = (Wv3[c * 3] * p0 + Wv3[c * 3 + 1] * p1 + Wv3[c * 3 + 2] * p2) + x[s];
     }
   }
+  stage_weight<64>(sK, Kf + (long long)b * 4096, 64, tid, 448);
+  stage_weight<64>(sV, Vf + (long long)b * 4096, 64, tid, 448);
+  if (tid < 64) sS0[tid] = s0[(long long)b * 64 + tid];
   // normalise (gamma/beta are folded into Kf/s0)
   float n[32];
   {
@@ -225,6 +224,7 @@ __global__ __launch_bounds__(512) void vertex_ca_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 32; ++i) n[i] = (x[i] - mean) * inv;
   }
+  __syncthreads();
   // scores^T[h*32+i, tok]
   f32x16 sc[2];
 #pragma unroll
@@ -256,13 +256,26 @@ __global__ __launch_bounds__(512) void vertex_ca_kernel(const float* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) p[16 * h + r] *= inv;
   }
-  // out^T[c, tok] = Vf[c, :] P + bp[c] + xq
+  // out^T[c, tok] = Vf[c, :] P + bp[c] + xq.  k-slot group qq of head h covers joints 8qq .. 8qq+7: groups whose
+  // joints are all >= J carry P = 0 and are skipped (J = 17: 3 of 4 groups per head remain).
   f32x16 o[2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[nt][r] = bp[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb];
-  tl_gemm<8, 2, LDW64>(sV, p, o, n0, hb);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    if (8 * (q & 3) < J) {  // wave-uniform
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sV + (nt * 32 + n0) * LDW64 + 8 * q + 4 * hb);
+        o[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, p[4 * q + 0], o[nt], 0, 0, 0);
+        o[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, p[4 * q + 1], o[nt], 0, 0, 0);
+        o[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, p[4 * q + 2], o[nt], 0, 0, 0);
+        o[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, p[4 * q + 3], o[nt], 0, 0, 0);
+      }
+    }
+  }
   if (valid) {
     float y[32];
 #pragma unroll
@@ -893,7 +906,7 @@ extern "C" int pmce_vertex_ca_f32(const float* xq, const float* vt, const float*
                                   hipStream_t stream) {
   PMCE_REQUIRE((xq || (vt && Wv3 && Eq)) && Kf && s0 && Vf && bp && out, "vertex_ca: null pointer");
   PMCE_REQUIRE(J >= 1 && J <= 32 && B > 0, "vertex_ca: J must be in 1..32");
-  hipLaunchKernelGGL(vertex_ca_kernel, dim3(2, B), dim3(512), 0, stream, xq, vt, Wv3, Eq, Kf, s0, Vf, bp, out, J);
+  hipLaunchKernelGGL(vertex_ca_kernel, dim3(2, B), dim3(448), 0, stream, xq, vt, Wv3, Eq, Kf, s0, Vf, bp, out, J);
   return pmce_check_launch("vertex_ca");
 }
 

@@ -1,0 +1,26 @@
+#!/bin/bash
+# PMC counters for selected kernels of the forward (one pass per counter group); usage: pmc_kernels.sh "regex"
+set -u
+pat=${1:-vertex_ca}
+export TMPDIR=/tmp
+mkdir -p gpurun_out/kpmc
+i=0
+for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM"; do
+  i=$((i+1))
+  (cd /tmp && timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OLDPWD/gpurun_out/kpmc/g$i -o pmc -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OLDPWD/gpurun_out/kpmc/g$i.log 2>&1)
+done
+PAT="$pat" python - <<'PY'
+import csv, glob, collections, os, re
+pat = re.compile(os.environ["PAT"])
+agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in glob.glob("gpurun_out/kpmc/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        name = row["Kernel_Name"].split("(")[0]
+        if not pat.search(name): continue
+        a = agg[name[:70]][row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
+for k in sorted(agg):
+    print(k)
+    for c, (v, n) in sorted(agg[k].items()):
+        print(f"    {c:32s} {v/n:16.1f}  (n={n})")
+PY
+find gpurun_out/kpmc -name "*.csv" -size +4M -delete
