@@ -172,6 +172,23 @@ int pmce_build_final_operand_f32(const float* g, const float* vt, float* A, int 
 int pmce_j_regress_f32(const float* mesh, const int* indptr, const int* indices, const float* data, float* out, int B,
                        int R, int NVF, float scale, pmce_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Evaluation metrics directly behind the path: replace the per-batch D2H + numpy of
+ * compute_both_err (data/PW3D/dataset.py:269-282) and the per-sample loop of evaluate (:351-462).
+ * ------------------------------------------------------------------------------------------------------- */
+/* Per sample b: mpvpe[b] = mean_v ||(pm*scale - rp) - (gm*scale - rg)||; joints P = pj - rowsum*rp (if rowsum), minus
+ * joint root_j, restricted to eval_idx (int32[n_eval]); mpjpe[b] = mean ||P-G||; pampjpe[b] after rigid_align
+ * (lib/coord_utils.py:151-173, fp64).  rp/rg NULL -> mesh roots are the samples' own joint root_j (compute_both_err).
+ * out_pe/out_ge (optional, [B,n_eval,3]) receive the aligned eval joints for pmce_accel_error_f32. */
+int pmce_sample_errors_f32(const float* pm, const float* gm, float scale, int V, const float* rp, const float* rg,
+                           const float* pj, const float* gj, int NJ, const float* rowsum, const int* eval_idx, int n_eval,
+                           int root_j, float* out_mpvpe, float* out_mpjpe, float* out_pampjpe, float* out_pe, float* out_ge,
+                           int B, pmce_stream_t stream);
+/* Per-sample acceleration error (lib/coord_utils.py:218-245 as used at data/PW3D/dataset.py:415-429): 0 for the first and
+ * last sample of each sequence (seq int32[N], samples of a sequence contiguous). */
+int pmce_accel_error_f32(const float* pe, const float* ge, const int* seq, float* out, int N, int n_eval,
+                         pmce_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

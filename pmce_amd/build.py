@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = osp.dirname(osp.abspath(__file__))
 CSRC = osp.join(HERE, "csrc")
 LIB = osp.join(HERE, "libpmce_hip.so")
-SOURCES = ["common.cpp", "gemm_f32.hip", "lifter.hip", "gru.hip", "coevo.hip", "model.cpp"]
+SOURCES = ["common.cpp", "gemm_f32.hip", "lifter.hip", "gru.hip", "coevo.hip", "metrics.hip", "model.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -1,0 +1,96 @@
+"""On-device evaluation behind the hot path — drop-ins for the reference's metric code:
+
+* :meth:`Evaluator.compute_both_err`  ==  ``dataset.compute_both_err`` (data/PW3D/dataset.py:269-282), the per-batch running
+  MPJPE / MPVPE printed by ``Tester.test`` (lib/core/base.py:227-233), without the D2H copy of ``[B,6890,3]`` meshes;
+* :meth:`Evaluator.evaluate`  ==  the arithmetic of ``dataset.evaluate`` (data/PW3D/dataset.py:351-462): MPJPE, PA-MPJPE,
+  MPVPE and acceleration error over a (possibly rank-sharded) set of clips, reduced with one small collective.
+
+Kernels: csrc/metrics.hip through the C ABI.  torch is used for allocation and the final few-float reductions only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, assets, ops, sharding
+
+H36M_EVAL_JOINT = (1, 2, 3, 4, 5, 6, 8, 10, 11, 12, 13, 14, 15, 16)   # data/PW3D/dataset.py:35
+P = _lib.ptr
+
+
+class Evaluator:
+    def __init__(self, device, j_regressor_h36m=None, root_regressor_row=None, eval_joint=H36M_EVAL_JOINT, root_joint=0):
+        """j_regressor_h36m: dense [17,6890] (default: the bundled J_regressor_h36m_correct).  root_regressor_row: dense
+        [6890] weights of the joint the MESH is root-aligned with in ``evaluate`` (the SMPL regressor's root row,
+        dataset.py:379-384; default = h36m joint 0 when the SMPL model files are unavailable)."""
+        self.device = torch.device(device)
+        self.lib = _lib.load()
+        jr = assets.load_j_regressor("h36m") if j_regressor_h36m is None else np.asarray(j_regressor_h36m)
+        self.jr = jr.astype(np.float32)
+        root = self.jr[root_joint] if root_regressor_row is None else np.asarray(root_regressor_row, dtype=np.float32)
+        self.root_row = root.reshape(1, -1)
+        self.rowsum = torch.from_numpy(self.jr.astype(np.float64).sum(1).astype(np.float32)).to(self.device)
+        self.eval_idx = torch.tensor(list(eval_joint), dtype=torch.int32, device=self.device)
+        self.n_eval, self.root_joint = len(eval_joint), root_joint
+
+    def _sample_errors(self, pm, gm, scale, rp, rg, pj, gj, rowsum, want_joints):
+        B, V, _ = pm.shape
+        dev = pm.device
+        out = [torch.empty(B, device=dev, dtype=torch.float32) for _ in range(3)]
+        pe = ge = None
+        if want_joints:
+            pe = torch.empty(B, self.n_eval, 3, device=dev, dtype=torch.float32)
+            ge = torch.empty_like(pe)
+        _lib.check(self.lib.pmce_sample_errors_f32(P(pm), P(gm), scale, V, P(rp), P(rg), P(pj), P(gj), pj.shape[1], P(rowsum),
+                                                   P(self.eval_idx), self.n_eval, self.root_joint, P(out[0]), P(out[1]),
+                                                   P(out[2]), P(pe), P(ge), B, _lib.current_stream()), "sample_errors")
+        return out[0], out[1], out[2], pe, ge
+
+    @torch.no_grad()
+    def compute_both_err(self, pred_mesh, target_mesh, pred_joint, target_joint):
+        """Same arguments and return as the reference method (all in mm, GPU tensors): (joint_mean_error, mesh_mean_error)."""
+        c = lambda t: t.to(self.device, torch.float32).contiguous()
+        mv, mj, _, _, _ = self._sample_errors(c(pred_mesh), c(target_mesh), 1.0, None, None, c(pred_joint), c(target_joint),
+                                              None, False)
+        return float(mj.mean().item()), float(mv.mean().item())
+
+    @torch.no_grad()
+    def per_sample(self, pred_mesh_m, gt_mesh_m):
+        """dataset.evaluate's per-sample arithmetic for meshes in METRES (x1000 inside, base.py:223):
+        returns (mpvpe[N], mpjpe[N], pampjpe[N], pred_eval_joints[N,14,3], gt_eval_joints[N,14,3]) in mm."""
+        c = lambda t: t.to(self.device, torch.float32).contiguous()
+        pm, gm = c(pred_mesh_m), c(gt_mesh_m)
+        pj, gj = ops.j_regress(pm, self.jr, 1000.0), ops.j_regress(gm, self.jr, 1000.0)
+        rp = ops.j_regress(pm, self.root_row, 1000.0).reshape(-1, 3).contiguous()
+        rg = ops.j_regress(gm, self.root_row, 1000.0).reshape(-1, 3).contiguous()
+        return self._sample_errors(pm, gm, 1000.0, rp, rg, pj, gj, self.rowsum, True)
+
+    @torch.no_grad()
+    def accel(self, pe, ge, seq_ids):
+        seq = torch.as_tensor(np.asarray(seq_ids), dtype=torch.int32, device=pe.device).contiguous()
+        out = torch.empty(pe.shape[0], device=pe.device, dtype=torch.float32)
+        _lib.check(self.lib.pmce_accel_error_f32(P(pe.contiguous()), P(ge.contiguous()), P(seq), P(out), pe.shape[0],
+                                                 pe.shape[1], _lib.current_stream()), "accel_error")
+        return out
+
+    @torch.no_grad()
+    def evaluate(self, pred_mesh_m, gt_mesh_m, seq_ids_global, lo=None, hi=None):
+        """Metrics over a clip set sharded contiguously over the ranks of the default process group (or unsharded).
+        pred/gt: this rank's clips [lo,hi); seq_ids_global: int sequence id of EVERY clip (host array, clip order).
+        One all_reduce of 4 floats + one all_gather of the 14x3 eval joints — never the meshes."""
+        seq_ids_global = np.asarray(seq_ids_global)
+        N = len(seq_ids_global)
+        lo = 0 if lo is None else lo
+        hi = N if hi is None else hi
+        mv, mj, pa, pe, ge = self.per_sample(pred_mesh_m, gt_mesh_m)
+        assert mv.shape[0] == hi - lo
+        partial = torch.stack([mv.double().sum(), mj.double().sum(), pa.double().sum(),
+                               torch.tensor(float(hi - lo), device=mv.device, dtype=torch.float64)])
+        tot = sharding.reduce_metric_sums(partial)
+        allj = sharding.gather_rows(torch.cat([pe, ge], 1))            # [N, 28, 3] in clip order
+        acc = self.accel(allj[:, :self.n_eval].contiguous(), allj[:, self.n_eval:].contiguous(), seq_ids_global)
+        n = float(tot[3].item())
+        return {"MPVPE": float(tot[0].item()) / n, "MPJPE": float(tot[1].item()) / n, "PA-MPJPE": float(tot[2].item()) / n,
+                "ACCEL": float(acc.double().sum().item()) / n, "samples": int(n)}

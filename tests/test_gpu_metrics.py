@@ -1,0 +1,69 @@
+"""GPU parity of the on-device metrics (csrc/metrics.hip) vs the reference's own metric functions (golden) and the oracle."""
+import os.path as osp
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, osp.join(osp.dirname(osp.abspath(__file__)), "golden"))
+from make_golden_metrics import inputs, smpl_like_regressor  # noqa: E402
+from oracle import metrics_oracle as MO  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def test_metrics_match_reference(golden):
+    from pmce_amd import assets
+    from pmce_amd.eval import Evaluator
+    dev = torch.device("cuda:0")
+    z = golden("metrics.npz")
+    pred, gt, seq = inputs()
+    jr = assets.load_j_regressor("h36m").astype(np.float32)
+    ev = Evaluator(dev, root_regressor_row=smpl_like_regressor()[0])
+    # compute_both_err: same call as Tester.test (mm tensors)
+    pm, gm = torch.from_numpy(pred).to(dev), torch.from_numpy(gt).to(dev)
+    J = torch.from_numpy(jr).to(dev)
+    pj, gj = torch.matmul(J[None], pm), torch.matmul(J[None], gm)
+    j_err, s_err = ev.compute_both_err(pm, gm, pj, gj)
+    print(f"compute_both_err: joint {j_err:.5f} (ref {float(z['j_err']):.5f}) mesh {s_err:.5f} (ref {float(z['s_err']):.5f})")
+    assert abs(j_err - float(z["j_err"])) < 1e-3 and abs(s_err - float(z["s_err"])) < 1e-3          # mm
+    # evaluate(): meshes in metres as they leave the model
+    mv, mj, pa, pe, ge = ev.per_sample(pm / 1000, gm / 1000)
+    e_mv = np.abs(mv.cpu().numpy() - z["mpvpe_mean_per_sample"]).max()
+    e_mj = np.abs(mj.cpu().numpy() - z["mpjpe"].mean(1)).max()
+    e_pa = np.abs(pa.cpu().numpy() - z["pampjpe"].mean(1)).max()
+    print(f"per-sample vs reference: MPVPE {e_mv:.2e} MPJPE {e_mj:.2e} PA-MPJPE {e_pa:.2e} mm")
+    assert e_mv < 1e-3 and e_mj < 1e-3 and e_pa < 1e-3
+    res = ev.evaluate(pm / 1000, gm / 1000, seq)
+    print(res)
+    assert abs(res["ACCEL"] * len(seq) - float(z["acc_error_sum"])) < 1e-2
+    assert abs(res["MPJPE"] - z["mpjpe"].mean()) < 1e-3 and abs(res["PA-MPJPE"] - z["pampjpe"].mean()) < 1e-3
+    assert abs(res["MPVPE"] - z["mpvpe_mean_per_sample"].mean()) < 1e-3
+
+
+def test_procrustes_edge_cases():
+    """reflection branch (det(R) < 0) and an exact similarity, vs the oracle."""
+    from pmce_amd.eval import Evaluator
+    dev = torch.device("cuda:0")
+    ev = Evaluator(dev)
+    rng = np.random.default_rng(1)
+    B, V = 4, 64
+    pj = rng.standard_normal((B, 17, 3)).astype(np.float32) * 100
+    gj = pj.copy()
+    gj[0] = gj[0] * 1.3 + 5.0                       # exact similarity -> PA error 0
+    gj[1][:, 0] *= -1                                # mirrored target -> reflection branch
+    gj[2] += rng.standard_normal((17, 3)).astype(np.float32) * 20
+    gj[3] = rng.standard_normal((17, 3)).astype(np.float32) * 100
+    mesh = np.zeros((B, V, 3), dtype=np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    _, mj, pa, _, _ = ev._sample_errors(t(mesh), t(mesh), 1.0, None, None, t(pj), t(gj), None, False)
+    idx = list(MO.H36M_EVAL_JOINT)
+    for b in range(B):
+        Pb = (pj[b] - pj[b][0])[idx].astype(np.float64)
+        Gb = (gj[b] - gj[b][0])[idx].astype(np.float64)
+        ref_pa = np.sqrt(((MO.rigid_align(Pb, Gb) - Gb) ** 2).sum(1)).mean()
+        ref_mj = np.sqrt(((Pb - Gb) ** 2).sum(1)).mean()
+        assert abs(float(pa[b]) - ref_pa) < 1e-3 * max(1.0, ref_pa), (b, float(pa[b]), ref_pa)
+        assert abs(float(mj[b]) - ref_mj) < 1e-3 * max(1.0, ref_mj)
+    assert float(pa[0]) < 1e-3
