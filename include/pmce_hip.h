@@ -189,6 +189,12 @@ int pmce_sample_errors_f32(const float* pm, const float* gm, float scale, int V,
 int pmce_accel_error_f32(const float* pe, const float* ge, const int* seq, float* out, int N, int n_eval,
                          pmce_stream_t stream);
 
+/* Sliding-window clip assembly on the GPU (lib/_img_utils.py:42-55; demo lib/utils/_dataset_demo.py:98-102):
+ * per-frame tables pose[L,J,2], feat[L,2048] + windows int32[W,2] (inclusive [start,end]; start == end repeats the frame)
+ * -> out_pose[W,16,J,2], out_feat[W,16,2048]. */
+int pmce_assemble_windows_f32(const float* pose, const float* feat, const int* win, float* out_pose, float* out_feat, int W,
+                              int L, int J, pmce_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

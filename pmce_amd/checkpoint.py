@@ -1,0 +1,91 @@
+"""Checkpoint I/O for the hot path.
+
+* :func:`load_reference_checkpoint` reads a reference ``*.pth.tar`` (``torch.save`` dict with ``'model_state_dict'``,
+  main/train.py:57-64; lifter-only checkpoints have the same key, PoseEstimation.py:71-74), strips a DataParallel
+  ``module.`` prefix (lib/funcs_utils.py:65-70), infers (num_joint, embed_dim, depth) from tensor shapes and validates every
+  key/shape against the layout of SURVEY §8b, naming anything missing or unexpected instead of failing later on the GPU.
+* :func:`export_packed` / :func:`load_packed` write/read the kernel-ready packed operands (pmce_amd.packing) as one
+  safetensors file, so a serving process can mmap the weights without the reference layout or the load-time repacking.
+"""
+from __future__ import annotations
+
+import re
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import packing, synth
+
+
+def infer_dims(sd):
+    """(kind, num_joint, embed_dim, depth) from a state_dict; kind in {'pmce', 'lifter', 'decoder'}."""
+    keys = list(sd.keys())
+    if any(k.startswith("pose_lifter.") for k in keys):
+        kind, lp = "pmce", "pose_lifter."
+    elif "spatial_pos_embed" in sd:
+        kind, lp = "lifter", ""
+    elif any(k.startswith("coevoblock1.") for k in keys):
+        j = sd["coevoblock1.joint_pos_embed"].shape[1]
+        return "decoder", int(j), 256, 3
+    else:
+        raise ValueError("not a PMCE / GraphormerNet / Pose2Mesh state_dict")
+    spe = sd[lp + "spatial_pos_embed"]
+    depth = 1 + max(int(m.group(1)) for k in keys for m in [re.match(re.escape(lp) + r"SpatialBlocks\.(\d+)\.", k)] if m)
+    return kind, int(spe.shape[1]), int(spe.shape[2]), depth
+
+
+def validate_state_dict(sd):
+    """Raise ValueError listing every missing / unexpected / mis-shaped tensor; returns (kind, J, C, depth)."""
+    kind, J, C, depth = infer_dims(sd)
+    spec = {"pmce": lambda: synth.pmce_spec(J, C, depth), "lifter": lambda: synth.lifter_spec(J, C, depth),
+            "decoder": lambda: synth.decoder_spec(J)}[kind]()
+    problems = []
+    for k, (shape, _, _) in spec.items():
+        if k not in sd:
+            problems.append(f"missing: {k} {tuple(shape)}")
+        elif tuple(sd[k].shape) != tuple(shape):
+            problems.append(f"shape: {k} is {tuple(sd[k].shape)}, expected {tuple(shape)}")
+    for k in sd:
+        if k not in spec:
+            problems.append(f"unexpected: {k}")
+    if problems:
+        raise ValueError(f"{kind} checkpoint (J={J}, C={C}, depth={depth}) does not match the reference layout:\n  "
+                         + "\n  ".join(problems[:40]) + ("\n  ..." if len(problems) > 40 else ""))
+    return kind, J, C, depth
+
+
+def load_reference_checkpoint(path, map_location="cpu"):
+    """-> (state_dict, kind, num_joint, embed_dim, depth); raises ValueError("No checkpoint exists!") like the reference's
+    load_checkpoint (lib/funcs_utils.py:122-128) when the file cannot be read."""
+    try:
+        obj = torch.load(path, map_location=map_location, weights_only=False)
+    except Exception as e:  # noqa: BLE001 - same contract as the reference
+        raise ValueError("No checkpoint exists!\n", e)
+    sd = packing.unwrap_checkpoint(obj)
+    kind, J, C, depth = validate_state_dict(sd)
+    return sd, kind, J, C, depth
+
+
+def export_packed(model, path):
+    """Write the packed operands of a pmce_amd.models.PMCE instance (on the GPU) to a safetensors file."""
+    from safetensors.torch import save_file
+    eng = model._ensure_packed()
+    tensors = OrderedDict((k, v.detach().cpu().contiguous()) for k, v in eng.packed.items())
+    meta = {"format": "pmce_amd.packed.v1", "num_joint": str(model.num_joint), "embed_dim": str(model.embed_dim),
+            "depth": str(model.depth)}
+    save_file(tensors, path, metadata=meta)
+    return meta
+
+
+def load_packed(path, device):
+    """-> (tensors on device, meta).  Register them with HipEngine.register() / pmce_model_set_tensor."""
+    from safetensors import safe_open
+    out = OrderedDict()
+    with safe_open(path, framework="pt", device=str(device)) as f:
+        meta = f.metadata()
+        for k in f.keys():
+            out[k] = f.get_tensor(k).contiguous()
+    if not meta or meta.get("format") != "pmce_amd.packed.v1":
+        raise ValueError(f"{path} is not a pmce_amd packed-weights file")
+    return out, meta

@@ -233,3 +233,30 @@ extern "C" int pmce_accel_error_f32(const float* pe, const float* ge, const int*
   hipLaunchKernelGGL(accel_error_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, pe, ge, seq, out, N, n_eval);
   return pmce_check_launch("accel_error");
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Window assembly for sliding-window evaluation (lib/_img_utils.py:42-55; demo lib/utils/_dataset_demo.py:98-102):
+// out_feat[w][t][:] = feat[frame(w,t)][:], out_pose likewise, frame(w,t) = start + t, or start when start == end.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void assemble_windows_kernel(const float* __restrict__ pose, const float* __restrict__ feat,
+                                                               const int* __restrict__ win, float* __restrict__ out_pose,
+                                                               float* __restrict__ out_feat, int W, int L, int J) {
+  const int wt = blockIdx.x;  // (window, t)
+  const int w = wt >> 4, t = wt & 15;
+  const int s = win[2 * w], e = win[2 * w + 1];
+  int fr = (s == e) ? s : s + t;
+  fr = min(max(fr, 0), L - 1);
+  const f32x4* src = reinterpret_cast<const f32x4*>(feat + (long long)fr * 2048);
+  f32x4* dst = reinterpret_cast<f32x4*>(out_feat + (long long)wt * 2048);
+  for (int i = threadIdx.x; i < 512; i += 256) dst[i] = src[i];
+  const float* ps = pose + (long long)fr * J * 2;
+  float* pd = out_pose + (long long)wt * J * 2;
+  for (int i = threadIdx.x; i < J * 2; i += 256) pd[i] = ps[i];
+}
+
+extern "C" int pmce_assemble_windows_f32(const float* pose, const float* feat, const int* win, float* out_pose,
+                                         float* out_feat, int W, int L, int J, hipStream_t stream) {
+  PMCE_REQUIRE(pose && feat && win && out_pose && out_feat && W > 0 && L > 0 && J > 0, "assemble_windows: bad args");
+  hipLaunchKernelGGL(assemble_windows_kernel, dim3(W * 16), dim3(256), 0, stream, pose, feat, win, out_pose, out_feat, W, L, J);
+  return pmce_check_launch("assemble_windows");
+}

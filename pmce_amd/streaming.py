@@ -1,0 +1,73 @@
+"""Sliding-window ("streaming") evaluation of long sequences — BASELINE config 5, SURVEY §8f ranks 2-3.
+
+The reference handles a video by cutting it into stride-1 windows of 16 frames, each an independent clip that predicts its
+middle frame (lib/_img_utils.py:27-57 ``split_into_chunks_pose``; demo: lib/utils/_dataset_demo.py:91-104 with the first and
+last 8 frames served by a single frame repeated 16 times).  Every frame's 2048-d feature would be copied 16 times if the
+windows were materialised on the host; here the per-frame tables are uploaded once and the windows are assembled on the
+GPU by ``pmce_assemble_windows_f32`` (16-byte vector copies, HBM-bound).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import FEAT_DIM, SEQLEN
+
+
+def window_indices(num_frames: int, seqlen: int = SEQLEN, stride: int = 1, match_vibe: bool = True) -> np.ndarray:
+    """[start, end] (inclusive) of every window of ONE video, as ``split_into_chunks_pose`` produces them
+    (lib/_img_utils.py:42-55): all stride-``stride`` windows, then — when stride != seqlen and match_vibe — trailing windows
+    are dropped so that the last window ends where the last full 16-frame VIBE chunk ends."""
+    if num_frames < seqlen:
+        return np.zeros((0, 2), dtype=np.int64)
+    starts = np.arange(0, num_frames - seqlen + 1, stride)
+    sf = np.stack([starts, starts + seqlen - 1], 1)
+    if stride != seqlen and match_vibe:
+        vibe_last_end = (num_frames // 16) * 16 - 1          # last element of view_as_windows(indexes, 16, step=16)[-1]
+        for j in range(1, len(sf) + 1):
+            if sf[-j][1] == vibe_last_end:
+                if j != 1:
+                    sf = sf[: len(sf) - j + 1]
+                break
+    return sf.astype(np.int64)
+
+
+def demo_window_list(num_frames: int, seqlen: int = SEQLEN) -> np.ndarray:
+    """One window per frame as the demo builds them (lib/utils/_dataset_demo.py:91-96): frames 0..seqlen/2-1 and the last
+    seqlen/2-1 frames use a single frame repeated seqlen times ([i,i]), the others the window whose middle they are."""
+    h = seqlen // 2
+    mid = [[i, i + seqlen - 1] for i in range(num_frames - seqlen + 1)]
+    head = [[i, i] for i in range(h)]
+    tail = [[num_frames - h + i, num_frames - h + i] for i in range(1, h)]
+    return np.asarray(head + mid + tail, dtype=np.int64)
+
+
+def assemble_windows(pose2d_frames: torch.Tensor, feat_frames: torch.Tensor, windows) -> tuple:
+    """Per-frame tables pose2d[L,J,2], feat[L,2048] (GPU) + windows int[W,2] -> (pose2d[W,16,J,2], img_feat[W,16,2048]).
+    start == end means "this frame repeated 16 times" (the demo's head/tail windows)."""
+    lib = _lib.load()
+    dev = feat_frames.device
+    p = pose2d_frames.to(torch.float32).contiguous()
+    f = feat_frames.to(torch.float32).contiguous()
+    L, J, _ = p.shape
+    w = torch.as_tensor(np.asarray(windows, dtype=np.int32), device=dev).contiguous()
+    W = w.shape[0]
+    out_p = torch.empty(W, SEQLEN, J, 2, device=dev, dtype=torch.float32)
+    out_f = torch.empty(W, SEQLEN, FEAT_DIM, device=dev, dtype=torch.float32)
+    _lib.check(lib.pmce_assemble_windows_f32(_lib.ptr(p), _lib.ptr(f), _lib.ptr(w), _lib.ptr(out_p), _lib.ptr(out_f), W, L, J,
+                                             _lib.current_stream()), "assemble_windows")
+    return out_p, out_f
+
+
+@torch.no_grad()
+def stream_forward(model, pose2d_frames, feat_frames, windows=None, batch: int = 256, with_joints: bool = False):
+    """Run ``model`` over all windows of one sequence in batches of ``batch`` clips; returns the concatenated outputs
+    (one row per window = per predicted middle frame)."""
+    L = feat_frames.shape[0]
+    windows = window_indices(L) if windows is None else np.asarray(windows)
+    outs = []
+    for lo in range(0, len(windows), batch):
+        p, f = assemble_windows(pose2d_frames, feat_frames, windows[lo:lo + batch])
+        outs.append(model.forward_with_joints(p, f) if with_joints else model(p, f))
+    return tuple(torch.cat([o[i] for o in outs], 0) for i in range(len(outs[0]))) if outs else ()

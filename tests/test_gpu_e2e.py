@@ -155,3 +155,47 @@ def test_full_size_properties(B):
     # regressed joints against a dense fp64 product
     ref = torch.einsum("jv,bvl->bjl", T(jr).double(), mesh.double().cpu() * 1000)
     assert maxabs(pred, ref) < 5e-3
+
+
+def test_streaming_windows_and_packed_weights(tmp_path):
+    """BASELINE config 5 plumbing: GPU window assembly is a bit-exact gather, stream_forward == forward on explicit windows;
+    and the packed-weights export round-trips."""
+    from pmce_amd import checkpoint, streaming, synth
+    J = 17
+    model = get_model(J, 256)
+    L = 40
+    p_np, f_np = synth.make_inputs(3, J, 5)                      # 48 frames of per-frame data
+    pose_fr = T(p_np.reshape(-1, J, 2)[:L]).to(dev())
+    feat_fr = T(f_np.reshape(-1, 2048)[:L]).to(dev())
+    win = streaming.demo_window_list(L)                          # includes repeated-frame head/tail windows
+    wp, wf = streaming.assemble_windows(pose_fr, feat_fr, win)
+    for w, (s, e) in enumerate(win):
+        idx = [s] * 16 if s == e else list(range(s, e + 1))
+        assert torch.equal(wf[w], feat_fr[idx]) and torch.equal(wp[w], pose_fr[idx])
+    out = streaming.stream_forward(model, pose_fr, feat_fr, windows=win, batch=16)
+    ref = model(wp, wf)
+    assert out[0].shape == (L, 6890, 3)
+    assert maxabs(out[0], ref[0]) < 1e-5 and maxabs(out[2], ref[2]) < 1e-2
+    # packed weights file
+    f = tmp_path / "packed.safetensors"
+    meta = checkpoint.export_packed(model, str(f))
+    tensors, meta2 = checkpoint.load_packed(str(f), dev())
+    assert meta2["num_joint"] == "17" and set(tensors) == set(model._engine.packed)
+    for k, v in tensors.items():
+        assert torch.equal(v, model._engine.packed[k]), k
+
+
+@pytest.mark.parametrize("B", [1, 77])
+def test_odd_batch_sizes(B):
+    """ragged batch sizes (no tile of any kernel is full): clip i of the batch == the same clip in a batch of 3."""
+    from pmce_amd import synth
+    J = 19
+    model = get_model(J, 256)
+    pose2d, img_feat = synth.make_inputs(B, J, 31)
+    p, f = T(pose2d).to(dev()), T(img_feat).to(dev())
+    mesh, pose, pose3d = model(p, f)
+    assert torch.isfinite(mesh).all()
+    for i in sorted({0, B // 2, B - 1}):
+        sel = [i, 0, B - 1]
+        m2, q2, l2 = model(p[sel], f[sel])
+        assert maxabs(m2[0], mesh[i]) < 1e-5 and maxabs(q2[0], pose[i]) < 1e-5 and maxabs(l2[0], pose3d[i]) < 1e-2

@@ -143,3 +143,25 @@ def test_build_verts_joints_relation_ties_first_index():
     joints = np.array([[0, 0, 0], [2, 0, 0], [0, 0, 0]], dtype=np.float32)       # joint 2 duplicates joint 0
     verts = np.array([[0.1, 0, 0], [1.0, 0, 0], [1.9, 0, 0]], dtype=np.float32)  # middle vertex equidistant
     assert assets.build_verts_joints_relation(joints, verts).tolist() == [0, 0, 1]
+
+
+def test_checkpoint_tooling(tmp_path):
+    from pmce_amd import checkpoint
+    sd = cached_state_dict(17, 256)
+    p = tmp_path / "mesh_test.pth.tar"
+    torch.save({"epoch": 3, "model_state_dict": {"module." + k: v for k, v in sd.items()}, "optim_state_dict": {},
+                "scheduler_state_dict": {}, "train_log": [], "test_log": []}, p)          # main/train.py:57-64 format
+    sd2, kind, J, C, depth = checkpoint.load_reference_checkpoint(str(p))
+    assert (kind, J, C, depth) == ("pmce", 17, 256, 3) and set(sd2) == set(sd)
+    lifter = {k[len("pose_lifter."):]: v for k, v in sd.items() if k.startswith("pose_lifter.")}
+    assert checkpoint.infer_dims(lifter) == ("lifter", 17, 256, 3)
+    bad = dict(sd)
+    bad.pop("pose_lifter.norm_s.weight")
+    bad["pose_mesh_coevo.linear_cur1.bias"] = torch.zeros(5)
+    bad["extra.key"] = torch.zeros(1)
+    with pytest.raises(ValueError) as e:
+        checkpoint.validate_state_dict(bad)
+    msg = str(e.value)
+    assert "missing: pose_lifter.norm_s.weight" in msg and "shape: pose_mesh_coevo.linear_cur1.bias" in msg and "unexpected: extra.key" in msg
+    with pytest.raises(ValueError, match="No checkpoint exists"):
+        checkpoint.load_reference_checkpoint(str(tmp_path / "nope.pth.tar"))
