@@ -136,7 +136,9 @@ __global__ __launch_bounds__(256) void ca_fold_kernel(const float* __restrict__ 
   lin_small<64, 64>(s_k, JLD, Wk, bk, s_a, JLD, J, tid, false);  // s_a = k
   lin_small<64, 64>(s_v, JLD, Wv, bv, s_b, JLD, J, tid, false);  // s_b = v
   __syncthreads();
-  const float scale = 0.17677669529663688110f;  // 32^-0.5 (vertx heads = 2, head_dim 32; CoevoDecoder.py:140,37-38)
+  // 32^-0.5 (vertx heads = 2, head_dim 32; CoevoDecoder.py:140,37-38) times log2(e): vertex_ca's softmax runs on the
+  // hardware 2^x, so the folded scores are produced directly in log2 units
+  const float scale = 0.17677669529663688110f * 1.44269504088896340736f;
   const float gq = gb[iq * 128 + lane], bqv = gb[iq * 128 + 64 + lane];
   float* Kfb = Kf + (long long)b * 64 * 64;
   float* Vfb = Vf + (long long)b * 64 * 64;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(448, 4) void vertex_ca_kernel(const float* __restri
     float sum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float e = expf(sc[h][r] - m);
+      const float e = __builtin_amdgcn_exp2f(sc[h][r] - m);  // scores are in log2 units (ca_fold)
       p[16 * h + r] = e;
       sum += e;
     }
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(256) void joint_stream_kernel(const float* __restri
     const int i = tid >> 3, h = tid & 7;
     const bool act = i < J;
     float qv[8], o[8];
-    const float scale = 0.35355339059327376220f;  // 8^-0.5 (joint heads = 8, head_dim 8)
+    const float scale = 0.35355339059327376220f * 1.44269504088896340736f;  // 8^-0.5 (8 heads of 8) * log2(e): 2^x softmax
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
       qv[d] = act ? s_q[i * JLD + 8 * h + d] * scale : 0.f;
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(256) void joint_stream_kernel(const float* __restri
           const float sc = qv[0] * k0.x + qv[1] * k0.y + qv[2] * k0.z + qv[3] * k0.w + qv[4] * k1.x + qv[5] * k1.y +
                            qv[6] * k1.z + qv[7] * k1.w;
           const float mn = fmaxf(m, sc);
-          const float corr = expf(m - mn), pj = expf(sc - mn);
+          const float corr = __builtin_amdgcn_exp2f(m - mn), pj = __builtin_amdgcn_exp2f(sc - mn);
           l = l * corr + pj;
           const f32x4 v0 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 64 + 8 * h]);
           const f32x4 v1 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 64 + 8 * h + 4]);
@@ -775,7 +777,7 @@ __global__ __launch_bounds__(256) void joint_stream_kernel(const float* __restri
   {
     const int i = tid >> 3, h = tid & 7;
     if (i < J) {
-      const float scale = 0.35355339059327376220f;
+      const float scale = 0.35355339059327376220f * 1.44269504088896340736f;
       float qv[8], o[8];
 #pragma unroll
       for (int d = 0; d < 8; ++d) {
@@ -788,7 +790,7 @@ __global__ __launch_bounds__(256) void joint_stream_kernel(const float* __restri
 #pragma unroll
         for (int d = 0; d < 8; ++d) sc += qv[d] * s_h[j * 193 + 64 + 8 * h + d];
         const float mn = fmaxf(m, sc);
-        const float corr = expf(m - mn), pj = expf(sc - mn);
+        const float corr = __builtin_amdgcn_exp2f(m - mn), pj = __builtin_amdgcn_exp2f(sc - mn);
         l = l * corr + pj;
 #pragma unroll
         for (int d = 0; d < 8; ++d) o[d] = o[d] * corr + pj * s_h[j * 193 + 128 + 8 * h + d];

@@ -43,7 +43,21 @@ int pmce_check_launch(const char* what);
 // so the output of one token-local GEMM is directly the B operand of the next: no LDS round trip.
 __device__ __forceinline__ int slot_channel(int s, int hb) { return 8 * (s >> 2) + 4 * hb + (s & 3); }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf for the erf-GELU.  fp32 MFMA and fp32 VALU share the same FMA units on gfx950 (measured: both together deliver
+// LESS than MFMA alone, scripts/microbench/mfma_valu.hip), so every VALU instruction in an MFMA kernel's epilogue costs
+// matrix throughput.  ocml erff is 36 VALU instructions; this is Abramowitz-Stegun 7.1.26 on the hardware rcp/exp2: 14
+// instructions, max abs error 4.7e-7 over [-6,6] (fp32 ulp at 1 is 1.2e-7; torch's own fp32 GELU sits 4.5e-7 from fp64).
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
+  return copysignf(fmaf(-p * t, e, 1.0f), x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 

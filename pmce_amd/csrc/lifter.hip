@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void seq_attention_kernel(const float* __restr
   const int lane = tid & 63, wave = tid >> 6;
   const int head = wave * 2 + (lane >> 5), i = lane & 31;
   if (i >= N) return;
-  const float scale = 1.0f / sqrtf((float)HD);
+  const float scale = 1.44269504088896340736f / sqrtf((float)HD);  // hd^-0.5 * log2(e): softmax on the hardware 2^x
   float q[HD], o[HD];
   const float* qsrc = qkv + (base + i * tok_stride) * (3 * C) + head * HD;
 #pragma unroll
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void seq_attention_kernel(const float* __restr
     }
     sc *= scale;
     const float mn = fmaxf(m, sc);
-    const float corr = expf(m - mn);  // first key: exp(-inf) = 0
-    const float pj = expf(sc - mn);
+    const float corr = __builtin_amdgcn_exp2f(m - mn);  // first key: 2^(-inf) = 0
+    const float pj = __builtin_amdgcn_exp2f(sc - mn);
     l = l * corr + pj;
     const float* vr = Vs + j * C + head * HD;
 #pragma unroll
