@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--joints", type=int, default=17)
     ap.add_argument("--embed-dim", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="keep every launch on one stream (profiling: rocprofv3 then prices each kernel alone)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -119,6 +121,9 @@ def main():
 
     def step():
         return model.forward_with_joints(pose2d, img_feat)
+
+    if args.single_stream:
+        model.set_concurrency(False)
 
     for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
         out = step()
@@ -152,6 +157,8 @@ def main():
     torch.cuda.synchronize()
     prof = model.profile_read()
     model.profile(False)
+    if args.single_stream:
+        model.set_concurrency(False)
     kernel_ms = {k: round(v[0] / nprof, 4) for k, v in prof.items() if v[1] > 0}
     launches = {k: int(v[1] // nprof) for k, v in prof.items() if v[1] > 0}
     # group timing classes by kernel function: the dominant KERNEL is what the roofline prices
@@ -233,7 +240,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"full two-stream PMCE forward (temporal pose encoder + CoEvoDecoder + 6890-vertex "
                                    f"upsample + J_regressor), batch={B}/GPU, T=16, J={J}, C={C}, random-init weights",
-                       "global_batch": B * world, "parallelism": f"clip-sharded dp{world}, weights replicated"},
+                       "global_batch": B * world, "parallelism": f"clip-sharded dp{world}, weights replicated",
+                       "streams": 1 if args.single_stream else 2},
             "roofline": roofline, "roofline_cross_attention": ca, "cpu_baseline": cpu,
             "kernel_ms_per_step": kernel_ms, "launches_per_step": launches,
             "ref_equiv_tflops": round(flops_clip * clips_per_s / 1e12, 2) if flops_clip else None,

@@ -17,7 +17,7 @@ if [[ $what == all || $what == bench ]]; then
 fi
 if [[ $what == all || $what == prof ]]; then
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof -o trace -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OLDPWD/gpurun_out/prof.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof -o trace -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --single-stream > $OLDPWD/gpurun_out/prof.log 2>&1)
   echo "rocprof exit: $?"
   find gpurun_out/prof -name "*stats*" | head
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)

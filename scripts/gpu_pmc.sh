@@ -6,7 +6,7 @@ mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc/$c
-  (cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OLDPWD/gpurun_out/pmc/$c -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/gpurun_out/pmc/$c.log 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OLDPWD/gpurun_out/pmc/$c -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --single-stream > $OLDPWD/gpurun_out/pmc/$c.log 2>&1)
   echo "$c exit $?"
 done
 python - <<'PY'
