@@ -118,10 +118,6 @@ int pmce_seq_attention_f32(const float* qkv, float* out, int nseq, int N, int C,
 int pmce_lifter_head_f32(const float* x, const float* lnw, const float* lnb, const float* Wr, const float* br,
                          const float* wf, const float* bf, float* pose3d, int B, int T, int J, int C, pmce_stream_t stream);
 
-/* nn.GRU gate update of one time step for ndir directions (CoevoDecoder.py:216-221). */
-int pmce_gru_gates_f32(const float* gi0, const float* gi1, const float* gh0, const float* gh1, const float* hp0,
-                       const float* hp1, float* ho0, float* ho1, long long gi_rs, long long gh_rs0, long long gh_rs1,
-                       long long hp_rs, long long ho_rs, int B, int H, int ndir, pmce_stream_t stream);
 /* Fused nn.GRU time step for ndir directions: gh = h_prev W_hh^T + b_hh on the matrix cores, then the gate update
  * (CoevoDecoder.py:216-221); gi = W_ih x + b_ih comes from pmce_gemm_nt_f32.  hp == NULL means h_prev = 0. */
 int pmce_gru_step_f32(const float* gi0, const float* gi1, const float* whh0, const float* whh1, const float* bhh0,

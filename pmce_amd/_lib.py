@@ -38,7 +38,6 @@ PROTOTYPES = {
     "pmce_ln_chain_f32": [_f, _l, _i, _f, _f, _fl, _f, _i, _i, _f, _f, _f, _fl, _f, _s],
     "pmce_seq_attention_f32": [_f, _f, _i, _i, _i, _i, _l, _l, _l, _s],
     "pmce_lifter_head_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _s],
-    "pmce_gru_gates_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _l, _l, _l, _l, _l, _i, _i, _i, _s],
     "pmce_gru_step_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _l, _l, _i, _i, _i, _s],
     "pmce_div_scalar_f32": [_f, _f, _l, _fl, _s],
     "pmce_vertex_init_gather_f32": [_f, _f, _f, _i, _i, _s],

@@ -22,13 +22,13 @@ constexpr int FINAL_K = 3360;  // 2048 + 1293 = 3341 rounded up to a multiple of
 constexpr int N_ADA = 24;      // live AdaLN instances (joint stream of blocks 1-2 is dead at inference)
 
 enum ProfClass {
-  P_GEMM_LIFTER, P_GEMM_GRU_IN, P_GRU_STEP, P_GEMM_ADA, P_GEMM_FINAL, P_LN, P_SEQ_ATTN, P_EMBED, P_HEAD, P_GRU_GATES_UNUSED,
+  P_GEMM_LIFTER, P_GEMM_GRU_IN, P_GRU_STEP, P_GEMM_ADA, P_GEMM_FINAL, P_LN, P_SEQ_ATTN, P_EMBED, P_HEAD,
   P_GATHER, P_JOINT_EMBED, P_CA_FOLD, P_VERTEX_CA, P_ADALN_MLP, P_ADALN_QKV, P_VERTEX_SA, P_TOKENS_KV, P_JOINT_STREAM,
   P_FINAL_OP, P_JREG, P_MISC, P_COUNT
 };
 const char* kProfNames[P_COUNT] = {
     "gemm_lifter", "gemm_gru_in", "gru_step", "gemm_ada", "gemm_final", "ln_chain", "seq_attention", "embed_tokens",
-    "lifter_head", "gru_gates_unused", "vertex_init_gather", "joint_embed", "ca_fold", "vertex_ca", "adaln_mlp", "adaln_qkv",
+    "lifter_head", "vertex_init_gather", "joint_embed", "ca_fold", "vertex_ca", "adaln_mlp", "adaln_qkv",
     "vertex_sa", "tokens_kv", "joint_stream", "build_final_operand", "j_regress", "misc"};
 
 struct Ev {
@@ -155,7 +155,7 @@ struct LifterWs {
   float *E, *X, *XN, *QKV, *AO;
 };
 struct DecoderWs {
-  float *GI0, *Y0, *GHb, *GI1, *Y1, *GB, *VT[3], *JF[3], *XK[3], *KF[3], *S0[3], *VF[3], *F1, *F2, *QKV, *KVJ, *FA, *JM;
+  float *GI0, *Y0, *GI1, *Y1, *GB, *VT[3], *JF[3], *XK[3], *KF[3], *S0[3], *VF[3], *F1, *F2, *QKV, *KVJ, *FA, *JM;
 };
 
 void carve_lifter(Carver& c, const pmce_model* m, int B, LifterWs& w) {
@@ -169,7 +169,6 @@ void carve_lifter(Carver& c, const pmce_model* m, int B, LifterWs& w) {
 void carve_decoder(Carver& c, const pmce_model* m, int B, DecoderWs& w) {
   w.GI0 = c.take((size_t)T * B * 6 * GH);
   w.Y0 = c.take((size_t)T * B * 2 * GH);
-  w.GHb = c.take((size_t)2 * B * 3 * GH);
   w.GI1 = c.take((size_t)2 * 9 * B * 3 * GH);
   w.Y1 = c.take((size_t)T * B * 2 * GH);
   w.GB = c.take((size_t)B * N_ADA * 128);
