@@ -102,6 +102,8 @@ def main():
 
     rank, local, world = sharding.init_from_env()
     assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if os.environ.get("PMCE_BENCH_SHARE_GPU"):   # plumbing test of the N>1 path on a 1-GPU box (with PMCE_DIST_BACKEND=gloo)
+        local = 0
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     B, J, C = args.batch, args.joints, args.embed_dim

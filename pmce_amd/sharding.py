@@ -29,8 +29,8 @@ def init_from_env(backend: str | None = None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:   # PMCE_DIST_BACKEND=gloo: plumbing tests of the N>1 path without N GPUs
+            backend = os.environ.get("PMCE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -42,8 +42,15 @@ def barrier():
         dist.barrier()
 
 
+def _comm_device(device):
+    """RCCL reduces device tensors in place; gloo (CPU tests / plumbing runs) gets host copies."""
+    if dist.is_initialized() and dist.get_backend() == "gloo":
+        return torch.device("cpu")
+    return device
+
+
 def reduce_max(value: float, device) -> float:
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_comm_device(torch.device(device)))
     if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -51,10 +58,10 @@ def reduce_max(value: float, device) -> float:
 
 def reduce_metric_sums(partial: torch.Tensor) -> torch.Tensor:
     """SUM-reduce a small vector of per-rank metric partials ([sum_err..., count]) over all ranks."""
-    t = partial.clone()
+    t = partial.detach().to(_comm_device(partial.device)).clone()
     if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t
+    return t.to(partial.device)
 
 
 def gather_rows(local: torch.Tensor) -> torch.Tensor:
@@ -63,6 +70,8 @@ def gather_rows(local: torch.Tensor) -> torch.Tensor:
     if not dist.is_initialized():
         return local
     world = dist.get_world_size()
+    out_device = local.device
+    local = local.detach().to(_comm_device(local.device))
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n)
@@ -72,4 +81,4 @@ def gather_rows(local: torch.Tensor) -> torch.Tensor:
     pad[: local.shape[0]] = local
     bufs = [torch.zeros_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0).to(out_device)
