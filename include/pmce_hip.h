@@ -77,6 +77,20 @@ int pmce_decoder_forward(pmce_model* m, const float* joints, const float* img_fe
 int pmce_forward(pmce_model* m, const float* pose2d, const float* img_feat, float* cam_mesh, float* cam_pose,
                  float* pose3d, float* pred_pose, int batch, void* ws, size_t ws_bytes, pmce_stream_t stream);
 
+/* Streaming (stride-1 windows of ONE long sequence, lib/_img_utils.py:27-57): the window-independent per-frame work
+ * (embedding + SpatialBlocks[0] + norm_s of the lifter, PoseEstimation.py:78-85; GRU layer-0 input projections) is done
+ * once per frame into x0[L,J,C] and gi0[L,6144]; pmce_stream_forward then serves W windows (int32 win[W,2], inclusive
+ * [start,end], start == end repeats the frame) from those tables.  Results equal pmce_forward on the assembled windows.
+ * Workspace: pmce_model_workspace_bytes(m, ceil(L/16)) for the precompute, (m, W) for the forward. */
+int pmce_stream_precompute(pmce_model* m, const float* pose2d_frames, const float* feat_frames, int L, float* x0, float* gi0,
+                           void* ws, size_t ws_bytes, pmce_stream_t stream);
+int pmce_stream_forward(pmce_model* m, const float* x0, const float* gi0, const int* win, int W, int L, float* cam_mesh,
+                        float* cam_pose, float* pose3d, float* pred_pose, void* ws, size_t ws_bytes, pmce_stream_t stream);
+/* building blocks of the above */
+int pmce_window_tokens_f32(const float* x0, const int* win, const float* tpos, const float* w2, const float* b2, float eps2,
+                           float* X, float* XN, int W, int L, int T, int J, int C, pmce_stream_t stream);
+int pmce_window_rows_f32(const float* src, const int* win, float* dst, int W, int L, int T, int ncols, pmce_stream_t stream);
+
 /* enable != 0 (default): pmce_forward / pmce_decoder_forward run the image-feature branch (GRU, AdaLN parameters) and the
  * short joint-side kernels on a second, internally created HIP stream, forked from and joined back into the caller's
  * stream with events (hipGraph-capturable; results are identical).  0 keeps every launch on the caller's stream. */

@@ -30,6 +30,10 @@ PROTOTYPES = {
     "pmce_lifter_forward": [C.c_void_p, _f, _f, _f, _i, _f, C.c_size_t, _s],
     "pmce_decoder_forward": [C.c_void_p, _f, _f, _f, _f, _i, _f, C.c_size_t, _s],
     "pmce_forward": [C.c_void_p, _f, _f, _f, _f, _f, _f, _i, _f, C.c_size_t, _s],
+    "pmce_stream_precompute": [C.c_void_p, _f, _f, _i, _f, _f, _f, C.c_size_t, _s],
+    "pmce_stream_forward": [C.c_void_p, _f, _f, _f, _i, _i, _f, _f, _f, _f, _f, C.c_size_t, _s],
+    "pmce_window_tokens_f32": [_f, _f, _f, _f, _f, _fl, _f, _f, _i, _i, _i, _i, _i, _s],
+    "pmce_window_rows_f32": [_f, _f, _f, _i, _i, _i, _i, _s],
     "pmce_model_set_concurrency": [C.c_void_p, _i],
     "pmce_model_profile": [C.c_void_p, _i],
     "pmce_model_profile_read": [C.c_void_p, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_longlong)],

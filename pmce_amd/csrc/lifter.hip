@@ -67,20 +67,32 @@ __device__ __forceinline__ void ln_regs(float* v, const float* __restrict__ w, c
   }
 }
 
+// Optional window gather (streaming): with win != nullptr, output row (w*T + t)*J + j reads input row
+// frame(w,t)*J + j, frame = win[2w] + t (or win[2w] when win[2w] == win[2w+1]: a single frame repeated).
 template <int C>
 __global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__ x, long long rows,
                                                        const float* __restrict__ w1, const float* __restrict__ b1,
                                                        float eps1, const float* __restrict__ add, int add_div, int add_mod,
                                                        float* __restrict__ out1, const float* __restrict__ w2,
-                                                       const float* __restrict__ b2, float eps2, float* __restrict__ out2) {
+                                                       const float* __restrict__ b2, float eps2, float* __restrict__ out2,
+                                                       const int* __restrict__ win, int nframes) {
   constexpr int NV = C / 64;
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  long long src = row;
+  if (win) {  // add_div = J, add_mod = T in this mode
+    const long long wt = row / add_div;
+    const int j = (int)(row % add_div), t = (int)(wt % add_mod);
+    const long long w = wt / add_mod;
+    const int s0 = win[2 * w], e0 = win[2 * w + 1];
+    const int fr = min(max(s0 == e0 ? s0 : s0 + t, 0), nframes - 1);
+    src = (long long)fr * add_div + j;
+  }
   float v[NV];
 #pragma unroll
   for (int i4 = 0; i4 < NV / 4; ++i4) {
-    const f32x4 t = *reinterpret_cast<const f32x4*>(x + row * C + i4 * 256 + lane * 4);
+    const f32x4 t = *reinterpret_cast<const f32x4*>(x + src * C + i4 * 256 + lane * 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i4 * 4 + i] = t[i];
   }
@@ -269,11 +281,48 @@ extern "C" int pmce_ln_chain_f32(const float* x, long long rows, int C, const fl
   const unsigned grid = (unsigned)((rows + 3) / 4);
   if (C == 256)
     hipLaunchKernelGGL((ln_chain_kernel<256>), dim3(grid), dim3(256), 0, stream, x, rows, w1, b1, eps1, add, add_div, add_mod,
-                       out1, w2, b2, eps2, out2);
+                       out1, w2, b2, eps2, out2, nullptr, 0);
   else
     hipLaunchKernelGGL((ln_chain_kernel<512>), dim3(grid), dim3(256), 0, stream, x, rows, w1, b1, eps1, add, add_div, add_mod,
-                       out1, w2, b2, eps2, out2);
+                       out1, w2, b2, eps2, out2, nullptr, 0);
   return pmce_check_launch("ln_chain");
+}
+
+// Streaming: tokens of W windows from the per-frame table x0[L,J,C] (= norm_s(SpatialBlocks[0](embed)), window-independent):
+//   X[w,t,j,:] = x0[frame(w,t),j,:] + tpos[t,:]  (PoseEstimation.py:87-88) ;  XN = LN(X; w2,b2,eps2)  (TemporalBlocks[0].norm1)
+extern "C" int pmce_window_tokens_f32(const float* x0, const int* win, const float* tpos, const float* w2, const float* b2,
+                                      float eps2, float* X, float* XN, int W, int L, int T, int J, int C,
+                                      hipStream_t stream) {
+  PMCE_REQUIRE(C == 256 || C == 512, "window_tokens: C must be 256 or 512");
+  PMCE_REQUIRE(x0 && win && tpos && w2 && b2 && X && XN && W > 0 && L > 0 && T > 0 && J > 0, "window_tokens: bad args");
+  const long long rows = (long long)W * T * J;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  if (C == 256)
+    hipLaunchKernelGGL((ln_chain_kernel<256>), dim3(grid), dim3(256), 0, stream, x0, rows, nullptr, nullptr, 0.f, tpos, J, T, X,
+                       w2, b2, eps2, XN, win, L);
+  else
+    hipLaunchKernelGGL((ln_chain_kernel<512>), dim3(grid), dim3(256), 0, stream, x0, rows, nullptr, nullptr, 0.f, tpos, J, T, X,
+                       w2, b2, eps2, XN, win, L);
+  return pmce_check_launch("window_tokens");
+}
+
+// Streaming: time-major gather of per-frame rows:  dst[t][w][:] = src[frame(w,t)][:]   (ncols % 4 == 0)
+__global__ __launch_bounds__(256) void window_rows_kernel(const float* __restrict__ src, const int* __restrict__ win,
+                                                          float* __restrict__ dst, int W, int L, int T, int ncols) {
+  const int tw = blockIdx.x;  // t * W + w
+  const int t = tw / W, w = tw % W;
+  const int s0 = win[2 * w], e0 = win[2 * w + 1];
+  const int fr = min(max(s0 == e0 ? s0 : s0 + t, 0), L - 1);
+  const f32x4* s = reinterpret_cast<const f32x4*>(src + (long long)fr * ncols);
+  f32x4* d = reinterpret_cast<f32x4*>(dst + (long long)tw * ncols);
+  for (int i = threadIdx.x; i < ncols / 4; i += 256) d[i] = s[i];
+}
+
+extern "C" int pmce_window_rows_f32(const float* src, const int* win, float* dst, int W, int L, int T, int ncols,
+                                    hipStream_t stream) {
+  PMCE_REQUIRE(src && win && dst && W > 0 && L > 0 && T > 0 && ncols > 0 && ncols % 4 == 0, "window_rows: bad args");
+  hipLaunchKernelGGL(window_rows_kernel, dim3(T * W), dim3(256), 0, stream, src, win, dst, W, L, T, ncols);
+  return pmce_check_launch("window_rows");
 }
 
 extern "C" int pmce_seq_attention_f32(const float* qkv, float* out, int nseq, int N, int C, int seq_div, long long seq_lo,

@@ -194,55 +194,87 @@ int gemm(const float* A, const float* W, const float* bias, const float* R, floa
 }
 
 // ---- GraphormerNet.forward --------------------------------------------------------------------------------
-int lifter_impl(pmce_model* m, const float* pose2d, const float* img_feat, float* pose3d, int B, LifterWs& w,
-                hipStream_t stream) {
+// Everything up to and including SpatialBlocks[0] is PER FRAME (its attention runs over the J joints of one frame,
+// PoseEstimation.py:78-85), so it is written over `nframes` frames: B*16 for independent clips, L for a streamed sequence.
+
+// attention + MLP of one block (pre-norm input in w.XN, residual stream in w.X); kind 0 spatial, 1 temporal
+int lifter_block_body(pmce_model* m, int kind, int i, long long M, int nframes, int B, LifterWs& w, hipStream_t stream) {
   const int J = m->J, C = m->C;
-  const long long M = (long long)B * T * J;
-  PMCE_REQUIRE(M < (1ll << 31), "lifter: batch too large");
+  const char* kn = kind == 0 ? "Spatial" : "Temporal";
+  RUN(P_GEMM_LIFTER, gemm(w.XN, m->f(blk(kn, i, "attn.qkv.weight")), m->f(blk(kn, i, "attn.qkv.bias")), nullptr, w.QKV,
+                          (int)M, 3 * C, C, C, 3 * C, 0, stream));
+  if (kind == 0)  // sequences = frames, tokens j contiguous                        (PoseEstimation.py:78,101)
+    RUN(P_SEQ_ATTN, pmce_seq_attention_f32(w.QKV, w.AO, nframes, J, C, 0, J, 0, 1, stream));
+  else  // sequences = (b,j), tokens t at stride J                                  (PoseEstimation.py:87,104)
+    RUN(P_SEQ_ATTN, pmce_seq_attention_f32(w.QKV, w.AO, B * J, T, C, J, 1, (long long)T * J, J, stream));
+  RUN(P_GEMM_LIFTER, gemm(w.AO, m->f(blk(kn, i, "attn.proj.weight")), m->f(blk(kn, i, "attn.proj.bias")), w.X, w.X, (int)M, C,
+                          C, C, C, 0, stream));
+  RUN(P_LN, pmce_ln_chain_f32(w.X, M, C, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, m->f(blk(kn, i, "norm2.weight")),
+                              m->f(blk(kn, i, "norm2.bias")), 1e-6f, w.XN, stream));
+  float* Hid = w.QKV;
+  RUN(P_GEMM_LIFTER, gemm(w.XN, m->f(blk(kn, i, "mlp.fc1.weight")), m->f(blk(kn, i, "mlp.fc1.bias")), nullptr, Hid, (int)M,
+                          2 * C, C, C, 2 * C, 1, stream));
+  RUN(P_GEMM_LIFTER, gemm(Hid, m->f(blk(kn, i, "mlp.fc2.weight")), m->f(blk(kn, i, "mlp.fc2.bias")), w.X, w.X, (int)M, C,
+                          2 * C, 2 * C, C, 0, stream));
+  return PMCE_OK;
+}
+
+// embedding + SpatialBlocks[0] over `nframes` frames; leaves the block output (before norm_s) in w.X
+int lifter_frames(pmce_model* m, const float* pose2d, const float* img_feat, int nframes, LifterWs& w, hipStream_t stream) {
+  const int J = m->J, C = m->C;
+  const long long M = (long long)nframes * J;
+  PMCE_REQUIRE(M < (1ll << 31), "lifter: too many tokens");
   RUN(P_GEMM_LIFTER, gemm(img_feat, m->f("lifter.imgfeat_embed.weight"), m->f("lifter.imgfeat_embed.bias"), nullptr, w.E,
-                          B * T, C, F, F, C, 0, stream));
+                          nframes, C, F, F, C, 0, stream));
   RUN(P_EMBED, pmce_embed_tokens_f32(pose2d, w.E, m->f("lifter.joint_embed.weight"), m->f("lifter.joint_embed.bias"),
                                      m->f("lifter.spatial_pos_embed"), w.X, M, J, C, stream));
   RUN(P_LN, pmce_ln_chain_f32(w.X, M, C, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr,
                               m->f(blk("Spatial", 0, "norm1.weight")), m->f(blk("Spatial", 0, "norm1.bias")), 1e-6f, w.XN,
                               stream));
+  return lifter_block_body(m, 0, 0, M, nframes, 0, w, stream);
+}
+
+// post-norm of block (kind, i): norm_s / norm_t (shared across depth, eps 1e-6), + temporal_pos_embed after the first
+// spatial block, fused with the NEXT block's norm1
+int lifter_post_norm(pmce_model* m, int kind, int i, long long M, LifterWs& w, hipStream_t stream) {
+  const int J = m->J, C = m->C;
+  const float* nw = m->f(kind == 0 ? "lifter.norm_s.weight" : "lifter.norm_t.weight");
+  const float* nb = m->f(kind == 0 ? "lifter.norm_s.bias" : "lifter.norm_t.bias");
+  const float* add = (kind == 0 && i == 0) ? m->f("lifter.temporal_pos_embed") : nullptr;
+  const float *w2 = nullptr, *b2 = nullptr;
+  if (kind == 0) {
+    w2 = m->f(blk("Temporal", i, "norm1.weight"));
+    b2 = m->f(blk("Temporal", i, "norm1.bias"));
+  } else if (i + 1 < m->depth) {
+    w2 = m->f(blk("Spatial", i + 1, "norm1.weight"));
+    b2 = m->f(blk("Spatial", i + 1, "norm1.bias"));
+  }
+  RUN(P_LN, pmce_ln_chain_f32(w.X, M, C, nw, nb, 1e-6f, add, J, T, w.X, w2, b2, 1e-6f, w2 ? w.XN : nullptr, stream));
+  return PMCE_OK;
+}
+
+// everything from TemporalBlocks[0] on, for B clips whose tokens (after norm_s + temporal_pos_embed) are in w.X and whose
+// TemporalBlocks[0].norm1 output is in w.XN
+int lifter_rest(pmce_model* m, float* pose3d, int B, LifterWs& w, hipStream_t stream) {
+  const int J = m->J, C = m->C;
+  const long long M = (long long)B * T * J;
   for (int i = 0; i < m->depth; ++i) {
-    for (int kind = 0; kind < 2; ++kind) {
-      const char* kn = kind == 0 ? "Spatial" : "Temporal";
-      RUN(P_GEMM_LIFTER, gemm(w.XN, m->f(blk(kn, i, "attn.qkv.weight")), m->f(blk(kn, i, "attn.qkv.bias")), nullptr, w.QKV,
-                              (int)M, 3 * C, C, C, 3 * C, 0, stream));
-      if (kind == 0)  // sequences = (b,t), tokens j contiguous                     (PoseEstimation.py:78,101)
-        RUN(P_SEQ_ATTN, pmce_seq_attention_f32(w.QKV, w.AO, B * T, J, C, 0, J, 0, 1, stream));
-      else  // sequences = (b,j), tokens t at stride J                              (PoseEstimation.py:87,104)
-        RUN(P_SEQ_ATTN, pmce_seq_attention_f32(w.QKV, w.AO, B * J, T, C, J, 1, (long long)T * J, J, stream));
-      RUN(P_GEMM_LIFTER, gemm(w.AO, m->f(blk(kn, i, "attn.proj.weight")), m->f(blk(kn, i, "attn.proj.bias")), w.X, w.X,
-                              (int)M, C, C, C, C, 0, stream));
-      RUN(P_LN, pmce_ln_chain_f32(w.X, M, C, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, m->f(blk(kn, i, "norm2.weight")),
-                                  m->f(blk(kn, i, "norm2.bias")), 1e-6f, w.XN, stream));
-      float* Hid = w.QKV;
-      RUN(P_GEMM_LIFTER, gemm(w.XN, m->f(blk(kn, i, "mlp.fc1.weight")), m->f(blk(kn, i, "mlp.fc1.bias")), nullptr, Hid,
-                              (int)M, 2 * C, C, C, 2 * C, 1, stream));
-      RUN(P_GEMM_LIFTER, gemm(Hid, m->f(blk(kn, i, "mlp.fc2.weight")), m->f(blk(kn, i, "mlp.fc2.bias")), w.X, w.X, (int)M,
-                              C, 2 * C, 2 * C, C, 0, stream));
-      // norm_s / norm_t (shared across depth, eps 1e-6), + temporal_pos_embed once, fused with the next norm1
-      const float* nw = m->f(kind == 0 ? "lifter.norm_s.weight" : "lifter.norm_t.weight");
-      const float* nb = m->f(kind == 0 ? "lifter.norm_s.bias" : "lifter.norm_t.bias");
-      const float* add = (kind == 0 && i == 0) ? m->f("lifter.temporal_pos_embed") : nullptr;
-      const float *w2 = nullptr, *b2 = nullptr;
-      if (kind == 0) {
-        w2 = m->f(blk("Temporal", i, "norm1.weight"));
-        b2 = m->f(blk("Temporal", i, "norm1.bias"));
-      } else if (i + 1 < m->depth) {
-        w2 = m->f(blk("Spatial", i + 1, "norm1.weight"));
-        b2 = m->f(blk("Spatial", i + 1, "norm1.bias"));
-      }
-      RUN(P_LN, pmce_ln_chain_f32(w.X, M, C, nw, nb, 1e-6f, add, J, T, w.X, w2, b2, 1e-6f, w2 ? w.XN : nullptr, stream));
+    for (int kind = (i == 0 ? 1 : 0); kind < 2; ++kind) {
+      PMCE_TRY(lifter_block_body(m, kind, i, M, B * T, B, w, stream));
+      PMCE_TRY(lifter_post_norm(m, kind, i, M, w, stream));
     }
   }
   RUN(P_HEAD, pmce_lifter_head_f32(w.X, m->f("lifter.regression.0.weight"), m->f("lifter.regression.0.bias"),
                                    m->f("lifter.regression.1.weight"), m->f("lifter.regression.1.bias"),
                                    m->f("lifter.fusion.weight"), m->f("lifter.fusion.bias"), pose3d, B, T, J, C, stream));
   return PMCE_OK;
+}
+
+int lifter_impl(pmce_model* m, const float* pose2d, const float* img_feat, float* pose3d, int B, LifterWs& w,
+                hipStream_t stream) {
+  PMCE_TRY(lifter_frames(m, pose2d, img_feat, B * T, w, stream));
+  PMCE_TRY(lifter_post_norm(m, 0, 0, (long long)B * T * m->J, w, stream));
+  return lifter_rest(m, pose3d, B, w, stream);
 }
 
 // ---- Pose2Mesh.forward ------------------------------------------------------------------------------------
@@ -279,12 +311,19 @@ int gru_layer(pmce_model* m, int layer, const float* gi_f, const float* gi_b, lo
 
 // image-feature branch of Pose2Mesh.forward: bi-GRU + AdaLN parameters.  Depends only on img_feat, so pmce_forward
 // runs it on a second stream concurrently with the pose lifter.
+// recurrences + AdaLN parameters, given the layer-0 input projections GI0 (time-major [t][b][6144])
+int gru_rest(pmce_model* m, int B, DecoderWs& w, hipStream_t stream);
+
 int gru_part(pmce_model* m, const float* img_feat, int B, DecoderWs& w, hipStream_t stream) {
   // ---- bi-GRU over the 16 frames (CoevoDecoder.py:228); buffers are time-major [t][b][.] ----
   // layer 0 input projections for both directions in one product: rows (b,t) of img_feat -> rows (t,b) of GI0
   RUN(P_GEMM_GRU_IN, pmce_gemm_nt_f32(img_feat, m->f("dec.gru.w_ih_l0"), m->f("dec.gru.b_ih_l0"), nullptr, w.GI0, B * T,
                                       6 * GH, F, F, F, 6 * GH, 0, 0, 0, 0, T, (long long)B * 6 * GH, 6 * GH, 1, 0, 0, 0, 0,
                                       stream));
+  return gru_rest(m, B, w, stream);
+}
+
+int gru_rest(pmce_model* m, int B, DecoderWs& w, hipStream_t stream) {
   // layer 0: both directions over all 16 steps.  gi slabs: fwd reads column block 0, bwd column block 1 of GI0.
   PMCE_TRY(gru_layer(m, 0, w.GI0, w.GI0 + 3 * GH, 6 * GH, 0, T - 1, T, T, w.Y0, B, stream));
   // layer 1: only y[8] is consumed (CoevoDecoder.py:229,241-243) -> fwd needs t = 0..8, bwd t = 15..8.
@@ -608,6 +647,70 @@ int pmce_forward(pmce_model* m, const float* pose2d, const float* img_feat, floa
                  "forward: pred_pose requested but no J_regressor registered (jreg.indptr/indices/data + rows)");
     RUN(P_JREG, pmce_j_regress_f32(cam_mesh, m->jr_indptr, m->jr_indices, m->jr_data, pred_pose, batch, m->jr_rows, NVF,
                                    1000.0f, stream));
+  }
+  return PMCE_OK;
+}
+
+// ---- streaming (stride-1 windows over one long sequence) -------------------------------------------
+int pmce_window_tokens_f32(const float* x0, const int* win, const float* tpos, const float* w2, const float* b2, float eps2,
+                           float* X, float* XN, int W, int L, int T, int J, int C, hipStream_t stream);
+int pmce_window_rows_f32(const float* src, const int* win, float* dst, int W, int L, int T, int ncols, hipStream_t stream);
+
+int pmce_stream_precompute(pmce_model* m, const float* pose2d_frames, const float* feat_frames, int L, float* x0, float* gi0,
+                           void* ws, size_t ws_bytes, pmce_stream_t stream) {
+  PMCE_REQUIRE(L > 0, "stream_precompute: L must be positive");
+  const int bf = (L + T - 1) / T;  // the per-frame pass needs the workspace of ceil(L/16) clips
+  PMCE_TRY(check_ws(m, bf, ws, ws_bytes));
+  PMCE_REQUIRE(m->has_lifter && m->has_decoder, "stream_precompute: needs both lifter and decoder tensors");
+  PMCE_REQUIRE(pose2d_frames && feat_frames && x0 && gi0, "stream_precompute: null pointer");
+  Carver c(ws, ws_bytes);
+  LifterWs lw;
+  carve_lifter(c, m, bf, lw);
+  // window-independent lifter work: embedding + SpatialBlocks[0] + norm_s, once per frame (PoseEstimation.py:78-85)
+  PMCE_TRY(lifter_frames(m, pose2d_frames, feat_frames, L, lw, stream));
+  RUN(P_LN, pmce_ln_chain_f32(lw.X, (long long)L * m->J, m->C, m->f("lifter.norm_s.weight"), m->f("lifter.norm_s.bias"), 1e-6f,
+                              nullptr, 1, 1, x0, nullptr, nullptr, 0.f, nullptr, stream));
+  // window-independent GRU work: layer-0 input projections of both directions, once per frame (CoevoDecoder.py:216-221)
+  RUN(P_GEMM_GRU_IN, gemm(feat_frames, m->f("dec.gru.w_ih_l0"), m->f("dec.gru.b_ih_l0"), nullptr, gi0, L, 6 * GH, F, F, 6 * GH,
+                          0, stream));
+  return PMCE_OK;
+}
+
+int pmce_stream_forward(pmce_model* m, const float* x0, const float* gi0, const int* win, int W, int L, float* cam_mesh,
+                        float* cam_pose, float* pose3d, float* pred_pose, void* ws, size_t ws_bytes, pmce_stream_t stream) {
+  PMCE_TRY(check_ws(m, W, ws, ws_bytes));
+  PMCE_REQUIRE(m->has_lifter && m->has_decoder, "stream_forward: needs both lifter and decoder tensors");
+  PMCE_REQUIRE(x0 && gi0 && win && cam_mesh && cam_pose && pose3d && L > 0, "stream_forward: null pointer");
+  Carver c(ws, ws_bytes);
+  LifterWs lw;
+  DecoderWs dw;
+  carve_lifter(c, m, W, lw);
+  carve_decoder(c, m, W, dw);
+  const bool single = !m->concurrent;
+  if (!single) PMCE_TRY(ensure_side(m));
+  hipStream_t gs = single ? stream : m->side;
+  if (!single) {
+    (void)hipEventRecord(m->ev_fork, stream);
+    (void)hipStreamWaitEvent(m->side, m->ev_fork, 0);
+  }
+  {
+    hipStream_t stream_save = stream;
+    stream = gs;  // RUN() launches on `stream`
+    RUN(P_MISC, pmce_window_rows_f32(gi0, win, dw.GI0, W, L, T, 6 * GH, stream));
+    stream = stream_save;
+  }
+  PMCE_TRY(gru_rest(m, W, dw, gs));
+  if (!single) (void)hipEventRecord(m->ev_join, m->side);
+  RUN(P_LN, pmce_window_tokens_f32(x0, win, m->f("lifter.temporal_pos_embed"), m->f(blk("Temporal", 0, "norm1.weight")),
+                                   m->f(blk("Temporal", 0, "norm1.bias")), 1e-6f, lw.X, lw.XN, W, L, T, m->J, m->C, stream));
+  PMCE_TRY(lifter_rest(m, pose3d, W, lw, stream));
+  RUN(P_MISC, pmce_div_scalar_f32(pose3d, dw.JM, (long long)W * m->J * 3, 1000.0f, stream));
+  if (!single) (void)hipStreamWaitEvent(stream, m->ev_join, 0);
+  PMCE_TRY(coevo_part(m, dw.JM, cam_pose, cam_mesh, W, dw, stream, single ? nullptr : m->side));
+  if (pred_pose) {
+    PMCE_REQUIRE(m->jr_indptr && m->jr_indices && m->jr_data && m->jr_rows > 0, "stream_forward: no J_regressor registered");
+    RUN(P_JREG, pmce_j_regress_f32(cam_mesh, m->jr_indptr, m->jr_indices, m->jr_data, pred_pose, W, m->jr_rows, NVF, 1000.0f,
+                                   stream));
   }
   return PMCE_OK;
 }

@@ -60,6 +60,56 @@ def assemble_windows(pose2d_frames: torch.Tensor, feat_frames: torch.Tensor, win
     return out_p, out_f
 
 
+class FrameCache:
+    """Per-frame tables of one sequence for the reuse path: x0[L,J,C] (lifter tokens after the window-independent first
+    spatial block) and gi0[L,6144] (GRU layer-0 input projections).  Built once by :func:`precompute_frames`."""
+
+    def __init__(self, x0, gi0, num_frames):
+        self.x0, self.gi0, self.L = x0, gi0, num_frames
+
+
+@torch.no_grad()
+def precompute_frames(model, pose2d_frames, feat_frames) -> FrameCache:
+    import ctypes as C
+    eng = model._ensure_packed()
+    p = pose2d_frames.to(torch.float32).contiguous()
+    f = feat_frames.to(torch.float32).contiguous()
+    L, J, _ = p.shape
+    dev = f.device
+    x0 = torch.empty(L, J, model.embed_dim, device=dev, dtype=torch.float32)
+    gi0 = torch.empty(L, 6144, device=dev, dtype=torch.float32)
+    ws = eng.workspace((L + SEQLEN - 1) // SEQLEN)
+    _lib.check(eng.lib.pmce_stream_precompute(eng.handle, _lib.ptr(p), _lib.ptr(f), L, _lib.ptr(x0), _lib.ptr(gi0),
+                                              C.c_void_p(ws.data_ptr()), ws.numel(), _lib.current_stream()), "stream_precompute")
+    return FrameCache(x0, gi0, L)
+
+
+@torch.no_grad()
+def stream_forward_cached(model, cache: FrameCache, windows=None, batch: int = 256, with_joints: bool = False):
+    """Same outputs as :func:`stream_forward`, but the per-frame work is taken from ``cache`` (about 21 % fewer FLOPs per
+    window: SpatialBlocks[0], imgfeat_embed and the GRU layer-0 input projection are not recomputed 16 times per frame)."""
+    import ctypes as C
+    from .config import NUM_VERTS_FULL
+    eng = model._ensure_packed()
+    windows = window_indices(cache.L) if windows is None else np.asarray(windows)
+    dev = cache.x0.device
+    J = model.num_joint
+    outs = []
+    for lo in range(0, len(windows), batch):
+        w = torch.as_tensor(np.asarray(windows[lo:lo + batch], dtype=np.int32), device=dev).contiguous()
+        W = w.shape[0]
+        mesh = torch.empty(W, NUM_VERTS_FULL, 3, device=dev, dtype=torch.float32)
+        pose = torch.empty(W, J, 3, device=dev, dtype=torch.float32)
+        pose3d = torch.empty(W, J, 3, device=dev, dtype=torch.float32)
+        pred = torch.empty(W, eng.regressor_rows, 3, device=dev, dtype=torch.float32) if with_joints else None
+        ws = eng.workspace(max(W, batch))
+        _lib.check(eng.lib.pmce_stream_forward(eng.handle, _lib.ptr(cache.x0), _lib.ptr(cache.gi0), _lib.ptr(w), W, cache.L,
+                                               _lib.ptr(mesh), _lib.ptr(pose), _lib.ptr(pose3d), _lib.ptr(pred),
+                                               C.c_void_p(ws.data_ptr()), ws.numel(), _lib.current_stream()), "stream_forward")
+        outs.append((mesh, pose, pose3d, pred) if with_joints else (mesh, pose, pose3d))
+    return tuple(torch.cat([o[i] for o in outs], 0) for i in range(len(outs[0]))) if outs else ()
+
+
 @torch.no_grad()
 def stream_forward(model, pose2d_frames, feat_frames, windows=None, batch: int = 256, with_joints: bool = False):
     """Run ``model`` over all windows of one sequence in batches of ``batch`` clips; returns the concatenated outputs

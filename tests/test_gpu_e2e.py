@@ -199,3 +199,31 @@ def test_odd_batch_sizes(B):
         sel = [i, 0, B - 1]
         m2, q2, l2 = model(p[sel], f[sel])
         assert maxabs(m2[0], mesh[i]) < 1e-5 and maxabs(q2[0], pose[i]) < 1e-5 and maxabs(l2[0], pose3d[i]) < 1e-2
+
+
+def test_streaming_frame_reuse_matches_window_forward():
+    """serving windows from per-frame tables (first spatial block + GRU layer-0 projections computed once
+    per frame) gives the same outputs as running every window as an independent clip."""
+    import time
+    from pmce_amd import streaming, synth
+    J = 17
+    model = get_model(J, 256)
+    L = 16 * 20
+    p_np, f_np = synth.make_inputs(20, J, 8)
+    pose_fr = T(p_np.reshape(-1, J, 2)[:L]).to(dev())
+    feat_fr = T(f_np.reshape(-1, 2048)[:L]).to(dev())
+    win = streaming.demo_window_list(L)                       # L windows incl. repeated-frame head/tail
+    ref = streaming.stream_forward(model, pose_fr, feat_fr, windows=win, batch=128, with_joints=True)
+    cache = streaming.precompute_frames(model, pose_fr, feat_fr)
+    out = streaming.stream_forward_cached(model, cache, windows=win, batch=128, with_joints=True)
+    e = [maxabs(a, b) for a, b in zip(out, ref)]
+    print("frame-reuse vs window forward: mesh %.2e pose %.2e pose3d %.2e mm pred %.2e mm" % tuple(e))
+    assert e[0] < 1e-5 and e[1] < 1e-5 and e[2] < 1e-2 and e[3] < 1e-2
+    for fn, name in ((lambda: streaming.stream_forward(model, pose_fr, feat_fr, windows=win, batch=320), "independent windows"),
+                     (lambda: streaming.stream_forward_cached(model, streaming.precompute_frames(model, pose_fr, feat_fr),
+                                                              windows=win, batch=320), "frame reuse")):
+        fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        print(f"   {name}: {5 * L / (time.perf_counter() - t0):.0f} windows/s")
