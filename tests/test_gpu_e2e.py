@@ -227,3 +227,27 @@ def test_streaming_frame_reuse_matches_window_forward():
             fn()
         torch.cuda.synchronize()
         print(f"   {name}: {5 * L / (time.perf_counter() - t0):.0f} windows/s")
+
+
+def test_forward_is_graph_capturable():
+    """The launch sequence (with its internal fork/join onto the side stream) has no host synchronisation or allocation:
+    it can be captured into a HIP graph and replayed, bit-identically."""
+    from pmce_amd import synth
+    J, B = 17, 8
+    model = get_model(J, 256)
+    pose2d, img_feat = synth.make_inputs(B, J, 55)
+    p, f = T(pose2d).to(dev()), T(img_feat).to(dev())
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            ref = model.forward_with_joints(p, f)          # warm-up outside capture: workspace, side stream, events
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        out = model.forward_with_joints(p, f)
+    for o in out:
+        o.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
