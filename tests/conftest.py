@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Make sure the in-tree HIP library exists and is current (hipcc cross-compiles without a GPU).  This builds the
+    product, it is not a fallback: if hipcc is missing the tests that need the library fail loudly."""
+    try:
+        from pmce_amd import build
+        build.build()
+    except Exception as e:  # noqa: BLE001
+        print(f"[conftest] could not build libpmce_hip.so: {e}")
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):
