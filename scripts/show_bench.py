@@ -1,5 +1,9 @@
-import sys, json
-for l in sys.stdin:
+"""Pretty-print bench.py JSON lines (from a file argument, or stdin when no argument is given)."""
+import json
+import sys
+
+src = open(sys.argv[1]) if len(sys.argv) > 1 else sys.stdin
+for l in src:
     if l.startswith("{"):
         d = json.loads(l)
         print(d["value"], "clips/s", d["ms_per_step"], "ms/step", d["roofline"])
