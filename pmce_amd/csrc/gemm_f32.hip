@@ -7,18 +7,20 @@
 // (CoevoDecoder.py:19-20), and the final 431->6890 upsample conv + 3 residual Linear(2048->6890) packed as one
 // [B,3360]x[3360,20670] product (CoevoDecoder.py:238-244).
 //
-// Design (DESIGN.md §GEMM):
+// Design (DESIGN.md §3.1):
 //  * v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD), 256 threads = 4 waves, block tile BMxBNx32, both
-//    operands K-contiguous so both tiles are staged with 128-byte-line global loads (8 lanes x 16 B per row),
-//    register-prefetched one k-tile ahead, double-buffered in LDS with a 36-float row stride (conflict-free
+//    operands K-contiguous.  Tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: 8 lanes x 16 B per 128-byte
+//    row, no VGPR round trip, no ds_write), one k-tile ahead into a double-buffered LDS whose rows are unpadded with
+//    their 16-byte chunks XOR-swizzled (swizzle on the DMA's source address and on the ds_read address: conflict-free
 //    ds_read_b128).  The k order inside each group of 8 is permuted (lanes 0-31 take k..k+3, lanes 32-63 take
 //    k+4..k+7) so that one ds_read_b128 per operand feeds four MFMAs.
 //  * PERSISTENT workgroups walk an XCD-local chunk of the tile order; the next tile's first k-tile is fetched
 //    under the current tile's last MFMAs (no exposed prologue).
-//  * TWO accumulator sets: the finished tile's epilogue (bias / GELU / residual / stores) is cut into 8 slices that
-//    ride inside the first 8 k-iterations of the NEXT tile, so stores, erf and residual loads issue in the shadow
-//    of the matrix pipe.  With K = 256 (8 k-iterations per tile) this is what lifts the lifter's Linear layers
-//    out of the regime where co-resident workgroups run their prologues and epilogues in lockstep.
+//  * TWO accumulator sets: the finished tile's epilogue (GELU / residual / stores) is cut into 8 slices that ride
+//    inside the first 8 k-iterations of the NEXT tile.  The bias is the accumulators' initial value; stores and
+//    residual loads are buffer instructions (descriptor on the wave tile, scalar element offset, one per-lane offset
+//    VGPR for the whole kernel), so a slice is one VMEM instruction (+ GELU) per element and no address arithmetic on
+//    the vector unit, which shares its FMA lanes with the fp32 matrix pipe.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -43,17 +45,31 @@ struct GemmParams {
   int grid_cap;                     // persistent workgroups per batch entry
 };
 
-template <int TN>
-struct PendingEpi {  // the finished-but-not-yet-stored tile
-  float* c;          // &C[row0][col0] of this lane's first element
+struct PendingEpi {  // the finished-but-not-yet-stored tile (all fields wave-uniform: they live in SGPRs)
+  float* c;          // &C[first row of the wave tile][first column of the wave tile]
   const float* r;    // same for the residual
-  float bv[TN];      // bias of this lane's column in each column tile
-  bool valid;        // wave-uniform
+  bool valid;
 };
+
+// LDS-DMA: one wave instruction moves 64 x 16 B from per-lane global addresses straight into LDS at
+// M0 + lane*16 (no VGPR round trip, no ds_write).  hipcc neither counts nor waits for it: the k-loop drains it
+// with an explicit s_waitcnt vmcnt(0) ahead of its barrier.  M0 is compiler-reserved, hence saved/restored inside
+// the statement.
+__device__ __forceinline__ void dma16(const float* gsrc, unsigned lds_wave_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_wave_base)
+      : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+}
 
 template <int BM, int BN, int WGM, int ACT, bool RES, bool CMAP>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
-  constexpr int LD = 36;
+  constexpr int LD = 32;  // unpadded rows (the DMA writes lane-linearly); 16-byte chunks XOR-swizzled instead
   constexpr int WGN = 4 / WGM;  // 4 waves arranged WGM x WGN
   constexpr int WM = BM / WGM, WN = BN / WGN;
   static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
@@ -64,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR: wave-tile origins stay scalar
   const int n0 = lane & 31, hb = lane >> 5;
   const int wm = wave % WGM, wn = wave / WGM;
 
@@ -95,7 +111,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
 
   // ---- per-thread global source pointers (fixed rows, advancing k).  Rows past the edge are CLAMPED to the
   // last valid row (their products are never stored), so the k-loop has no predicated loads or branches. ----
-  const int kc = (tid & 7) * 4, r0 = tid >> 3;
+  // DMA instruction i of a wave fills tile rows 32*i + 8*wave .. +7: lane L lands at row (L>>3), PHYSICAL chunk (L&7).
+  // Physical chunk p of tile row r holds logical chunk p ^ swz(r), swz(r) = (r>>1)&7 (the same involution on the
+  // ds_read side): 16 consecutive lanes of a ds_read_b128 (rows n..n+15, one logical chunk) hit 16 distinct
+  // 4-bank groups of the 64 banks.
+  const int r0 = tid >> 3;
+  const int kc = ((tid & 7) ^ ((r0 >> 1) & 7)) * 4;
   const float* aptr[LA];
   const float* bptr[LB];
   auto set_ptrs = [&](int mb, int nb) {
@@ -111,65 +132,108 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
     }
   };
 
-  f32x4 ra[LA], rb[LB];
-  auto gload = [&](int kt) {
+  const unsigned lds_a = __builtin_amdgcn_readfirstlane(lds_addr(&As[0][0]) + wave * (8 * LD * 4));
+  const unsigned lds_b = __builtin_amdgcn_readfirstlane(lds_addr(&Bs[0][0]) + wave * (8 * LD * 4));
+  auto gdma = [&](int kt, int buf) {  // k-tile kt of the pointed-at tile -> LDS buffer `buf`
     const int ko = kt * 32;
 #pragma unroll
-    for (int i = 0; i < LA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(aptr[i] + ko);
+    for (int i = 0; i < LA; ++i) dma16(aptr[i] + ko, lds_a + (buf * BM + 32 * i) * (LD * 4));
 #pragma unroll
-    for (int i = 0; i < LB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bptr[i] + ko);
+    for (int i = 0; i < LB; ++i) dma16(bptr[i] + ko, lds_b + (buf * BN + 32 * i) * (LD * 4));
   };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < LA; ++i) *reinterpret_cast<f32x4*>(&As[buf][(r0 + 32 * i) * LD + kc]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < LB; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][(r0 + 32 * i) * LD + kc]) = rb[i];
+  auto dma_wait_and_sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   };
 
   const int nk = p.K / 32;
-  const bool pipelined = !CMAP && nk >= 8;  // the sliced epilogue needs 8 k-iterations to ride in
+  // the sliced epilogue needs 8 k-iterations to ride in (and a wave tile inside its descriptor's 2 GiB window)
+  const bool pipelined = !CMAP && nk >= 8 && p.c_lo < (1ll << 21);
   int li = bx;
   if (li >= chunk_len) return;
   int m_base, n_base, m_next = 0, n_next = 0;
   tile_coords(chunk_start + li, m_base, n_base);
   set_ptrs(m_base, n_base);
-  gload(0);
-  lstore(0);
-  __syncthreads();
+  gdma(0, 0);
+  dma_wait_and_sync();
   int buf = 0;
   bool has_next = false;
 
   // Element e of a wave tile (e = slice*EPS + u): accumulator register r = e % 16 of sub-tile ij = e / 16
-  // (i = ij % TM, j = ij / TM); its offset from the lane's first element is (i*32 + (r&3) + 8*(r>>2))*ldc + j*32.
-#define EPI_OFF(e) ((((((e) / 16) % TM) * 32 + (((e) % 16) & 3) + 8 * (((e) % 16) >> 2)) * ldc) + (((e) / 16) / TM) * 32)
+  // (i = ij % TM, j = ij / TM).  Its address is  (wave-tile origin + ROW(e)*ldc + COL(e))  +  lane_off  with
+  // lane_off = 4*hb*ldc + n0: a buffer descriptor on the wave-tile origin, the element's scalar offset in soffset and ONE
+  // per-lane VGPR offset for the whole kernel (buffer_store_dword v, voff, s[rsrc], soff offen) - no address VALU at
+  // all.  VALU cycles are matrix cycles here (§3.1), and 64-bit pointer arithmetic per store was most of the
+  // epilogue's cost.
+#define EPI_ROW(e) ((((e) / 16) % TM) * 32 + (((e) % 16) & 3) + 8 * (((e) % 16) >> 2))
+#define EPI_COL(e) ((((e) / 16) / TM) * 32)
+#define EPI_OFF(e) (EPI_ROW(e) * ldc + EPI_COL(e))
+  // byte offset for the buffer forms.  `ldcb` is re-materialised (opaque to the optimiser) in every slice: otherwise all
+  // 16*TM*TN loop-invariant soffsets are hoisted out of the k-loop, overflow the SGPR file and come back through
+  // v_readlane + 5 wait states per store.  One s_mul per element on the otherwise idle scalar unit is free.
+#define EPI_BYTES(e, ldcb) (EPI_ROW(e) * (ldcb) + EPI_COL(e) * 4)
+  auto opaque_ldcb = [&]() {
+    int v = ldc * 4;
+    asm volatile("" : "+s"(v));
+    return v;
+  };
+  const unsigned lane_off = (unsigned)(4 * hb * ldc + n0) * 4u;  // bytes
+  constexpr int RSRC_FLAGS = 0x00020000;                          // raw dword buffer (gfx9 DATA_FORMAT = 32)
 
-  // one k-iteration into `cur`; if S >= 0 it also carries slice S of the pending tile's (`prv`) epilogue
-  auto iteration = [&](f32x16(&cur)[TM][TN], const f32x16(&prv)[TM][TN], PendingEpi<TN>& pend, int kt, auto slice_tag) {
+  // The bias is the accumulators' initial value (no add in the epilogue); the next tile's is fetched a tile ahead.
+  float bv_next[TN];
+  auto load_bias = [&](int nb) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = nb + wn * WN + j * 32 + n0;
+      bv_next[j] = (bias && n < p.N) ? bias[n] : 0.f;
+    }
+  };
+
+  // one k-iteration into `cur`; if S >= 0 it also carries slice S of the pending tile's (`prv`) epilogue.  Order:
+  // slice S (its residuals were loaded an iteration ago), DMA of the next k-tile, residual loads of slice S+1, MFMAs.
+  // Every vector-memory operation is thus issued ahead of the MFMAs and the vmcnt(0) in front of the barrier finds
+  // them long done; and no compiler-counted load is consumed while an (uncounted) DMA is younger than it.
+  float rv[EPS];  // residuals of the slice that runs in the next iteration
+  const int swz = (n0 >> 1) & 7;
+  auto iteration = [&](f32x16(&cur)[TM][TN], const f32x16(&prv)[TM][TN], PendingEpi& pend, int kt, auto slice_tag) {
     constexpr int S = decltype(slice_tag)::value;
     constexpr int SS = S < 0 ? 0 : S;
-    bool loaded = true;
+    if (S >= 0 && pend.valid) {
+      const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(pend.c, 0, 0x7fffffff, RSRC_FLAGS);
+      const int ldcb = opaque_ldcb();
+#pragma unroll
+      for (int u = 0; u < EPS; ++u) {
+        const int e = SS * EPS + u;
+        float v = prv[(e / 16) % TM][(e / 16) / TM][e % 16];
+        if (ACT == 1) v = gelu_erf(v);
+        if (RES) v += rv[u];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, lane_off, EPI_BYTES(e, ldcb), 0);
+      }
+    }
     if (kt + 1 < nk) {
-      gload(kt + 1);
+      gdma(kt + 1, buf ^ 1);
     } else if (has_next) {  // cross-tile prefetch: the next tile's first k-tile flies under this tile's last MFMAs
       set_ptrs(m_next, n_next);
-      gload(0);
-    } else {
-      loaded = false;
+      gdma(0, buf ^ 1);
     }
-    float rv[EPS];
-    if (S >= 0 && RES && pend.valid) {
+    if (S >= 0 && S < 7 && RES && pend.valid) {
+      const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pend.r), 0, 0x7fffffff, RSRC_FLAGS);
+      const int ldcb = opaque_ldcb();
 #pragma unroll
-      for (int u = 0; u < EPS; ++u) rv[u] = pend.r[EPI_OFF(SS * EPS + u)];
+      for (int u = 0; u < EPS; ++u)
+        rv[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, lane_off, EPI_BYTES((SS + 1) * EPS + u, ldcb), 0));
     }
-    const float* as = &As[buf][(wm * WM + n0) * LD + 4 * hb];
-    const float* bs = &Bs[buf][(wn * WN + n0) * LD + 4 * hb];
+    const float* as = &As[buf][(wm * WM + n0) * LD];
+    const float* bs = &Bs[buf][(wn * WN + n0) * LD];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+      const int co = 4 * ((2 * g + hb) ^ swz);  // physical position of logical chunk 2g+hb in this lane's rows
       f32x4 a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LD + 8 * g);
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LD + co);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LD + 8 * g);
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LD + co);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -178,29 +242,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
           for (int j = 0; j < TN; ++j)
             cur[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], cur[i][j], 0, 0, 0);
     }
-    if (S >= 0 && pend.valid) {
-#pragma unroll
-      for (int u = 0; u < EPS; ++u) {
-        const int e = SS * EPS + u;
-        float v = prv[(e / 16) % TM][(e / 16) / TM][e % 16] + pend.bv[(e / 16) / TM];
-        if (ACT == 1) v = gelu_erf(v);
-        if (RES) v += rv[u];
-        pend.c[EPI_OFF(e)] = v;
-      }
-    }
-    if (loaded) lstore(buf ^ 1);
-    __syncthreads();
+    dma_wait_and_sync();
     buf ^= 1;
   };
 
   // k-loop of one tile into `cur`, with the pending tile's epilogue slices riding in iterations 0..7
-  auto run_tile = [&](f32x16(&cur)[TM][TN], const f32x16(&prv)[TM][TN], PendingEpi<TN>& pend) {
+  auto run_tile = [&](f32x16(&cur)[TM][TN], const f32x16(&prv)[TM][TN], PendingEpi& pend) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cur[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) cur[i][j][r] = bv_next[j];
+    if (has_next) load_bias(n_next);
     if (pipelined) {  // nk >= 8: the first eight iterations are straight-line code, each with its own slice
       iteration(cur, prv, pend, 0, std::integral_constant<int, 0>{});
       iteration(cur, prv, pend, 1, std::integral_constant<int, 1>{});
@@ -224,7 +278,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
     for (int j = 0; j < TN; ++j) {
       const int n = nb + wn * WN + j * 32 + n0;
       const bool nok = n < p.N;
-      const float bv = (bias && nok) ? bias[n] : 0.f;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int mrow = mb + wm * WM + i * 32 + 4 * hb;
@@ -233,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
           for (int r = 0; r < 16; ++r) {
             const int m = mrow + (r & 3) + 8 * (r >> 2);
             if (nok && m < p.M)
-              C[(long long)(m % p.c_div) * p.c_lo + (long long)(m / p.c_div) * p.c_hi + n] = acc[i][j][r] + bv;
+              C[(long long)(m % p.c_div) * p.c_lo + (long long)(m / p.c_div) * p.c_hi + n] = acc[i][j][r];
           }
         } else {
           float* __restrict__ Cp = C + (long long)mrow * ldc + n;  // 32-bit offsets from here on
@@ -246,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              float v = acc[i][j][r] + bv;
+              float v = acc[i][j][r];
               if (ACT == 1) v = gelu_erf(v);
               if (RES) v += rv[r];
               Cp[((r & 3) + 8 * (r >> 2)) * ldc] = v;
@@ -256,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
             for (int r = 0; r < 16; ++r) {
               const int rr = (r & 3) + 8 * (r >> 2);
               if (nok && mrow + rr < p.M) {
-                float v = acc[i][j][r] + bv;
+                float v = acc[i][j][r];
                 if (ACT == 1) v = gelu_erf(v);
                 if (RES) v += Rp[rr * ldc];
                 Cp[rr * ldc] = v;
@@ -269,14 +322,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
   };
 
   // after a tile's k-loop: either park it as pending (interior tile with a successor) or store it now
-  auto finish_tile = [&](const f32x16(&acc)[TM][TN], PendingEpi<TN>& pend) {
+  auto finish_tile = [&](const f32x16(&acc)[TM][TN], PendingEpi& pend) {
     const bool full = (m_base + BM <= p.M) && (n_base + BN <= p.N);
     if (pipelined && full && has_next) {
-      const long long o = (long long)(m_base + wm * WM + 4 * hb) * ldc + n_base + wn * WN + n0;
+      const long long o = (long long)(m_base + wm * WM) * ldc + n_base + wn * WN;
       pend.c = C + o;
       pend.r = RES ? R + o : nullptr;
+      if (RES) {
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pend.r), 0, 0x7fffffff, RSRC_FLAGS);
+        const int ldcb = opaque_ldcb();
 #pragma unroll
-      for (int j = 0; j < TN; ++j) pend.bv[j] = bias ? bias[n_base + wn * WN + j * 32 + n0] : 0.f;
+        for (int u = 0; u < EPS; ++u) rv[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, lane_off, EPI_BYTES(u, ldcb), 0));
+      }
       pend.valid = true;
     } else {
       epilogue_now(acc, m_base, n_base);
@@ -285,12 +342,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
   };
 
   f32x16 acc0[TM][TN], acc1[TM][TN];
-  PendingEpi<TN> pend;
+  PendingEpi pend;
   pend.valid = false;
   pend.c = nullptr;
   pend.r = nullptr;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) pend.bv[j] = 0.f;
+  load_bias(n_base);
 
   while (true) {
     has_next = li + gx < chunk_len;
@@ -312,6 +368,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
     n_base = n_next;
   }
 #undef EPI_OFF
+#undef EPI_ROW
+#undef EPI_COL
+#undef EPI_BYTES
 }
 
 template <int BM, int BN, int WGM>
