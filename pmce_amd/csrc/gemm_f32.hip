@@ -51,16 +51,17 @@ struct PendingEpi {  // the finished-but-not-yet-stored tile (all fields wave-un
   bool valid;
 };
 
-// LDS-DMA: one wave instruction moves 64 x 16 B from per-lane global addresses straight into LDS at
-// M0 + lane*16 (no VGPR round trip, no ds_write).  hipcc neither counts nor waits for it: the k-loop drains it
-// with an explicit s_waitcnt vmcnt(0) ahead of its barrier.  M0 is compiler-reserved, hence saved/restored inside
-// the statement.
-__device__ __forceinline__ void dma16(const float* gsrc, unsigned lds_wave_base) {
+// LDS-DMA: one wave instruction moves 64 x 16 B from per-lane buffer offsets straight into LDS at M0 + lane*16 (no
+// VGPR round trip, no ds_write).  Buffer form: descriptor on the operand, a 32-bit per-lane byte offset that is fixed
+// for a whole tile, the k-tile's byte offset in soffset - the k-loop spends no vector instruction on addresses.
+// hipcc neither counts nor waits for it: the k-loop drains it with an explicit s_waitcnt vmcnt(0) ahead of its
+// barrier.  M0 is compiler-reserved, hence saved/restored inside the statement.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff, unsigned lds_wave_base) {
   unsigned keep;
   asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_wave_base)
+      : "v"(voff), "s"(rsrc), "s"(lds_wave_base), "s"(soff)
       : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr(const float* p) {
@@ -117,29 +118,30 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
   // 4-bank groups of the 64 banks.
   const int r0 = tid >> 3;
   const int kc = ((tid & 7) ^ ((r0 >> 1) & 7)) * 4;
-  const float* aptr[LA];
-  const float* bptr[LB];
+  unsigned aoff[LA], boff[LB];  // byte offsets from A / W (the launcher checks that both operands span < 4 GiB)
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 0xffffffff, 0x00020000);
   auto set_ptrs = [&](int mb, int nb) {
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
       const int r = min(mb + r0 + 32 * i, p.M - 1);
-      aptr[i] = A + (long long)(r % p.a_div) * p.a_lo + (long long)(r / p.a_div) * p.a_hi + kc;
+      aoff[i] = (unsigned)(((long long)(r % p.a_div) * p.a_lo + (long long)(r / p.a_div) * p.a_hi + kc) * 4);
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
       const int r = min(nb + r0 + 32 * i, p.N - 1);
-      bptr[i] = W + (long long)r * p.ldw + kc;
+      boff[i] = (unsigned)(((long long)r * p.ldw + kc) * 4);
     }
   };
 
   const unsigned lds_a = __builtin_amdgcn_readfirstlane(lds_addr(&As[0][0]) + wave * (8 * LD * 4));
   const unsigned lds_b = __builtin_amdgcn_readfirstlane(lds_addr(&Bs[0][0]) + wave * (8 * LD * 4));
   auto gdma = [&](int kt, int buf) {  // k-tile kt of the pointed-at tile -> LDS buffer `buf`
-    const int ko = kt * 32;
+    const int ko = kt * 128;  // bytes
 #pragma unroll
-    for (int i = 0; i < LA; ++i) dma16(aptr[i] + ko, lds_a + (buf * BM + 32 * i) * (LD * 4));
+    for (int i = 0; i < LA; ++i) dma16(rsrc_a, aoff[i], ko, lds_a + (buf * BM + 32 * i) * (LD * 4));
 #pragma unroll
-    for (int i = 0; i < LB; ++i) dma16(bptr[i] + ko, lds_b + (buf * BN + 32 * i) * (LD * 4));
+    for (int i = 0; i < LB; ++i) dma16(rsrc_w, boff[i], ko, lds_b + (buf * BN + 32 * i) * (LD * 4));
   };
   auto dma_wait_and_sync = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -391,11 +393,13 @@ static void launch_gemm(const GemmParams& p, int batch, bool cmap, hipStream_t s
   }
 }
 
-// Tile choice.  All tiles of a launch take the same time, so a launch runs in ceil(tiles / resident slots) rounds;
-// M = B*16*J is rarely a multiple of 128*256 (B=256, J=17: 544 row tiles = 2.125 x 256 CUs), so the tile shape is
-// picked to minimise rounds * (blocks per CU) * tile area.  Blocks per CU are bounded by LDS (2 x (BM+BN) x 144 B).
-struct TileCfg { int bm, bn, bpc; };
-static const TileCfg kTiles[] = {{128, 128, 2}, {96, 128, 2}, {64, 128, 2}, {64, 64, 4}};
+// Tile choice.  Persistent workgroups spread an XCD's chunk of tiles evenly over its 32 CUs whatever the number of
+// resident workgroups, and co-resident workgroups share one matrix pipe, so a launch takes as long as its busiest CU:
+// ceil(ceil(tiles / 8) / 32) tiles of BM x BN.  M = B*16*J is rarely a multiple of 128*256 (B=256, J=17: 544 row tiles
+// of 128), so the shape that quantises best wins; `ovh` is the measured per-area handicap of the smaller tiles at large
+// K (twice the operand traffic per FLOP for 64x64).  Blocks per CU (LDS: 2 x (BM+BN) x 128 B; VGPRs) only size the grid.
+struct TileCfg { int bm, bn, bpc; double ovh; };
+static const TileCfg kTiles[] = {{128, 128, 2, 1.0}, {96, 128, 2, 1.015}, {64, 128, 3, 1.03}, {64, 64, 4, 1.03}};
 static int pick_tile(int M, int N, int batch) {
   if (const char* e = getenv("PMCE_GEMM_TILE")) {  // tuning/debug knob: force a tile config (0..3)
     const int v = atoi(e);
@@ -406,11 +410,8 @@ static int pick_tile(int M, int N, int batch) {
   for (int i = 0; i < 4; ++i) {
     const TileCfg& t = kTiles[i];
     const long long tiles = (long long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn) * batch;
-    const long long slots = 256ll * t.bpc;
-    const long long rounds = (tiles + slots - 1) / slots;
-    // a partially filled single round only costs what its busiest CU runs
-    const long long per_cu = rounds > 1 ? rounds * t.bpc : (tiles + 255) / 256;
-    const double cost = (double)per_cu * t.bm * t.bn * (1.0 + 2048.0 / (t.bm * t.bn));  // mild bias to big tiles
+    const long long per_cu = ((tiles + 7) / 8 + 31) / 32;
+    const double cost = (double)per_cu * t.bm * t.bn * t.ovh;
     if (cost < best_cost) { best_cost = cost; best = i; }
   }
   return best;
@@ -434,6 +435,12 @@ extern "C" int pmce_gemm_nt_f32(const float* A, const float* W, const float* bia
   const bool cmap = c_div > 0;
   PMCE_REQUIRE(!cmap || (act == 0 && R == nullptr), "gemm: a C row map cannot be combined with act/residual");
   PMCE_REQUIRE(cmap || p.c_lo < (1ll << 26), "gemm: ldc too large");
+  {  // the LDS-DMA addresses operands with 32-bit byte offsets
+    const long long am = M - 1;
+    const long long a_span = (am < p.a_div ? am : (long long)p.a_div - 1) * p.a_lo + (am / p.a_div) * p.a_hi + K;  // upper bound
+    PMCE_REQUIRE(a_span * 4 < (1ll << 32) && (long long)N * ldw * 4 < (1ll << 32),
+                 "gemm: an operand spans 4 GiB or more per batch entry (split the batch)");
+  }
   p.act = act;
   p.bsA = bsA; p.bsW = bsW; p.bsBias = bsBias; p.bsC = bsC;
   const int ti = pick_tile(M, N, batch);

@@ -12,18 +12,20 @@ shapes = [  # name, M, N, K, act, res
     ("final", 256, 20670, 3360, 0, False), ("ada", 256, 3072, 2048, 0, False), ("imgfeat", 4096, 256, 2048, 0, False),
     ("qkv512", 69632, 1536, 512, 0, False), ("qkvJ19", 77824, 768, 256, 0, False),
 ]
-names = ["128x128", "96x128", "64x128", "64x64", "auto"]
+names = ["128x128", "96x128", "64x128", "64x64", "auto", "64x128/g3", "96x128/g3?", "64x64/g5"]
+cfgs = [(0, None), (1, None), (2, None), (3, None), (None, None), (2, 3), (1, 3), (3, 5)]
 only = sys.argv[1:] 
 for name, M, N, K, act, res in shapes:
     if only and name not in only: continue
     A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) * K ** -0.5; b = torch.randn(N, device=dev)
     R = torch.randn(M, N, device=dev) if res else None
     out = torch.empty(M, N, device=dev)
-    best = [1e9] * 5
+    best = [1e9] * len(cfgs)
     for rnd in range(4):
-        for t in range(5):
-            if t < 4: os.environ["PMCE_GEMM_TILE"] = str(t)
-            else: os.environ.pop("PMCE_GEMM_TILE", None)
+        for t, (tile, grid) in enumerate(cfgs):
+            os.environ.pop("PMCE_GEMM_TILE", None); os.environ.pop("PMCE_GEMM_GRID", None)
+            if tile is not None: os.environ["PMCE_GEMM_TILE"] = str(tile)
+            if grid is not None: os.environ["PMCE_GEMM_GRID"] = str(grid)
             ops.gemm_nt(A, W, b, R, act, out=out)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -32,5 +34,5 @@ for name, M, N, K, act, res in shapes:
             for _ in range(n): ops.gemm_nt(A, W, b, R, act, out=out)
             e1.record(); torch.cuda.synchronize()
             best[t] = min(best[t], e0.elapsed_time(e1) / n)
-    os.environ.pop("PMCE_GEMM_TILE", None)
-    print(f"{name:8s} M={M} N={N} K={K}: " + " | ".join(f"{names[t]} {best[t]*1e3:7.1f}us {2.0*M*N*K/best[t]/1e9:6.1f}TF" for t in range(5)), flush=True)
+    os.environ.pop("PMCE_GEMM_TILE", None); os.environ.pop("PMCE_GEMM_GRID", None)
+    print(f"{name:8s} M={M} N={N} K={K}: " + " | ".join(f"{names[t]} {best[t]*1e3:7.1f}us {2.0*M*N*K/best[t]/1e9:6.1f}TF" for t in range(len(cfgs))), flush=True)
