@@ -11,6 +11,13 @@
 // Block = 64 batch rows x 32 hidden units x {r,z,n}; 4 waves = 2 row blocks x 2 K-halves (K = 1024 split in two so
 // that B = 256 gives 4 x 32 x 2 = 256 blocks, one per CU, all four SIMDs busy); the K-halves meet in LDS and
 // the gate math runs on the accumulator layout (col = unit, row = batch), so gh never touches HBM.
+//
+// With ONE wave per SIMD nothing hides a workgroup barrier, so the K loop has none: every wave stages its own
+// operand slices (32 rows of h, 96 rows of W_hh, 32 k per stage) into a private two-stage LDS ring by LDS-DMA
+// (buffer_load_dwordx4 ... lds: no VGPR round trip, descriptor + fixed per-lane offsets + the k offset in soffset, so the
+// loop issues no vector ALU instruction at all) and only waits on its own vmcnt.  Rows are unpadded 128-byte lines with
+// XOR-swizzled 16-byte chunks (conflict-free ds_read_b128), the k order inside each 8 is permuted as in gemm_f32.hip.
+// The two row-block waves of a K-half fetch the same W_hh lines; the second hits in the CU's L1.
 // ------------------------------------------------------------------------------------------------------
 struct GruStepArgs {
   const float* gi[2];     // + row*gi_rs + gate*H + unit   (b_ih already added by the input-projection GEMM)
@@ -22,19 +29,32 @@ struct GruStepArgs {
   int B, H;
 };
 
-// NQ = number of K-slices (wave groups) per workgroup: 2 -> 4 waves, 4 -> 8 waves (two per SIMD, so one wave's LDS / barrier
-// latency hides under the other's MFMAs).
+__device__ __forceinline__ void gru_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff, unsigned lds_wave_base) {
+  unsigned keep;  // M0 is compiler-reserved: saved and restored inside the statement
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(lds_wave_base), "s"(soff)
+      : "memory");
+}
+
+// NQ = K-slices (wave groups) per workgroup: 2 -> 4 waves staging 32 k per stage, 4 -> 8 waves (two per SIMD: one wave's
+// LDS / DMA waits hide under the other's MFMAs) staging 16 k per stage.  Either way the rings fill 128 KB of LDS.
 template <int NQ>
 __global__ __launch_bounds__(128 * NQ) void gru_step_kernel(GruStepArgs a) {
-  constexpr int NT = 128 * NQ;        // threads
-  constexpr int KH = 64 / NQ;         // k per K-slice per iteration (row of 64 floats + 4 pad in LDS)
-  constexpr int LD = 68;              // conflict-free ds_read_b128 row stride
-  constexpr int RW = 16 / NQ;         // accumulator rows each wave finishes
-  constexpr int LA = 1024 / NT, LW = 1536 / NT;  // float4 loads per thread per iteration (A: 64x16, W: 96x16)
-  __shared__ __attribute__((aligned(16))) float smem[2 * (64 + 96) * LD];
+  constexpr int KS = 64 / NQ;              // k per stage
+  constexpr int ROWB = KS * 4;             // bytes per staged row
+  constexpr int LPR = KS / 4;              // lanes (16-byte chunks) per row
+  constexpr int RPI = 64 / LPR;            // rows per DMA instruction
+  constexpr int NA = 32 / RPI, NW = 96 / RPI;
+  constexpr int RW = 16 / NQ;              // accumulator rows each wave finishes
+  constexpr int STAGE = (32 + 96) * ROWB;  // bytes per stage per wave: 32 h rows + 96 W rows
+  // conflict-free ds_read_b128 on unpadded rows: chunk c of row r sits at c ^ swz(r)
+  auto swz_of = [](int r) { return KS == 32 ? (r >> 1) & 7 : (r >> 2) & 3; };
+  __shared__ __attribute__((aligned(16))) float smem[2 * NQ * 2 * STAGE / 4];  // 2*NQ waves x 2 stages = 128 KB
   const int d = blockIdx.z;
   const int u0 = blockIdx.x * 32, m0 = blockIdx.y * 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n0 = lane & 31, hb = lane >> 5;
   const int rb = wave & 1, kq = wave >> 1;
   const int H = a.H, Kq = H / NQ;
@@ -64,69 +84,65 @@ __global__ __launch_bounds__(128 * NQ) void gru_step_kernel(GruStepArgs a) {
     for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
 
   if (hp) {
-    // staging assignment per iteration: A 64 rows x 16 float4, W 96 rows x 16 float4; float4 c4 of a row belongs to
-    // K-slice c4 / (16/NQ)
-    constexpr int CPS = 16 / NQ;  // float4 per slice per row
-    const float* ap[LA];
-    const float* wp[LW];
+    // DMA instruction i moves rows RPI*i .. of the stage (rows 0-31: h, rows 32-127: W gate-major): lane L lands at
+    // row RPI*i + L/LPR, PHYSICAL chunk L%LPR, and fetches logical chunk (L%LPR) ^ swz(row).
+    const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hp), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 0xffffffff, 0x00020000);
+    unsigned hoff[NA], woff[NW];
 #pragma unroll
-    for (int i = 0; i < LA; ++i) {
-      const int idx = tid + NT * i, row = idx >> 4, c4 = idx & 15;
-      const int m = min(m0 + row, a.B - 1);
-      ap[i] = hp + (long long)m * a.h_rs + (c4 / CPS) * Kq + (c4 % CPS) * 4;
+    for (int i = 0; i < NA; ++i) {
+      const int row = RPI * i + lane / LPR;
+      const int c = (lane % LPR) ^ swz_of(row);
+      const int m = min(m0 + rb * 32 + row, a.B - 1);
+      hoff[i] = (unsigned)(((long long)m * a.h_rs + 4 * c) * 4);
     }
 #pragma unroll
-    for (int i = 0; i < LW; ++i) {
-      const int idx = tid + NT * i, row = idx >> 4, c4 = idx & 15;
-      const int gate = row >> 5, uu = row & 31;
-      wp[i] = W + (long long)(gate * H + u0 + uu) * H + (c4 / CPS) * Kq + (c4 % CPS) * 4;
+    for (int i = 0; i < NW; ++i) {
+      const int row = RPI * i + lane / LPR;  // gate = row >> 5, unit = row & 31
+      const int c = (lane % LPR) ^ swz_of(row);
+      woff[i] = (unsigned)(((long long)((row >> 5) * H + u0 + (row & 31)) * H + 4 * c) * 4);
     }
-    f32x4 ra[LA], rw[LW];
-    auto gload = [&](int kt) {
+    const unsigned lds_wave =
+        __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)smem) + wave * (2 * STAGE);
+    auto dma_stage = [&](int kt) {
+      const int soff = (kq * Kq + kt * KS) * 4;
+      const unsigned dst = lds_wave + (kt & 1) * STAGE;
 #pragma unroll
-      for (int i = 0; i < LA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * KH);
+      for (int i = 0; i < NA; ++i) gru_dma16(rsrc_h, hoff[i], soff, dst + i * 1024);
 #pragma unroll
-      for (int i = 0; i < LW; ++i) rw[i] = *reinterpret_cast<const f32x4*>(wp[i] + kt * KH);
+      for (int i = 0; i < NW; ++i) gru_dma16(rsrc_w, woff[i], soff, dst + 32 * ROWB + i * 1024);
     };
-    auto lstore = [&](int buf) {
-      float* As = smem + buf * (64 + 96) * LD;
-      float* Bs = As + 64 * LD;
-#pragma unroll
-      for (int i = 0; i < LA; ++i) {
-        const int idx = tid + NT * i;
-        *reinterpret_cast<f32x4*>(As + (idx >> 4) * LD + (idx & 15) * 4) = ra[i];
-      }
-#pragma unroll
-      for (int i = 0; i < LW; ++i) {
-        const int idx = tid + NT * i;
-        *reinterpret_cast<f32x4*>(Bs + (idx >> 4) * LD + (idx & 15) * 4) = rw[i];
-      }
-    };
-    const int nk = Kq / KH;
-    gload(0);
-    lstore(0);
-    __syncthreads();
+    const int nk = Kq / KS;
+    const float* my = smem + wave * (2 * STAGE / 4);
+    const int swz = swz_of(n0);  // the same for rows n0, 32+n0, 64+n0, 96+n0
+    dma_stage(0);
     for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < nk) gload(kt + 1);
-      const float* As = smem + buf * (64 + 96) * LD + (rb * 32 + n0) * LD + kq * KH + 4 * hb;
-      const float* Bs = smem + buf * (64 + 96) * LD + 64 * LD + n0 * LD + kq * KH + 4 * hb;
+      if (kt + 1 < nk) {
+        dma_stage(kt + 1);
+        // all but the NA+NW just issued: stage kt has landed
+        if (NQ == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      const float* As = my + (kt & 1) * (STAGE / 4) + n0 * KS;
+      const float* Bs = my + (kt & 1) * (STAGE / 4) + 32 * KS + n0 * KS;
 #pragma unroll
-      for (int g8 = 0; g8 < KH / 8; ++g8) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(As + 8 * g8);
+      for (int g8 = 0; g8 < KS / 8; ++g8) {
+        const int co = 4 * ((2 * g8 + hb) ^ swz);
+        const f32x4 av = *reinterpret_cast<const f32x4*>(As + co);
         f32x4 bv[3];
 #pragma unroll
-        for (int g = 0; g < 3; ++g) bv[g] = *reinterpret_cast<const f32x4*>(Bs + g * 32 * LD + 8 * g8);
+        for (int g = 0; g < 3; ++g) bv[g] = *reinterpret_cast<const f32x4*>(Bs + g * 32 * KS + co);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[g][s], acc[g], 0, 0, 0);
       }
-      if (kt + 1 < nk) lstore(buf ^ 1);
-      __syncthreads();
     }
+    __syncthreads();  // every wave is done with its private ring: the reduction below reuses the memory
     // meet the K-slices: every wave publishes the rows its partners finish, then sums the partners' copies of its own
-    float* red = smem;  // [dst kq][src slot][rb][gate][q][lane]  (the operand tiles are dead now)
+    float* red = smem;  // [dst kq][src slot][rb][gate][q][lane]
 #pragma unroll
     for (int dq = 0; dq < NQ; ++dq) {
       if (dq == kq) continue;
@@ -190,7 +206,8 @@ extern "C" int pmce_gru_step_f32(const float* gi0, const float* gi1, const float
   a.gi[0] = gi0; a.gi[1] = gi1; a.whh[0] = whh0; a.whh[1] = whh1; a.bhh[0] = bhh0; a.bhh[1] = bhh1;
   a.hprev[0] = hp0; a.hprev[1] = hp1; a.hout[0] = ho0; a.hout[1] = ho1;
   a.gi_rs = gi_rs; a.h_rs = h_rs; a.B = B; a.H = H;
-  static const int nq = getenv("PMCE_GRU_NQ") ? atoi(getenv("PMCE_GRU_NQ")) : 2;   // tuning knob: K-slices per workgroup (2 and 4 measure the same)
+  PMCE_REQUIRE((long long)B * h_rs * 4 < (1ll << 32) && 3ll * H * H * 4 < (1ll << 32), "gru_step: h or W_hh spans 4 GiB or more");
+  static const int nq = getenv("PMCE_GRU_NQ") ? atoi(getenv("PMCE_GRU_NQ")) : 4;  // tuning knob
   if (nq == 2)
     hipLaunchKernelGGL((gru_step_kernel<2>), dim3(H / 32, (B + 63) / 64, ndir), dim3(256), 0, stream, a);
   else
