@@ -335,7 +335,11 @@ __global__ __launch_bounds__(512) void adaln_mlp_kernel(const float* __restrict_
       tl_gemm<8, 1, LDW64>(sW1 + ht * 32 * LDW64, a, &acc1, n0, hb);
       float hreg[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hreg[r] = gelu_erf(acc1[r]);
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 g = gelu_erf2(f32x2{acc1[r], acc1[r + 1]});
+        hreg[r] = g.x;
+        hreg[r + 1] = g.y;
+      }
       tl_gemm<4, 2, LDW256>(sW2 + ht * 32, hreg, acc2, n0, hb);
     }
     if (yout && valid) {

@@ -205,12 +205,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
       const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(pend.c, 0, 0x7fffffff, RSRC_FLAGS);
       const int ldcb = opaque_ldcb();
 #pragma unroll
-      for (int u = 0; u < EPS; ++u) {
+      for (int u = 0; u < EPS; u += 2) {  // EPS is even; pairs share the packed GELU
         const int e = SS * EPS + u;
-        float v = prv[(e / 16) % TM][(e / 16) / TM][e % 16];
-        if (ACT == 1) v = gelu_erf(v);
-        if (RES) v += rv[u];
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, lane_off, EPI_BYTES(e, ldcb), 0);
+        f32x2 v = {prv[(e / 16) % TM][(e / 16) / TM][e % 16], prv[((e + 1) / 16) % TM][((e + 1) / 16) / TM][(e + 1) % 16]};
+        if (ACT == 1) v = gelu_erf2(v);
+        if (RES) v += f32x2{rv[u], rv[u + 1]};
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), rc, lane_off, EPI_BYTES(e, ldcb), 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), rc, lane_off, EPI_BYTES(e + 1, ldcb), 0);
       }
     }
     if (kt + 1 < nk) {
