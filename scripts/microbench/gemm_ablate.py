@@ -6,29 +6,26 @@ sys.path.insert(0, REPO)
 import torch
 src = open(os.path.join(REPO, "pmce_amd/csrc/gemm_f32.hip")).read()
 KEEP = 'asm volatile("" :: "v"(v));'
+STORE2 = """        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), rc, lane_off, EPI_BYTES(e, ldcb), 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), rc, lane_off, EPI_BYTES(e + 1, ldcb), 0);"""
 def variant(name):
     s = src
-    if name == "G":   # same number of store instructions, but into a small per-workgroup region (cache-resident): issue vs HBM
-        s = s.replace("pend.c = C + o;", "pend.c = C + (long long)blockIdx.x * 16384 + (o & 4095);")
-        s = s.replace("pend.c[EPI_OFF(e)] = v;", "pend.c[(EPI_OFF(e)) & 8191] = v;")
-        return s
     if name >= "B":   # no epilogue stores (values kept alive)
-        s = s.replace("pend.c[EPI_OFF(e)] = v;", KEEP)
+        assert STORE2 in s
+        s = s.replace(STORE2, '        asm volatile("" :: "v"(v.x), "v"(v.y));')
         s = s.replace("Cp[((r & 3) + 8 * (r >> 2)) * ldc] = v;", KEEP).replace("Cp[rr * ldc] = v;", KEEP)
-    if name >= "C":   # no global loads inside the k-loop (registers keep the prologue's tile)
-        s = s.replace("      gload(kt + 1);\n", "      ;\n").replace("      set_ptrs(m_next, n_next);\n      gload(0);\n", "      ;\n")
-    if name >= "D":   # no LDS writes
-        s = s.replace("    if (loaded) lstore(buf ^ 1);\n", "")
-    if name >= "E":   # no barrier in the k-loop
-        s = s.replace("    if (loaded) lstore(buf ^ 1);\n", "").replace("    __syncthreads();\n    buf ^= 1;\n", "    buf ^= 1;\n")
-    if name >= "F":   # no ds_reads either: operands are whatever is in registers
-        s = re.sub(r"for \(int i = 0; i < TM; \+\+i\) a\[i\] = \*reinterpret_cast<const f32x4\*>\(as \+ i \* 32 \* LD \+ 8 \* g\);",
-                   "for (int i = 0; i < TM; ++i) a[i] = f32x4{as[0], as[1], as[2], as[3]};", s)
-        s = re.sub(r"for \(int j = 0; j < TN; \+\+j\) b\[j\] = \*reinterpret_cast<const f32x4\*>\(bs \+ j \* 32 \* LD \+ 8 \* g\);",
-                   "for (int j = 0; j < TN; ++j) b[j] = f32x4{bs[0], bs[1], bs[2], bs[3]};", s)
+    if name >= "C":   # no DMA inside the k-loop (LDS keeps the prologue's tile)
+        s = s.replace("      gdma(kt + 1, buf ^ 1);\n", "      ;\n").replace("      set_ptrs(m_next, n_next);\n      gdma(0, buf ^ 1);\n", "      ;\n")
+    if name >= "D":   # no wait / barrier in the k-loop
+        s = s.replace("    dma_wait_and_sync();\n    buf ^= 1;\n", "    buf ^= 1;\n")
+    if name >= "E":   # no ds_reads either: operands are whatever is in registers
+        s = s.replace("for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LD + co);",
+                      "for (int i = 0; i < TM; ++i) a[i] = f32x4{as[0], as[1], as[2], as[3]};")
+        s = s.replace("for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LD + co);",
+                      "for (int j = 0; j < TN; ++j) b[j] = f32x4{bs[0], bs[1], bs[2], bs[3]};")
     return s
 libs = {}
-for v in "ABG":
+for v in "ABCDE":
     d = f"/tmp/gemm_abl_{v}"; os.makedirs(d, exist_ok=True)
     open(f"{d}/gemm_f32.hip", "w").write(variant(v))
     for f in ("common.hpp", "common.cpp"):
@@ -41,8 +38,8 @@ for v in "ABG":
     lib.pmce_gemm_nt_f32.argtypes = [vp] * 5 + [i, i, i, l, i, l, i, i, l, l, i, l, l, i, l, l, l, l, vp]
     libs[v] = lib
 dev = torch.device("cuda:0")
-desc = {"G": "stores to a cache-resident region", "A": "baseline", "B": "- epilogue stores", "C": "- global loads", "D": "- LDS writes", "E": "- barrier", "F": "- ds_reads (MFMA only)"}
-for name, M, N, K, act, res, tile in [("qkv 96x128", 69632, 768, 256, 0, False, 1), ("qkv 128x128", 69632, 768, 256, 0, False, 0), ("qkv 64x128", 69632, 768, 256, 0, False, 2), ("fc1 96x128", 69632, 512, 256, 1, False, 1)]:
+desc = {"G": "stores to a cache-resident region", "A": "baseline", "B": "- epilogue stores", "C": "- DMA", "D": "- wait+barrier", "E": "- ds_reads (MFMA only)"}
+for name, M, N, K, act, res, tile in [("qkv 96x128", 69632, 768, 256, 0, False, 1), ("qkv 128x128", 69632, 768, 256, 0, False, 0), ("proj 64x64", 69632, 256, 256, 0, True, 3), ("fc2 64x64", 69632, 256, 512, 0, True, 3), ("gi0 128x128", 4096, 6144, 2048, 0, False, 0)]:
     os.environ["PMCE_GEMM_TILE"] = str(tile)
     A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) * K ** -0.5; b = torch.randn(N, device=dev)
     R = torch.randn(M, N, device=dev) if res else None
