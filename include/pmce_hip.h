@@ -205,6 +205,13 @@ int pmce_accel_error_f32(const float* pe, const float* ge, const int* seq, float
 int pmce_assemble_windows_f32(const float* pose, const float* feat, const int* win, float* out_pose, float* out_feat, int W,
                               int L, int J, pmce_stream_t stream);
 
+/* Detector keypoints -> model input, per frame (data/PW3D/dataset.py:185-204 add_pelvis_and_neck /
+ * normalize_screen_coordinates, applied at :160-161 and :235-237): kp[L,J0,kp_stride] pixel coordinates (x, y first),
+ * shape int32[L,2] = (height, width) -> out[L,J0+n_extra,2]; n_extra = 1 appends the pelvis (hip midpoint), 2 also the
+ * neck (shoulder midpoint); x' = x/w*2 - 1, y' = y/w*2 - h/w. */
+int pmce_prepare_pose2d_f32(const float* kp, int kp_stride, const int* shape, float* out, int L, int J0, int n_extra, int lhip,
+                            int rhip, int lsho, int rsho, pmce_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

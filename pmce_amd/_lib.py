@@ -58,6 +58,7 @@ PROTOTYPES = {
     "pmce_sample_errors_f32": [_f, _f, _fl, _i, _f, _f, _f, _f, _i, _f, _f, _i, _i, _f, _f, _f, _f, _f, _i, _s],
     "pmce_accel_error_f32": [_f, _f, _f, _f, _i, _i, _s],
     "pmce_assemble_windows_f32": [_f, _f, _f, _f, _f, _i, _i, _i, _s],
+    "pmce_prepare_pose2d_f32": [_f, _i, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s],
 }
 _RESTYPES = {
     "pmce_last_error_string": C.c_char_p,

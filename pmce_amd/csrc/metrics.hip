@@ -260,3 +260,42 @@ extern "C" int pmce_assemble_windows_f32(const float* pose, const float* feat, c
   hipLaunchKernelGGL(assemble_windows_kernel, dim3(W * 16), dim3(256), 0, stream, pose, feat, win, out_pose, out_feat, W, L, J);
   return pmce_check_launch("assemble_windows");
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Detector output -> model input, per frame (data/PW3D/dataset.py:185-204,160-161,235-237): keep (x, y) of the J0 detected
+// keypoints, append pelvis = (L_Hip + R_Hip)/2 and (unless only_pelvis) neck = (L_Shoulder + R_Shoulder)/2, then
+// normalise to the screen: x' = x/w*2 - 1, y' = y/w*2 - h/w.  kp[L][J0][kp_stride] pixels, shape[L][2] = (height, width).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prepare_pose2d_kernel(const float* __restrict__ kp, int kp_stride,
+                                                             const int* __restrict__ shape, float* __restrict__ out, int L,
+                                                             int J0, int n_extra, int lhip, int rhip, int lsho, int rsho) {
+  const int J = J0 + n_extra;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= L * J) return;
+  const int f = idx / J, j = idx % J;
+  const float* k = kp + (long long)f * J0 * kp_stride;
+  float x, y;
+  if (j < J0) {
+    x = k[j * kp_stride];
+    y = k[j * kp_stride + 1];
+  } else {
+    const int a = (j == J0) ? lhip : lsho, b = (j == J0) ? rhip : rsho;
+    x = (k[a * kp_stride] + k[b * kp_stride]) * 0.5f;
+    y = (k[a * kp_stride + 1] + k[b * kp_stride + 1]) * 0.5f;
+  }
+  const float h = (float)shape[2 * f], w = (float)shape[2 * f + 1];
+  out[(long long)idx * 2] = x / w * 2.0f - 1.0f;
+  out[(long long)idx * 2 + 1] = y / w * 2.0f - h / w;
+}
+
+extern "C" int pmce_prepare_pose2d_f32(const float* kp, int kp_stride, const int* shape, float* out, int L, int J0, int n_extra,
+                                       int lhip, int rhip, int lsho, int rsho, hipStream_t stream) {
+  PMCE_REQUIRE(kp && shape && out && L > 0 && J0 > 0 && kp_stride >= 2, "prepare_pose2d: bad args");
+  PMCE_REQUIRE(n_extra >= 0 && n_extra <= 2, "prepare_pose2d: n_extra must be 0 (none), 1 (pelvis) or 2 (pelvis + neck)");
+  PMCE_REQUIRE(n_extra == 0 || (lhip >= 0 && lhip < J0 && rhip >= 0 && rhip < J0), "prepare_pose2d: hip index out of range");
+  PMCE_REQUIRE(n_extra < 2 || (lsho >= 0 && lsho < J0 && rsho >= 0 && rsho < J0), "prepare_pose2d: shoulder index out of range");
+  const long long n = (long long)L * (J0 + n_extra);
+  hipLaunchKernelGGL(prepare_pose2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, kp, kp_stride, shape, out, L,
+                     J0, n_extra, lhip, rhip, lsho, rsho);
+  return pmce_check_launch("prepare_pose2d");
+}

@@ -1,0 +1,67 @@
+"""GPU: prepare_pose2d kernel vs the oracle / the reference's golden outputs, and the pinned host->device feeder."""
+import os.path as osp
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = osp.dirname(osp.abspath(__file__))
+sys.path.insert(0, osp.dirname(HERE))
+sys.path.insert(0, osp.join(HERE, "golden"))
+from oracle import staging_oracle as so  # noqa: E402
+from pmce_amd import staging, streaming  # noqa: E402
+import make_golden_staging as mg  # noqa: E402  (input generators only)
+
+pytestmark = pytest.mark.gpu
+G = np.load(osp.join(HERE, "golden", "staging.npz"))
+DEV = "cuda:0"
+
+
+def test_prepare_pose2d_matches_reference_golden():
+    kp, shapes = mg.inputs()
+    out = staging.prepare_pose2d(torch.from_numpy(kp).to(DEV), torch.from_numpy(shapes).to(DEV)).cpu().numpy()
+    assert out.shape == (40, 19, 2) and out.dtype == np.float32
+    # fp32 on the device vs the reference's float64 intermediate: <= 1 ulp of values in [-1, 1.8]
+    np.testing.assert_allclose(out, G["norm"], rtol=0, atol=2.4e-7)
+
+
+def test_prepare_pose2d_variants_and_errors():
+    kp, shapes = mg.inputs()
+    k, s = torch.from_numpy(kp).to(DEV), torch.from_numpy(shapes).to(DEV)
+    o1 = staging.prepare_pose2d(k, s, extra=1).cpu().numpy()
+    want1 = np.stack([so.normalize_screen_coordinates(so.add_pelvis_and_neck(kp[i], only_pelvis=True)[:, :2], shapes[i][1], shapes[i][0])
+                      for i in range(len(kp))])
+    np.testing.assert_allclose(o1, want1, rtol=0, atol=2.4e-7)
+    o0 = staging.prepare_pose2d(k[:, :, :2].contiguous(), s, extra=0).cpu().numpy()     # stride-2 keypoints, nothing appended
+    np.testing.assert_array_equal(o0, o1[:, :17])
+    with pytest.raises(ValueError):
+        staging.prepare_pose2d(k, s[:5])
+
+
+def test_pinned_feeder_delivers_batches_in_order():
+    rng = np.random.default_rng(0)
+    batches = [{"pose2d": rng.standard_normal((b, 16, 17, 2)).astype(np.float32),
+                "img_feat": rng.standard_normal((b, 16, 2048)).astype(np.float32)} for b in (8, 8, 5, 8, 1)]
+    feeder = staging.PinnedFeeder(DEV, {"pose2d": ((8, 16, 17, 2), torch.float32), "img_feat": ((8, 16, 2048), torch.float32)}, slots=2)
+    got = []
+    for dev in feeder.run(batches):
+        got.append({k: v.clone() for k, v in dev.items()})     # consume on the compute stream
+    assert len(got) == len(batches)
+    for g, b in zip(got, batches):
+        for k in b:
+            np.testing.assert_array_equal(g[k].cpu().numpy(), b[k])
+
+
+def test_frames_to_windows_pipeline_matches_host_assembly():
+    """keypoints -> prepare_pose2d -> window table -> on-device window assembly == the host-side __getitem__ recipe."""
+    kp, shapes = mg.inputs()
+    feats = np.random.default_rng(1).standard_normal((40, 2048)).astype(np.float32)
+    names = [f"0/seq/image_{i:05d}.jpg" for i in range(40)]
+    win = staging.mesh_window_table(names, 16, 1)
+    p = staging.prepare_pose2d(torch.from_numpy(kp).to(DEV), torch.from_numpy(shapes).to(DEV))
+    wp, wf = streaming.assemble_windows(p, torch.from_numpy(feats).to(DEV), win)
+    host_p = np.stack([G["norm"][a:b + 1] for a, b in win])
+    host_f = np.stack([feats[a:b + 1] for a, b in win])
+    np.testing.assert_allclose(wp.cpu().numpy(), host_p, rtol=0, atol=2.4e-7)
+    np.testing.assert_array_equal(wf.cpu().numpy(), host_f)
