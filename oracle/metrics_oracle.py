@@ -3,8 +3,10 @@ rank 1.  numpy float64 restatement of:
   * ``compute_both_err`` (reference data/PW3D/dataset.py:269-282, identical in data/Human36M/dataset.py:611-623),
   * ``rigid_transform_3D`` / ``rigid_align`` (lib/coord_utils.py:151-173),
   * ``compute_error_accel`` (lib/coord_utils.py:218-245),
-  * the per-sample arithmetic of ``PW3D.evaluate`` (data/PW3D/dataset.py:351-462).
-Pinned against outputs of the reference's own functions: tests/golden/metrics.npz (tests/golden/make_golden_metrics.py).
+  * the per-sample arithmetic of ``PW3D.evaluate`` (data/PW3D/dataset.py:351-462) and of ``Human36M.evaluate``
+    (data/Human36M/dataset.py:715-848: camera-4 samples only, ANNOTATED ground-truth joints).
+Pinned against outputs of the reference's own functions: tests/golden/metrics.npz, metrics_h36m.npz
+(tests/golden/make_golden_metrics.py, make_golden_metrics_h36m.py).
 """
 import numpy as np
 
@@ -53,10 +55,18 @@ def compute_error_accel(joints_gt, joints_pred):
     return np.mean(normed, axis=1)
 
 
-def evaluate_samples(mesh_out, mesh_gt, reg_root, root_idx, reg_h36m, seq_ids, eval_joint=H36M_EVAL_JOINT):
+def evaluate_samples(mesh_out, mesh_gt, reg_root, root_idx, reg_h36m, seq_ids, eval_joint=H36M_EVAL_JOINT, gt_joints=None,
+                     keep=None):
     """Per-sample arithmetic of PW3D.evaluate (dataset.py:372-433) for meshes already in millimetres.
     reg_root[Rr,6890] with row root_idx = the SMPL regressor's root joint (dataset.py:379-384); reg_h36m[17,6890].
+    Human36M.evaluate (Human36M/dataset.py:715-848) is the same arithmetic with two differences: only samples with
+    keep[n] (camera 4, :728-730,760-762) take part, and the ground-truth joints are the annotated gt_joints[N,17,3]
+    (:797-799) instead of the ones regressed from the ground-truth mesh.
     Returns dict(mpvpe[N,6890], mpjpe[N,14], pampjpe[N,14], accel_sum, summary means)."""
+    if keep is not None:
+        keep = np.asarray(keep, dtype=bool)
+        mesh_out, mesh_gt, seq_ids = mesh_out[keep], mesh_gt[keep], np.asarray(seq_ids)[keep]
+        gt_joints = None if gt_joints is None else np.asarray(gt_joints)[keep]
     N = mesh_out.shape[0]
     mpvpe = np.zeros((N, mesh_out.shape[1]))
     mpjpe = np.zeros((N, len(eval_joint)))
@@ -68,7 +78,8 @@ def evaluate_samples(mesh_out, mesh_gt, reg_root, root_idx, reg_h36m, seq_ids, e
         mg = mg - np.dot(reg_root, mg)[root_idx]
         mpvpe[n] = np.sqrt(np.sum((mo - mg) ** 2, 1))                 # :389
         po = np.dot(reg_h36m, mo); po = po - po[0]; po = po[eval_joint, :]   # :392-394
-        pg = np.dot(reg_h36m, mg); pg = pg - pg[0]; pg = pg[eval_joint, :]   # :395-397
+        pg = np.dot(reg_h36m, mg) if gt_joints is None else gt_joints[n].astype(np.float64)
+        pg = pg - pg[0]; pg = pg[eval_joint, :]                      # :395-397
         mpjpe[n] = np.sqrt(np.sum((po - pg) ** 2, 1))                 # :431
         pampjpe[n] = np.sqrt(np.sum((rigid_align(po, pg) - pg) ** 2, 1))  # :432-433
         P.append(po); G.append(pg)

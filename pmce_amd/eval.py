@@ -3,7 +3,9 @@
 * :meth:`Evaluator.compute_both_err`  ==  ``dataset.compute_both_err`` (data/PW3D/dataset.py:269-282), the per-batch running
   MPJPE / MPVPE printed by ``Tester.test`` (lib/core/base.py:227-233), without the D2H copy of ``[B,6890,3]`` meshes;
 * :meth:`Evaluator.evaluate`  ==  the arithmetic of ``dataset.evaluate`` (data/PW3D/dataset.py:351-462): MPJPE, PA-MPJPE,
-  MPVPE and acceleration error over a (possibly rank-sharded) set of clips, reduced with one small collective.
+  MPVPE and acceleration error over a (possibly rank-sharded) set of clips, reduced with one small collective; with
+  ``gt_joints_mm`` / ``keep_global`` it is ``Human36M.evaluate`` (data/Human36M/dataset.py:715-848): annotated ground-truth
+  joints, camera-4 samples only.
 
 Kernels: csrc/metrics.hip through the C ABI.  torch is used for allocation and the final few-float reductions only.
 """
@@ -57,15 +59,23 @@ class Evaluator:
         return float(mj.mean().item()), float(mv.mean().item())
 
     @torch.no_grad()
-    def per_sample(self, pred_mesh_m, gt_mesh_m):
+    def per_sample(self, pred_mesh_m, gt_mesh_m, gt_joints_mm=None):
         """dataset.evaluate's per-sample arithmetic for meshes in METRES (x1000 inside, base.py:223):
-        returns (mpvpe[N], mpjpe[N], pampjpe[N], pred_eval_joints[N,14,3], gt_eval_joints[N,14,3]) in mm."""
+        returns (mpvpe[N], mpjpe[N], pampjpe[N], pred_eval_joints[N,14,3], gt_eval_joints[N,14,3]) in mm.
+        gt_joints_mm [N,17,3]: annotated ground-truth joints (Human36M/dataset.py:797-799) used instead of the ones
+        regressed from the ground-truth mesh."""
         c = lambda t: t.to(self.device, torch.float32).contiguous()
         pm, gm = c(pred_mesh_m), c(gt_mesh_m)
-        pj, gj = ops.j_regress(pm, self.jr, 1000.0), ops.j_regress(gm, self.jr, 1000.0)
+        pj = ops.j_regress(pm, self.jr, 1000.0)
         rp = ops.j_regress(pm, self.root_row, 1000.0).reshape(-1, 3).contiguous()
         rg = ops.j_regress(gm, self.root_row, 1000.0).reshape(-1, 3).contiguous()
-        return self._sample_errors(pm, gm, 1000.0, rp, rg, pj, gj, self.rowsum, True)
+        if gt_joints_mm is None:
+            gj = ops.j_regress(gm, self.jr, 1000.0)
+        else:
+            # The kernel aligns joint k as  j[k] - rowsum[k]*root  (joints regressed from a root-aligned mesh).  Annotated
+            # joints are plain coordinates aligned by their own joint 0, so the root term is added here and cancels there.
+            gj = c(gt_joints_mm) + self.rowsum[None, :, None] * rg[:, None, :]
+        return self._sample_errors(pm, gm, 1000.0, rp, rg, pj, gj.contiguous(), self.rowsum, True)
 
     @torch.no_grad()
     def accel(self, pe, ge, seq_ids):
@@ -76,20 +86,26 @@ class Evaluator:
         return out
 
     @torch.no_grad()
-    def evaluate(self, pred_mesh_m, gt_mesh_m, seq_ids_global, lo=None, hi=None):
+    def evaluate(self, pred_mesh_m, gt_mesh_m, seq_ids_global, lo=None, hi=None, gt_joints_mm=None, keep_global=None):
         """Metrics over a clip set sharded contiguously over the ranks of the default process group (or unsharded).
         pred/gt: this rank's clips [lo,hi); seq_ids_global: int sequence id of EVERY clip (host array, clip order).
-        One all_reduce of 4 floats + one all_gather of the 14x3 eval joints — never the meshes."""
+        One all_reduce of 4 floats + one all_gather of the 14x3 eval joints — never the meshes.
+        Human3.6M flavour: gt_joints_mm = this rank's annotated joints [hi-lo,17,3]; keep_global = bool per clip (camera 4):
+        dropped clips count nowhere, and the acceleration error is taken over the kept clips of each sequence."""
         seq_ids_global = np.asarray(seq_ids_global)
         N = len(seq_ids_global)
         lo = 0 if lo is None else lo
         hi = N if hi is None else hi
-        mv, mj, pa, pe, ge = self.per_sample(pred_mesh_m, gt_mesh_m)
+        keep_global = np.ones(N, dtype=bool) if keep_global is None else np.asarray(keep_global, dtype=bool)
+        mv, mj, pa, pe, ge = self.per_sample(pred_mesh_m, gt_mesh_m, gt_joints_mm)
         assert mv.shape[0] == hi - lo
-        partial = torch.stack([mv.double().sum(), mj.double().sum(), pa.double().sum(),
-                               torch.tensor(float(hi - lo), device=mv.device, dtype=torch.float64)])
+        k = torch.from_numpy(keep_global[lo:hi]).to(mv.device)
+        kd = k.double()
+        partial = torch.stack([(mv.double() * kd).sum(), (mj.double() * kd).sum(), (pa.double() * kd).sum(), kd.sum()])
         tot = sharding.reduce_metric_sums(partial)
         allj = sharding.gather_rows(torch.cat([pe, ge], 1))            # [N, 28, 3] in clip order
+        kg = torch.from_numpy(keep_global).to(allj.device)
+        allj, seq_ids_global = allj[kg], seq_ids_global[keep_global]
         acc = self.accel(allj[:, :self.n_eval].contiguous(), allj[:, self.n_eval:].contiguous(), seq_ids_global)
         n = float(tot[3].item())
         return {"MPVPE": float(tot[0].item()) / n, "MPJPE": float(tot[1].item()) / n, "PA-MPJPE": float(tot[2].item()) / n,

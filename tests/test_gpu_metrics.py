@@ -67,3 +67,31 @@ def test_procrustes_edge_cases():
         assert abs(float(pa[b]) - ref_pa) < 1e-3 * max(1.0, ref_pa), (b, float(pa[b]), ref_pa)
         assert abs(float(mj[b]) - ref_mj) < 1e-3 * max(1.0, ref_mj)
     assert float(pa[0]) < 1e-3
+
+
+def test_h36m_flavour_matches_reference(golden):
+    """Evaluator with annotated GT joints + camera filter == Human36M.evaluate / compute_both_err (golden from the reference)."""
+    from make_golden_metrics_h36m import gt_joints, layout
+    from pmce_amd import assets
+    from pmce_amd.eval import Evaluator
+    dev = torch.device("cuda:0")
+    z = golden("metrics_h36m.npz")
+    pred, gt, _ = inputs()
+    cams, _, seqs = layout(len(pred))
+    gj = gt_joints(gt)
+    ev = Evaluator(dev, root_regressor_row=smpl_like_regressor()[0])
+    pm, gm = torch.from_numpy(pred).to(dev), torch.from_numpy(gt).to(dev)
+    J = torch.from_numpy(assets.load_j_regressor("h36m").astype(np.float32)).to(dev)
+    j_err, s_err = ev.compute_both_err(pm, gm, torch.matmul(J[None], pm), torch.from_numpy(gj).to(dev))
+    assert abs(j_err - float(z["j_err"])) < 1e-3 and abs(s_err - float(z["s_err"])) < 1e-3
+    keep = cams == 4
+    mv, mj, pa, _, _ = ev.per_sample(pm / 1000, gm / 1000, torch.from_numpy(gj).to(dev))
+    e = [np.abs(a.cpu().numpy()[keep] - z[k]).max() for a, k in ((mv, "mpvpe"), (mj, "mpjpe"), (pa, "pampjpe"))]
+    print("per-sample vs Human36M.evaluate: MPVPE %.2e MPJPE %.2e PA-MPJPE %.2e mm" % tuple(e))
+    assert max(e) < 1e-3
+    res = ev.evaluate(pm / 1000, gm / 1000, seqs, gt_joints_mm=torch.from_numpy(gj).to(dev), keep_global=keep)
+    print(res)
+    assert res["samples"] == int(z["n"])
+    assert abs(res["ACCEL"] * res["samples"] - float(z["acc_error_sum"])) < 1e-2
+    assert abs(res["MPJPE"] - z["mpjpe"].mean()) < 1e-3 and abs(res["PA-MPJPE"] - z["pampjpe"].mean()) < 1e-3
+    assert abs(res["MPVPE"] - z["mpvpe"].mean()) < 1e-3

@@ -49,3 +49,23 @@ def test_rigid_align_known_answers():
     P = np.cumsum(rng.standard_normal((6, 14, 3)), 0)
     acc = MO.compute_error_accel(joints_gt=P, joints_pred=P + np.arange(6)[:, None, None] ** 2 * 0.5)   # constant accel offset 1.0/axis
     assert np.allclose(acc, np.sqrt(3.0))
+
+
+def test_h36m_flavour_matches_reference(golden):
+    """Human36M.evaluate / compute_both_err (data/Human36M/dataset.py:611-623,715-848): camera-4 filter, annotated GT joints."""
+    from make_golden_metrics_h36m import gt_joints, layout
+    z = golden("metrics_h36m.npz")
+    pred, gt, _ = inputs()
+    cams, _, seqs = layout(len(pred))
+    gj = gt_joints(gt)
+    jr = assets.load_j_regressor("h36m").astype(np.float64)
+    pj = np.einsum("jv,nvc->njc", jr, pred.astype(np.float64))
+    j_err, s_err = MO.compute_both_err(pred.astype(np.float64), gt.astype(np.float64), pj, gj.astype(np.float64))
+    assert abs(j_err - float(z["j_err"])) < 2e-3 and abs(s_err - float(z["s_err"])) < 2e-3     # reference runs this one in fp32
+    r = MO.evaluate_samples(pred, gt, smpl_like_regressor(), 0, jr, seqs, gt_joints=gj, keep=cams == 4)
+    assert r["mpjpe"].shape[0] == int(z["n"]) == 8
+    # the reference multiplies float32 regressors with float32 meshes here; the oracle works in float64
+    np.testing.assert_allclose(r["mpjpe"].mean(1), z["mpjpe"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(r["pampjpe"].mean(1), z["pampjpe"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(r["mpvpe"].mean(1), z["mpvpe"], rtol=0, atol=1e-4)
+    assert abs(r["ACCEL"] * int(z["n"]) - float(z["acc_error_sum"])) < 1e-3
