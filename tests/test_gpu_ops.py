@@ -40,6 +40,12 @@ def sd_dev(sd, keys_prefix):
     (4352, 512, 256, 1, False),      # fc1 + GELU
     (4352, 256, 512, 0, True),       # fc2 + residual
     (130, 20670, 96, 0, False),      # ragged N (final-product shape)
+    # full lifter sizes (B=256): persistent workgroups walk many tiles, so the sliced epilogue that rides in the NEXT
+    # tile's k-loop, the cross-tile DMA prefetch and the edge-tile fallback all run - every output element is checked
+    (69632, 768, 256, 0, False),     # qkv, 128x128 tiles
+    (69632, 256, 256, 0, True),      # proj + residual, 64x64 tiles
+    (69632, 512, 256, 1, False),     # fc1 + GELU, 64x128 tiles
+    (69650, 256, 512, 0, True),      # fc2 + residual, ragged last row tile
 ])
 def test_gemm_nt(M, N, K, act, res):
     from pmce_amd import ops
