@@ -27,6 +27,10 @@
 
 #include "common.hpp"
 
+#ifndef PMCE_ST_AUX
+#define PMCE_ST_AUX 2  // cache policy of the epilogue stores: 2 = nt (streaming), 0 = default
+#endif
+
 struct GemmParams {
   const float* A;
   const float* W;
@@ -210,8 +214,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
         f32x2 v = {prv[(e / 16) % TM][(e / 16) / TM][e % 16], prv[((e + 1) / 16) % TM][((e + 1) / 16) / TM][(e + 1) % 16]};
         if (ACT == 1) v = gelu_erf2(v);
         if (RES) v += f32x2{rv[u], rv[u + 1]};
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), rc, lane_off, EPI_BYTES(e, ldcb), 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), rc, lane_off, EPI_BYTES(e + 1, ldcb), 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), rc, lane_off, EPI_BYTES(e, ldcb), PMCE_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), rc, lane_off, EPI_BYTES(e + 1, ldcb), PMCE_ST_AUX);
       }
     }
     if (kt + 1 < nk) {
