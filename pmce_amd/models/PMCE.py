@@ -42,8 +42,8 @@ class PMCE(HipModuleBase):
         eng.finalize()
         return eng
 
-    def _run(self, pose2d, img_feat, want_joints):
-        eng = self._ensure_packed()
+    def _run(self, pose2d, img_feat, want_joints, eng=None):
+        eng = eng or self._ensure_packed()
         pose2d = _check_input(pose2d, (SEQLEN, self.num_joint, 2), "pose2d")
         img_feat = _check_input(img_feat, (SEQLEN, FEAT_DIM), "img_feat")
         B = pose2d.shape[0]
@@ -86,6 +86,65 @@ class PMCE(HipModuleBase):
 
     def profile_read(self):
         return self._ensure_packed().profile_read()
+
+    def pipeline(self, depth: int = 2) -> "Pipeline":
+        """Several batches in flight at once on shared weights; see :class:`Pipeline`."""
+        return Pipeline(self, depth)
+
+
+class Pipeline:
+    """Keeps ``depth`` forwards of independent batches in flight (clips are independent, reference lib/_img_utils.py:74-78):
+    batch k runs on lane k % depth - a handle of its own on the shared weights, with its own workspace and streams - so the
+    decoder's latency-bound kernels of one batch overlap the matrix-bound pose lifter of the next.  Results are identical to
+    ``model.forward_with_joints`` (same kernels, same order within a batch).
+
+        pipe = model.pipeline(depth=2)
+        tickets = [pipe.submit(p, f) for p, f in batches]      # returns at once
+        for t in tickets:
+            mesh, pose, pose3d, pred = t.result()             # makes the CURRENT stream wait for that batch
+    """
+
+    class Ticket:
+        def __init__(self, outputs, done):
+            self.outputs, self.done = outputs, done
+
+        def result(self):
+            cur = torch.cuda.current_stream(self.outputs[0].device)
+            cur.wait_event(self.done)
+            for t in self.outputs:              # allocated on the lane's stream, consumed on the caller's
+                if t is not None:
+                    t.record_stream(cur)
+            return self.outputs
+
+    def __init__(self, model: "PMCE", depth: int = 2):
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.model = model
+        main = model._ensure_packed()
+        self.engines = [main] + [main.clone_shared() for _ in range(depth - 1)]
+        self.streams = [torch.cuda.Stream(device=main.device) for _ in range(depth)]
+        self.k = 0
+
+    @torch.no_grad()
+    def submit(self, pose2d, img_feat, want_joints: bool = True) -> "Pipeline.Ticket":
+        lane = self.k % len(self.engines)
+        self.k += 1
+        st = self.streams[lane]
+        cur = torch.cuda.current_stream(pose2d.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)                      # inputs produced on the caller's stream
+        st.wait_event(ready)
+        with torch.cuda.stream(st):
+            out = self.model._run(pose2d, img_feat, want_joints and self.engines[lane].regressor_rows > 0, self.engines[lane])
+            pose2d.record_stream(st)
+            img_feat.record_stream(st)
+            done = torch.cuda.Event()
+            done.record(st)
+        return Pipeline.Ticket(out, done)
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
 
 
 def get_model(num_joint, embed_dim, depth):

@@ -82,6 +82,17 @@ class HipEngine:
     def finalize(self):
         _lib.check(self.lib.pmce_model_finalize(self.handle), "pmce_model_finalize")
 
+    def clone_shared(self) -> "HipEngine":
+        """A second handle on the SAME packed weights (no copy): its own workspace, side stream and events, so that two
+        forwards can be in flight at once (models.PMCE.Pipeline)."""
+        other = HipEngine(self.J, self.C, self.depth)
+        other.register(self.packed)
+        if self.regressor_rows:
+            _lib.check(other.lib.pmce_model_set_regressor_rows(other.handle, self.regressor_rows), "set_regressor_rows")
+            other.regressor_rows = self.regressor_rows
+        other.finalize()
+        return other
+
     def workspace(self, batch: int):
         if self.ws is None or batch > self.ws_batch or self.ws.device != self.device:
             nbytes = self.lib.pmce_model_workspace_bytes(self.handle, batch)

@@ -251,3 +251,23 @@ def test_forward_is_graph_capturable():
     torch.cuda.synchronize()
     for a, b in zip(out, ref):
         assert torch.equal(a, b)
+
+
+def test_pipeline_matches_direct_forward():
+    """Several batches in flight on shared weights (models.PMCE.Pipeline) == the same batches run one at a time, bit for bit,
+    also when the batch size changes between submissions."""
+    from pmce_amd import synth
+    J = 17
+    model = get_model(J, 256)
+    batches = []
+    for i, B in enumerate((5, 5, 3, 8, 5, 1)):
+        p, f = synth.make_inputs(B, J, 700 + i)
+        batches.append((T(p).to(dev()), T(f).to(dev())))
+    direct = [tuple(t.clone() for t in model.forward_with_joints(p, f)) for p, f in batches]
+    pipe = model.pipeline(depth=3)
+    tickets = [pipe.submit(p, f) for p, f in batches]
+    for d, t in zip(direct, tickets):
+        got = t.result()
+        for a, b in zip(d, got):
+            assert torch.equal(a, b)
+    pipe.synchronize()
