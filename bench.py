@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="batches in flight (models.PMCE.Pipeline): a step's decoder overlaps the next step's pose lifter; "
                          "1 = strictly one batch at a time")
+    ap.add_argument("--no-stagger", action="store_true", help="pipeline lanes free-run instead of starting a batch's lifter "
+                                                              "when the previous batch's has finished")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the extra (untimed-for-value) host-fed measurement")
     args = ap.parse_args()
 
@@ -126,7 +128,7 @@ def main():
     img_feat = torch.from_numpy(feat_np).to(dev)
 
     depth = 1 if args.single_stream else max(1, args.pipeline_depth)
-    pipe = model.pipeline(depth) if depth > 1 else None
+    pipe = model.pipeline(depth, stagger=not args.no_stagger) if depth > 1 else None
     last = [None]
 
     def step():

@@ -96,6 +96,12 @@ int pmce_window_rows_f32(const float* src, const int* win, float* dst, int W, in
  * stream with events (hipGraph-capturable; results are identical).  0 keeps every launch on the caller's stream. */
 int pmce_model_set_concurrency(pmce_model* m, int enable);
 
+/* Staggering of several forwards in flight (one handle per lane, shared weights): makes `stream` wait until the pose
+ * lifter of the last pmce_forward enqueued on `m` has finished, so that the next batch's lifter (long matrix-bound GEMMs)
+ * runs beside that batch's decoder (short latency-bound kernels) instead of beside its lifter.  No-op before m's first
+ * forward.  Ordering only: results do not depend on it. */
+int pmce_model_wait_lifter(pmce_model* m, pmce_stream_t stream);
+
 /* Per-kernel-class timing of the forwards above (HIP events on the caller's stream).  enable != 0 starts
  * accumulating; pmce_model_profile_read synchronises the recorded events and returns, for class i, its
  * name, accumulated milliseconds and launch count; returns the number of classes. */

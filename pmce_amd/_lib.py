@@ -35,6 +35,7 @@ PROTOTYPES = {
     "pmce_window_tokens_f32": [_f, _f, _f, _f, _f, _fl, _f, _f, _i, _i, _i, _i, _i, _s],
     "pmce_window_rows_f32": [_f, _f, _f, _i, _i, _i, _i, _s],
     "pmce_model_set_concurrency": [C.c_void_p, _i],
+    "pmce_model_wait_lifter": [C.c_void_p, _s],
     "pmce_model_profile": [C.c_void_p, _i],
     "pmce_model_profile_read": [C.c_void_p, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_longlong)],
     "pmce_gemm_nt_f32": [_f, _f, _f, _f, _f, _i, _i, _i, _l, _i, _l, _i, _i, _l, _l, _i, _l, _l, _i, _l, _l, _l, _l, _s],

@@ -47,6 +47,7 @@ struct pmce_model {
   // second stream for the image-feature branch (created on first use, destroyed with the model)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
+  hipEvent_t ev_lifter = nullptr;  // recorded by pmce_forward when its pose lifter is enqueued (pmce_model_wait_lifter)
   bool concurrent = true;  // pmce_model_set_concurrency
   // regressor (optional)
   const int* jr_indptr = nullptr;
@@ -485,7 +486,7 @@ void pmce_model_destroy(pmce_model* m) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
   }
-  for (hipEvent_t e : {m->ev_fork, m->ev_join, m->ev_a, m->ev_b, m->ev_c, m->ev_d})
+  for (hipEvent_t e : {m->ev_fork, m->ev_join, m->ev_a, m->ev_b, m->ev_c, m->ev_d, m->ev_lifter})
     if (e) (void)hipEventDestroy(e);
   if (m->side) (void)hipStreamDestroy(m->side);
   delete m;
@@ -640,6 +641,8 @@ int pmce_forward(pmce_model* m, const float* pose2d, const float* img_feat, floa
   PMCE_TRY(lifter_impl(m, pose2d, img_feat, pose3d, batch, lw, stream));
   // pose3d.reshape(-1, J, 3) / 1000  (PMCE.py:17-18)
   RUN(P_MISC, pmce_div_scalar_f32(pose3d, dw.JM, (long long)batch * m->J * 3, 1000.0f, stream));
+  if (!m->ev_lifter) (void)hipEventCreateWithFlags(&m->ev_lifter, hipEventDisableTiming);
+  if (m->ev_lifter) (void)hipEventRecord(m->ev_lifter, stream);
   if (!single) (void)hipStreamWaitEvent(stream, m->ev_join, 0);  // join
   PMCE_TRY(coevo_part(m, dw.JM, cam_pose, cam_mesh, batch, dw, stream, single ? nullptr : m->side));
   if (pred_pose) {
@@ -713,6 +716,15 @@ int pmce_stream_forward(pmce_model* m, const float* x0, const float* gi0, const 
                                    stream));
   }
   return PMCE_OK;
+}
+
+int pmce_model_wait_lifter(pmce_model* m, pmce_stream_t stream) {
+  PMCE_REQUIRE(m, "model_wait_lifter: null model");
+  if (m->ev_lifter && hipStreamWaitEvent(stream, m->ev_lifter, 0) != hipSuccess) {
+    pmce_set_error("model_wait_lifter: %s", hipGetErrorString(hipGetLastError()));
+    return PMCE_ERR_LAUNCH;
+  }
+  return PMCE_OK;  // no forward has run on m yet: nothing to wait for
 }
 
 int pmce_model_set_concurrency(pmce_model* m, int enable) {

@@ -87,9 +87,9 @@ class PMCE(HipModuleBase):
     def profile_read(self):
         return self._ensure_packed().profile_read()
 
-    def pipeline(self, depth: int = 2) -> "Pipeline":
+    def pipeline(self, depth: int = 2, stagger: bool = True) -> "Pipeline":
         """Several batches in flight at once on shared weights; see :class:`Pipeline`."""
-        return Pipeline(self, depth)
+        return Pipeline(self, depth, stagger)
 
 
 class Pipeline:
@@ -116,7 +116,8 @@ class Pipeline:
                     t.record_stream(cur)
             return self.outputs
 
-    def __init__(self, model: "PMCE", depth: int = 2):
+    def __init__(self, model: "PMCE", depth: int = 2, stagger: bool = True):
+        self.stagger, self.prev = stagger, None
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.model = model
@@ -134,6 +135,10 @@ class Pipeline:
         ready = torch.cuda.Event()
         ready.record(cur)                      # inputs produced on the caller's stream
         st.wait_event(ready)
+        if self.stagger and self.prev is not None and self.prev is not self.engines[lane]:
+            # start this batch's pose lifter when the previous batch's has finished: lifter(k+1) overlaps decoder(k)
+            _lib.check(self.engines[lane].lib.pmce_model_wait_lifter(self.prev.handle, C.c_void_p(st.cuda_stream)), "model_wait_lifter")
+        self.prev = self.engines[lane]
         with torch.cuda.stream(st):
             out = self.model._run(pose2d, img_feat, want_joints and self.engines[lane].regressor_rows > 0, self.engines[lane])
             pose2d.record_stream(st)
