@@ -8,6 +8,9 @@ sd = synth.make_state_dict(synth.pmce_spec(J, 256, 3), seed=123)
 model = models.PMCE.get_model(J, 256, 3); model.load_state_dict(sd); model.set_j_regressor(assets.load_j_regressor("h36m")); model = model.to(dev)
 p, f = (torch.from_numpy(a).to(dev) for a in synth.make_inputs(B, J, seed=1))
 cfgs = [(1, False, True), (1, False, False), (2, False, True), (2, False, False), (2, True, True), (2, True, False), (3, False, True)]
+if len(sys.argv) > 1:   # e.g. "2,1,1" = depth 2, stagger, two-stream forwards: only that configuration in this process
+    d, st, cc = (int(x) for x in sys.argv[1].split(","))
+    cfgs = [(d, bool(st), bool(cc))]
 pipes = {c: model.pipeline(c[0], stagger=c[1]) for c in cfgs}
 res = {c: [] for c in cfgs}
 for rnd in range(5):
