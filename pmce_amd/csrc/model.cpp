@@ -442,6 +442,12 @@ int coevo_part(pmce_model* m, const float* joints, float* cam_pose, float* cam_m
 }
 
 // second stream + fork/join events, created on first use
+// pmce_model_wait_lifter: the point of a forward after which only its decoder is left
+void mark_lifter_done(pmce_model* m, hipStream_t stream) {
+  if (!m->ev_lifter) (void)hipEventCreateWithFlags(&m->ev_lifter, hipEventDisableTiming);
+  if (m->ev_lifter) (void)hipEventRecord(m->ev_lifter, stream);
+}
+
 int ensure_side(pmce_model* m) {
   if (m->side) return PMCE_OK;
   int lo = 0, hi = 0;
@@ -641,8 +647,7 @@ int pmce_forward(pmce_model* m, const float* pose2d, const float* img_feat, floa
   PMCE_TRY(lifter_impl(m, pose2d, img_feat, pose3d, batch, lw, stream));
   // pose3d.reshape(-1, J, 3) / 1000  (PMCE.py:17-18)
   RUN(P_MISC, pmce_div_scalar_f32(pose3d, dw.JM, (long long)batch * m->J * 3, 1000.0f, stream));
-  if (!m->ev_lifter) (void)hipEventCreateWithFlags(&m->ev_lifter, hipEventDisableTiming);
-  if (m->ev_lifter) (void)hipEventRecord(m->ev_lifter, stream);
+  mark_lifter_done(m, stream);
   if (!single) (void)hipStreamWaitEvent(stream, m->ev_join, 0);  // join
   PMCE_TRY(coevo_part(m, dw.JM, cam_pose, cam_mesh, batch, dw, stream, single ? nullptr : m->side));
   if (pred_pose) {
@@ -708,6 +713,7 @@ int pmce_stream_forward(pmce_model* m, const float* x0, const float* gi0, const 
                                    m->f(blk("Temporal", 0, "norm1.bias")), 1e-6f, lw.X, lw.XN, W, L, T, m->J, m->C, stream));
   PMCE_TRY(lifter_rest(m, pose3d, W, lw, stream));
   RUN(P_MISC, pmce_div_scalar_f32(pose3d, dw.JM, (long long)W * m->J * 3, 1000.0f, stream));
+  mark_lifter_done(m, stream);
   if (!single) (void)hipStreamWaitEvent(stream, m->ev_join, 0);
   PMCE_TRY(coevo_part(m, dw.JM, cam_pose, cam_mesh, W, dw, stream, single ? nullptr : m->side));
   if (pred_pose) {

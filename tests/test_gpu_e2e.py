@@ -219,9 +219,16 @@ def test_streaming_frame_reuse_matches_window_forward():
     e = [maxabs(a, b) for a, b in zip(out, ref)]
     print("frame-reuse vs window forward: mesh %.2e pose %.2e pose3d %.2e mm pred %.2e mm" % tuple(e))
     assert e[0] < 1e-5 and e[1] < 1e-5 and e[2] < 1e-2 and e[3] < 1e-2
+    # batches in flight on several lanes: identical to one lane
+    one = streaming.stream_forward_cached(model, cache, windows=win, batch=64, with_joints=True, lanes=1)
+    for lanes in (2, 3):
+        many = streaming.stream_forward_cached(model, cache, windows=win, batch=64, with_joints=True, lanes=lanes)
+        assert all(torch.equal(a, b) for a, b in zip(one, many))
     for fn, name in ((lambda: streaming.stream_forward(model, pose_fr, feat_fr, windows=win, batch=320), "independent windows"),
                      (lambda: streaming.stream_forward_cached(model, streaming.precompute_frames(model, pose_fr, feat_fr),
-                                                              windows=win, batch=320), "frame reuse")):
+                                                              windows=win, batch=320), "frame reuse"),
+                     (lambda: streaming.stream_forward_cached(model, streaming.precompute_frames(model, pose_fr, feat_fr),
+                                                              windows=win, batch=160), "frame reuse, 2 x 160 in flight")):
         fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(5):
             fn()
