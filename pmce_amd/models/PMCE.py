@@ -120,14 +120,22 @@ class Pipeline:
         self.stagger, self.prev = stagger, None
         if depth < 1:
             raise ValueError("depth must be >= 1")
-        self.model = model
-        main = model._ensure_packed()
-        self.engines = [main] + [main.clone_shared() for _ in range(depth - 1)]
-        self.streams = [torch.cuda.Stream(device=main.device) for _ in range(depth)]
+        self.model, self.depth = model, depth
+        self.engines, self.streams = [], []
         self.k = 0
+        self._bind()
+
+    def _bind(self):
+        """(Re)build the lanes on the model's current packed weights (they are re-packed after load_state_dict / .to())."""
+        main = self.model._ensure_packed()
+        if not self.engines or self.engines[0] is not main:
+            self.engines = [main] + [main.clone_shared() for _ in range(self.depth - 1)]
+            self.streams = [torch.cuda.Stream(device=main.device) for _ in range(self.depth)]
+            self.prev = None
 
     @torch.no_grad()
     def submit(self, pose2d, img_feat, want_joints: bool = True) -> "Pipeline.Ticket":
+        self._bind()
         lane = self.k % len(self.engines)
         self.k += 1
         st = self.streams[lane]

@@ -278,3 +278,20 @@ def test_pipeline_matches_direct_forward():
         for a, b in zip(d, got):
             assert torch.equal(a, b)
     pipe.synchronize()
+
+
+def test_pipeline_follows_reloaded_weights():
+    """A pipeline created before load_state_dict must serve the NEW weights afterwards (lanes share the model's packed copy)."""
+    from pmce_amd import synth
+    J = 17
+    model = get_model(J, 256)
+    p, f = (T(a).to(dev()) for a in synth.make_inputs(3, J, 31))
+    pipe = model.pipeline(depth=2)
+    a0 = pipe.submit(p, f).result()[0].clone()
+    sd2 = synth.make_state_dict(synth.pmce_spec(J, 256, 3), seed=777)
+    model.load_state_dict(sd2)
+    want = model.forward_with_joints(p, f)[0]
+    got = [pipe.submit(p, f).result()[0] for _ in range(2)]        # both lanes
+    model.load_state_dict(cached_state_dict(J, 256))                # the model object is shared by the tests of this file
+    assert not torch.equal(a0, want)
+    assert torch.equal(got[0], want) and torch.equal(got[1], want)
