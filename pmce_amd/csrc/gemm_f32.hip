@@ -200,7 +200,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
   // slice S (its residuals were loaded an iteration ago), DMA of the next k-tile, residual loads of slice S+1, MFMAs.
   // Every vector-memory operation is thus issued ahead of the MFMAs and the vmcnt(0) in front of the barrier finds
   // them long done; and no compiler-counted load is consumed while an (uncounted) DMA is younger than it.
-  float rv[EPS];  // residuals of the slice that runs in the next iteration
+  // residuals, fetched TWO slices ahead (slice S uses rv[S & 1]; one k-iteration of a 64x64 tile is shorter than an HBM
+  // round trip, and the residual stream is cold when the launch starts)
+  float rv[2][EPS];
   const int swz = (n0 >> 1) & 7;
   auto iteration = [&](f32x16(&cur)[TM][TN], const f32x16(&prv)[TM][TN], PendingEpi& pend, int kt, auto slice_tag) {
     constexpr int S = decltype(slice_tag)::value;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
         const int e = SS * EPS + u;
         f32x2 v = {prv[(e / 16) % TM][(e / 16) / TM][e % 16], prv[((e + 1) / 16) % TM][((e + 1) / 16) / TM][(e + 1) % 16]};
         if (ACT == 1) v = gelu_erf2(v);
-        if (RES) v += f32x2{rv[u], rv[u + 1]};
+        if (RES) v += f32x2{rv[SS & 1][u], rv[SS & 1][u + 1]};
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), rc, lane_off, EPI_BYTES(e, ldcb), PMCE_ST_AUX);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), rc, lane_off, EPI_BYTES(e + 1, ldcb), PMCE_ST_AUX);
       }
@@ -224,12 +226,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
       set_ptrs(m_next, n_next);
       gdma(0, buf ^ 1);
     }
-    if (S >= 0 && S < 7 && RES && pend.valid) {
+    if (S >= 0 && S < 6 && RES && pend.valid) {
       const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pend.r), 0, 0x7fffffff, RSRC_FLAGS);
       const int ldcb = opaque_ldcb();
 #pragma unroll
       for (int u = 0; u < EPS; ++u)
-        rv[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, lane_off, EPI_BYTES((SS + 1) * EPS + u, ldcb), 0));
+        rv[SS & 1][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, lane_off, EPI_BYTES((SS + 2) * EPS + u, ldcb), 0));
     }
     const float* as = &As[buf][(wm * WM + n0) * LD];
     const float* bs = &Bs[buf][(wn * WN + n0) * LD];
@@ -339,7 +341,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
         const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pend.r), 0, 0x7fffffff, RSRC_FLAGS);
         const int ldcb = opaque_ldcb();
 #pragma unroll
-        for (int u = 0; u < EPS; ++u) rv[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, lane_off, EPI_BYTES(u, ldcb), 0));
+        for (int u = 0; u < 2 * EPS; ++u)   // slices 0 and 1
+          rv[u / EPS][u % EPS] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, lane_off, EPI_BYTES(u, ldcb), 0));
       }
       pend.valid = true;
     } else {
