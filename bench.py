@@ -271,12 +271,8 @@ def main():
                          f"thread count calibrated over 8..128"}
 
     if rank == 0:
-        flops_clip = None
-        try:
-            from oracle import pmce_oracle as O
-            flops_clip = O.flops_per_clip(J, C)["total"]
-        except Exception:
-            pass
+        from pmce_amd.workload import flops_per_clip
+        flops_clip = flops_per_clip(J, C)["total"]
         line = {
             "metric": "16-frame clips/s", "value": round(clips_per_s, 1), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),

@@ -165,3 +165,11 @@ def test_checkpoint_tooling(tmp_path):
     assert "missing: pose_lifter.norm_s.weight" in msg and "shape: pose_mesh_coevo.linear_cur1.bias" in msg and "unexpected: extra.key" in msg
     with pytest.raises(ValueError, match="No checkpoint exists"):
         checkpoint.load_reference_checkpoint(str(tmp_path / "nope.pth.tar"))
+
+
+def test_workload_flops_agree_with_oracle_count():
+    from oracle import pmce_oracle as O
+    from pmce_amd.workload import flops_per_clip
+    for J, C in ((17, 256), (19, 256), (17, 512)):
+        assert flops_per_clip(J, C) == O.flops_per_clip(J, C)
+    assert abs(flops_per_clip(17, 256)["total"] - 3.552e9) < 5e6
