@@ -295,3 +295,20 @@ def test_pipeline_follows_reloaded_weights():
     model.load_state_dict(cached_state_dict(J, 256))                # the model object is shared by the tests of this file
     assert not torch.equal(a0, want)
     assert torch.equal(got[0], want) and torch.equal(got[1], want)
+
+
+@pytest.mark.parametrize("J,C", [(19, 256), (17, 512)])
+def test_streaming_frame_reuse_other_configs(J, C):
+    """frame reuse == independent windows for the COCO-19 input and the 512-wide lifter as well."""
+    from pmce_amd import streaming, synth
+    model = get_model(J, C)
+    L = 16 * 3
+    p_np, f_np = synth.make_inputs(3, J, 21)
+    pose_fr = T(p_np.reshape(-1, J, 2)[:L]).to(dev())
+    feat_fr = T(f_np.reshape(-1, 2048)[:L]).to(dev())
+    win = streaming.demo_window_list(L)
+    ref = streaming.stream_forward(model, pose_fr, feat_fr, windows=win, batch=20, with_joints=True)
+    cache = streaming.precompute_frames(model, pose_fr, feat_fr)
+    out = streaming.stream_forward_cached(model, cache, windows=win, batch=20, with_joints=True, lanes=2)
+    e = [maxabs(a, b) for a, b in zip(out, ref)]
+    assert e[0] < 1e-5 and e[1] < 1e-5 and e[2] < 1e-2 and e[3] < 1e-2, e
