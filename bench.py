@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--no-stagger", action="store_true", help="pipeline lanes free-run instead of starting a batch's lifter "
                                                               "when the previous batch's has finished")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the extra (untimed-for-value) host-fed measurement")
+    ap.add_argument("--no-variant", action="store_true",
+                    help="skip the second timed configuration (the 512-wide pose encoder that BASELINE.json's north_star quotes "
+                         "throughput on; every reference config ships 256, which is what `value` is measured on)")
     args = ap.parse_args()
 
     from pmce_amd import assets, models, sharding, synth
@@ -216,6 +219,41 @@ def main():
               "frac": round(ach / PEAK_HBM_GBS, 4), "bytes_per_clip_dir_block": 229376,
               "avg_launch_ms": round(kernel_ms["vertex_ca"] / launches["vertex_ca"], 5)}
 
+    # ---- the same measurement on the 512-wide pose encoder (north_star's "(B,T=16,J=17,C=512)"); all ranks take part ----
+    variant = None
+    if not args.no_variant and not args.single_stream and C != 512:
+        C2 = 512
+        sd2 = synth.make_state_dict(synth.pmce_spec(J, C2, 3), seed=123)
+        model2 = models.PMCE.get_model(J, C2, 3)
+        model2.load_state_dict(sd2)
+        model2.set_j_regressor(assets.load_j_regressor("h36m"))
+        model2 = model2.to(dev)
+        pipe2 = model2.pipeline(depth, stagger=not args.no_stagger) if depth > 1 else None
+        run2 = (lambda: pipe2.submit(pose2d, img_feat)) if pipe2 else (lambda: model2.forward_with_joints(pose2d, img_feat))
+        k2 = max(5, min(args.steps, 10))
+        for _ in range(3):
+            o2 = run2()
+        torch.cuda.synchronize()
+        sharding.barrier()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(k2):
+            o2 = run2()
+        torch.cuda.synchronize()
+        sharding.barrier()
+        torch.cuda.synchronize()
+        dt2 = sharding.reduce_max(time.perf_counter() - t2, dev)
+        o2 = o2.result() if pipe2 else o2
+        from pmce_amd.workload import flops_per_clip as _fpc
+        v2 = B * world * k2 / dt2
+        variant = {"config": {"workload": f"same path, pose encoder width C={C2} (BASELINE.json north_star), batch={B}/GPU, J={J}",
+                              "global_batch": B * world, "batches_in_flight": depth},
+                   "value": round(v2, 1), "unit": "clips/s", "steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 4),
+                   "ref_equiv_tflops": round(_fpc(J, C2)["total"] * v2 / 1e12, 2),
+                   "outputs_finite": bool(torch.isfinite(o2[0]).all().item())}
+        del model2, pipe2, o2, sd2
+        torch.cuda.empty_cache()
+
     # ---- host-fed rate (reported next to `value`, never as it): the same clips start in pageable host memory every step
     # and travel through pmce_amd.staging.PinnedFeeder (memcpy to a pinned ring, async H2D on a copy stream that runs
     # under the previous step's kernels) ----
@@ -281,7 +319,7 @@ def main():
                                    f"upsample + J_regressor), batch={B}/GPU, T=16, J={J}, C={C}, random-init weights",
                        "global_batch": B * world, "parallelism": f"clip-sharded dp{world}, weights replicated",
                        "streams": 1 if args.single_stream else 2 * depth, "batches_in_flight": depth},
-            "roofline": roofline, "roofline_cross_attention": ca, "cpu_baseline": cpu, "host_fed": host_fed,
+            "roofline": roofline, "roofline_cross_attention": ca, "cpu_baseline": cpu, "host_fed": host_fed, "variant_c512": variant,
             "kernel_ms_per_step": kernel_ms, "launches_per_step": launches,
             "ref_equiv_tflops": round(flops_clip * clips_per_s / 1e12, 2) if flops_clip else None,
             "outputs_finite": finite,
