@@ -131,7 +131,7 @@ def main():
     img_feat = torch.from_numpy(feat_np).to(dev)
 
     depth = 1 if args.single_stream else max(1, args.pipeline_depth)
-    pipe = model.pipeline(depth, stagger=not args.no_stagger) if depth > 1 else None
+    pipe = model.pipeline(depth, stagger=not args.no_stagger).prepare(B) if depth > 1 else None
     last = [None]
 
     def step():
@@ -228,7 +228,7 @@ def main():
         model2.load_state_dict(sd2)
         model2.set_j_regressor(assets.load_j_regressor("h36m"))
         model2 = model2.to(dev)
-        pipe2 = model2.pipeline(depth, stagger=not args.no_stagger) if depth > 1 else None
+        pipe2 = model2.pipeline(depth, stagger=not args.no_stagger).prepare(B) if depth > 1 else None
         run2 = (lambda: pipe2.submit(pose2d, img_feat)) if pipe2 else (lambda: model2.forward_with_joints(pose2d, img_feat))
         k2 = max(5, min(args.steps, 10))
         for _ in range(3):

@@ -155,6 +155,24 @@ class Pipeline:
             done.record(st)
         return Pipeline.Ticket(out, done)
 
+    def prepare(self, batch: int):
+        """One-time setup of every lane for ``batch`` clips, so that no lane pays it at its first real submit: workspace
+        allocation, creation of the lane's internal stream and events, first touch of its buffers (one forward on zeros)."""
+        self._bind()
+        J = self.model.num_joint
+        dev = self.engines[0].device
+        p = torch.zeros(batch, SEQLEN, J, 2, device=dev)
+        f = torch.zeros(batch, SEQLEN, FEAT_DIM, device=dev)
+        for eng, st in zip(self.engines, self.streams):
+            st.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(st):
+                self.model._run(p, f, eng.regressor_rows > 0, eng)
+                p.record_stream(st)
+                f.record_stream(st)
+        self.synchronize()
+        self.prev = None
+        return self
+
     def synchronize(self):
         for st in self.streams:
             st.synchronize()
