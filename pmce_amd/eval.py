@@ -110,3 +110,41 @@ class Evaluator:
         n = float(tot[3].item())
         return {"MPVPE": float(tot[0].item()) / n, "MPJPE": float(tot[1].item()) / n, "PA-MPJPE": float(tot[2].item()) / n,
                 "ACCEL": float(acc.double().sum().item()) / n, "samples": int(n)}
+
+
+class RunningEval:
+    """Batch-by-batch form of :meth:`Evaluator.evaluate` for test sets that should not sit in memory as meshes: every batch
+    is reduced to its per-sample errors and 14x3 evaluation joints on the device as soon as it is produced (82 KB of mesh
+    per clip shrink to 180 B), and the ranks meet once in :meth:`finish`."""
+
+    def __init__(self, evaluator: Evaluator):
+        self.ev = evaluator
+        self.mv, self.mj, self.pa, self.pe, self.ge = [], [], [], [], []
+
+    @torch.no_grad()
+    def add(self, pred_mesh_m, gt_mesh_m, gt_joints_mm=None):
+        mv, mj, pa, pe, ge = self.ev.per_sample(pred_mesh_m, gt_mesh_m, gt_joints_mm)
+        for lst, t in zip((self.mv, self.mj, self.pa, self.pe, self.ge), (mv, mj, pa, pe, ge)):
+            lst.append(t)
+
+    @torch.no_grad()
+    def finish(self, seq_ids_global, lo=None, hi=None, keep_global=None):
+        """Same result dict as Evaluator.evaluate over this rank's clips [lo, hi) added in order."""
+        ev = self.ev
+        seq_ids_global = np.asarray(seq_ids_global)
+        N = len(seq_ids_global)
+        lo = 0 if lo is None else lo
+        hi = N if hi is None else hi
+        keep_global = np.ones(N, dtype=bool) if keep_global is None else np.asarray(keep_global, dtype=bool)
+        mv, mj, pa, pe, ge = (torch.cat(x) for x in (self.mv, self.mj, self.pa, self.pe, self.ge))
+        assert mv.shape[0] == hi - lo, f"added {mv.shape[0]} clips, shard holds {hi - lo}"
+        kd = torch.from_numpy(keep_global[lo:hi]).to(mv.device).double()
+        tot = sharding.reduce_metric_sums(torch.stack([(mv.double() * kd).sum(), (mj.double() * kd).sum(),
+                                                       (pa.double() * kd).sum(), kd.sum()]))
+        allj = sharding.gather_rows(torch.cat([pe, ge], 1))
+        kg = torch.from_numpy(keep_global).to(allj.device)
+        allj, seq = allj[kg], seq_ids_global[keep_global]
+        acc = ev.accel(allj[:, :ev.n_eval].contiguous(), allj[:, ev.n_eval:].contiguous(), seq)
+        n = float(tot[3].item())
+        return {"MPVPE": float(tot[0].item()) / n, "MPJPE": float(tot[1].item()) / n, "PA-MPJPE": float(tot[2].item()) / n,
+                "ACCEL": float(acc.double().sum().item()) / n, "samples": int(n)}

@@ -95,3 +95,25 @@ def test_h36m_flavour_matches_reference(golden):
     assert abs(res["ACCEL"] * res["samples"] - float(z["acc_error_sum"])) < 1e-2
     assert abs(res["MPJPE"] - z["mpjpe"].mean()) < 1e-3 and abs(res["PA-MPJPE"] - z["pampjpe"].mean()) < 1e-3
     assert abs(res["MPVPE"] - z["mpvpe"].mean()) < 1e-3
+
+
+def test_running_eval_equals_one_shot(golden):
+    """RunningEval (batch by batch, meshes dropped) == Evaluator.evaluate on the whole set, for both dataset flavours."""
+    from make_golden_metrics_h36m import gt_joints, layout
+    from pmce_amd.eval import Evaluator, RunningEval
+    dev = torch.device("cuda:0")
+    pred, gt, seq = inputs()
+    pm, gm = torch.from_numpy(pred).to(dev) / 1000, torch.from_numpy(gt).to(dev) / 1000
+    ev = Evaluator(dev, root_regressor_row=smpl_like_regressor()[0])
+    want = ev.evaluate(pm, gm, seq)
+    run = RunningEval(ev)
+    for a, b in ((0, 3), (3, 4), (4, 10)):
+        run.add(pm[a:b], gm[a:b])
+    assert run.finish(seq) == want
+    cams, _, seqs = layout(len(pred))
+    gj = torch.from_numpy(gt_joints(gt)).to(dev)
+    want = ev.evaluate(pm, gm, seqs, gt_joints_mm=gj, keep_global=cams == 4)
+    run = RunningEval(ev)
+    for a, b in ((0, 6), (6, 10)):
+        run.add(pm[a:b], gm[a:b], gj[a:b])
+    assert run.finish(seqs, keep_global=cams == 4) == want
