@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""BASELINE configs[1]: CoEvoDecoder-only forward (models.CoevoDecoder.get_model), batch 64, one MI355X.  Prints clips/s, the
+north-star cross-attention kernel against the HBM roof (the CPU baseline of the path is bench.py's)."""
+import argparse, json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=50)
+    args = ap.parse_args()
+    from pmce_amd import models, synth
+    dev = torch.device("cuda:0")
+    J, B = 17, args.batch
+    sd = {k[len("pose_mesh_coevo."):]: v for k, v in synth.make_state_dict(synth.pmce_spec(J, 256, 3), seed=123).items()
+          if k.startswith("pose_mesh_coevo.")}
+    dec = models.CoevoDecoder.get_model(J, 256)
+    dec.load_state_dict(sd)
+    dec = dec.to(dev)
+    g = torch.Generator().manual_seed(0)
+    joints = (torch.randn(B, J, 3, generator=g) * 0.3).to(dev)                      # N(0, 0.3^2) m  (SURVEY 8d cfg 2)
+    feats = torch.relu(torch.randn(B, 16, 2048, generator=g)).to(dev)
+    for _ in range(5):
+        dec(joints, feats)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pose, mesh = dec(joints, feats)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    eng = dec._ensure_packed()
+    eng.set_concurrency(False); eng.profile(True)
+    for _ in range(3):
+        dec(joints, feats)
+    torch.cuda.synchronize()
+    prof = eng.profile_read(); eng.profile(False); eng.set_concurrency(True)
+    ca_ms = prof["vertex_ca"][0] / prof["vertex_ca"][1]
+    out = {"config": f"CoEvoDecoder-only forward, batch={B}, J=17", "clips_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4),
+           "cross_attention": {"kernel": "vertex_ca", "avg_launch_ms": round(ca_ms, 5), "bytes_per_clip_dir_block": 229376,
+                               "achieved_GBps": round(229376 * B / (ca_ms * 1e-3) / 1e9, 1), "peak_GBps": 8000},
+           "kernel_ms_per_step": {k: round(v[0] / 3, 4) for k, v in prof.items() if v[1] > 0 and v[0] / 3 > 0.01},
+           "outputs_finite": bool(torch.isfinite(mesh).all().item() and torch.isfinite(pose).all().item())}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
