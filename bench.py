@@ -247,7 +247,7 @@ def main():
         from pmce_amd.workload import flops_per_clip as _fpc
         v2 = B * world * k2 / dt2
         variant = {"config": {"workload": f"same path, pose encoder width C={C2} (BASELINE.json north_star), batch={B}/GPU, J={J}",
-                              "global_batch": B * world, "batches_in_flight": depth},
+                              "global_batch": B * world, "seq_len": 16, "joints": J, "embed_dim": C2, "batches_in_flight": depth},
                    "value": round(v2, 1), "unit": "clips/s", "steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 4),
                    "ref_equiv_tflops": round(_fpc(J, C2)["total"] * v2 / 1e12, 2),
                    "outputs_finite": bool(torch.isfinite(o2[0]).all().item())}
@@ -317,7 +317,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"full two-stream PMCE forward (temporal pose encoder + CoEvoDecoder + 6890-vertex "
                                    f"upsample + J_regressor), batch={B}/GPU, T=16, J={J}, C={C}, random-init weights",
-                       "global_batch": B * world, "parallelism": f"clip-sharded dp{world}, weights replicated",
+                       "global_batch": B * world, "seq_len": 16, "joints": J, "embed_dim": C,
+                       "parallelism": f"clip-sharded dp{world}, weights replicated",
                        "streams": 1 if args.single_stream else 2 * depth, "batches_in_flight": depth},
             "roofline": roofline, "roofline_cross_attention": ca, "cpu_baseline": cpu, "host_fed": host_fed, "variant_c512": variant,
             "kernel_ms_per_step": kernel_ms, "launches_per_step": launches,
