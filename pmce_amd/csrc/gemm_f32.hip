@@ -9,7 +9,7 @@
 //
 // Design:
 //  * v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD), 256 threads = 4 waves, block tile BMxBNx32, both
-//    operands K-contiguous.  Tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: 8 lanes x 16 B per 128-byte
+//    operands K-contiguous.  Tiles go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: 8 lanes x 16 B per 128-byte
 //    row, no VGPR round trip, no ds_write), one k-tile ahead into a double-buffered LDS whose rows are unpadded with
 //    their 16-byte chunks XOR-swizzled (swizzle on the DMA's source address and on the ds_read address: conflict-free
 //    ds_read_b128).  The k order inside each group of 8 is permuted (lanes 0-31 take k..k+3, lanes 32-63 take
@@ -19,8 +19,9 @@
 //  * TWO accumulator sets: the finished tile's epilogue (GELU / residual / stores) is cut into 8 slices that ride
 //    inside the first 8 k-iterations of the NEXT tile.  The bias is the accumulators' initial value; stores and
 //    residual loads are buffer instructions (descriptor on the wave tile, scalar element offset, one per-lane offset
-//    VGPR for the whole kernel), so a slice is one VMEM instruction (+ GELU) per element and no address arithmetic on
-//    the vector unit, which shares its FMA lanes with the fp32 matrix pipe.
+//    VGPR for the whole kernel), so a slice is one VMEM instruction (+ packed GELU) per element and no address arithmetic
+//    on the vector unit, which shares its FMA lanes with the fp32 matrix pipe.  Stores are streaming (nt); residuals are
+//    fetched two slices ahead (the residual stream is cold when a launch starts).
 #include <stdlib.h>
 
 #include <type_traits>
