@@ -96,6 +96,10 @@ class HipEngine:
     def workspace(self, batch: int):
         if self.ws is None or batch > self.ws_batch or self.ws.device != self.device:
             nbytes = self.lib.pmce_model_workspace_bytes(self.handle, batch)
+            if self.ws is not None and self.ws.is_cuda:
+                # forwards enqueued on this stream may still be using the old buffer: the allocator must not hand it out
+                # to another stream before they are done
+                self.ws.record_stream(torch.cuda.current_stream(self.ws.device))
             self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             self.ws_batch = batch
         return self.ws
