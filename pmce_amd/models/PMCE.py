@@ -121,15 +121,17 @@ class Pipeline:
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.model, self.depth = model, depth
-        self.engines, self.streams = [], []
+        self.engines, self.streams, self._main = [], [], None
         self.k = 0
         self._bind()
 
     def _bind(self):
         """(Re)build the lanes on the model's current packed weights (they are re-packed after load_state_dict / .to())."""
         main = self.model._ensure_packed()
-        if not self.engines or self.engines[0] is not main:
-            self.engines = [main] + [main.clone_shared() for _ in range(self.depth - 1)]
+        if not self.engines or self._main is not main:
+            # every lane is a handle of its own (the model's handle and workspace stay free for direct forward() calls)
+            self._main = main
+            self.engines = [main.clone_shared() for _ in range(self.depth)]
             self.streams = [torch.cuda.Stream(device=main.device) for _ in range(self.depth)]
             self.prev = None
 
