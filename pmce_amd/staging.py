@@ -114,6 +114,19 @@ class PinnedFeeder:
         self._used[slot] = True
         return {k: self.dev[slot][k][:n] for k, n in view.items()}
 
+    class Batch(dict):
+        """Device views of one fed batch.  By default its slot is considered consumed by whatever the CURRENT stream has
+        enqueued when the consumer asks for the next batch; a consumer that works on another stream (e.g. a
+        models.PMCE.Pipeline lane) calls ``release(event)`` with an event recorded after its last use instead."""
+
+        def __init__(self, views, feeder, slot):
+            super().__init__(views)
+            self._feeder, self._slot, self._released = feeder, slot, False
+
+        def release(self, event: "torch.cuda.Event"):
+            self._feeder.consumed[self._slot] = event
+            self._released = True
+
     def run(self, host_batches):
         it = iter(host_batches)
         pending = []                                     # (slot, device views), oldest first
@@ -127,8 +140,12 @@ class PinnedFeeder:
         while pending:
             s, views = pending.pop(0)
             torch.cuda.current_stream(self.device).wait_event(self.copied[s])
-            yield views                                  # the consumer enqueues its kernels for this batch ...
-            self.consumed[s].record(torch.cuda.current_stream(self.device))
+            batch = PinnedFeeder.Batch(views, self, s)
+            yield batch                                  # the consumer enqueues its kernels for this batch ...
+            if not batch._released:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                self.consumed[s] = ev
             b = next(it, None)                           # ... and only then is the next slot refilled: the wait in _submit
             if b is not None:                            # is for the batch BEFORE the one just enqueued, so the GPU
                 pending.append((slot, self._submit(slot, b)))   # always has work queued while the host copies
