@@ -65,3 +65,28 @@ def test_frames_to_windows_pipeline_matches_host_assembly():
     host_f = np.stack([feats[a:b + 1] for a, b in win])
     np.testing.assert_allclose(wp.cpu().numpy(), host_p, rtol=0, atol=2.4e-7)
     np.testing.assert_array_equal(wf.cpu().numpy(), host_f)
+
+
+def test_feeder_with_pipeline_release_events():
+    """Feeder slots handed to pipeline lanes (released by the lane's completion event, not by the current stream):
+    every batch's outputs equal the direct forward of the same host data, with fewer slots than batches."""
+    from pmce_amd import assets, models, synth
+    J, B = 17, 6
+    model = models.PMCE.get_model(J, 256, 3)
+    model.load_state_dict(synth.make_state_dict(synth.pmce_spec(J, 256, 3), seed=123))
+    model.set_j_regressor(assets.load_j_regressor("h36m"))
+    model = model.to(DEV)
+    host = []
+    for i in range(7):
+        p, f = synth.make_inputs(B, J, 900 + i)
+        host.append({"pose2d": p, "img_feat": f})
+    want = [model(torch.from_numpy(h["pose2d"]).to(DEV), torch.from_numpy(h["img_feat"]).to(DEV))[0].clone() for h in host]
+    pipe = model.pipeline(depth=2)
+    feeder = staging.PinnedFeeder(DEV, {"pose2d": ((B, 16, J, 2), torch.float32), "img_feat": ((B, 16, 2048), torch.float32)}, slots=3)
+    tickets = []
+    for d in feeder.run(host):
+        t = pipe.submit(d["pose2d"], d["img_feat"], want_joints=False)
+        d.release(t.done)
+        tickets.append(t)
+    for w, t in zip(want, tickets):
+        assert torch.equal(t.result()[0], w)
