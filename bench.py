@@ -1,32 +1,94 @@
 #!/usr/bin/env python3
 """bench.py — PMCE hot-path throughput on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the full two-stream hot path (temporal pose encoder + CoEvoDecoder + 6890-vertex
-upsample + J_regressor projection) over one batch of synthetic 16-frame clips per GPU (BASELINE.json configs[2]:
-batch = 256, J = 17, C = 256), inputs resident in HBM.  Prints ONE JSON line (rank 0) with the whole-job clips/s,
-the roofline of the dominant kernel class (from HIP-event timings taken inside this run), and the oracle's CPU
-baseline on the host cores (rank 0, N = 1 only).
+N > 1: one process per GPU over RCCL.  Either the caller launches the ranks (`python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N`, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in the environment) or, when WORLD_SIZE is
+not set, this script spawns its own N ranks on 127.0.0.1 and relays rank 0's JSON line.
+
+A "step" is one pass of the full two-stream hot path (temporal pose encoder + CoEvoDecoder + 6890-vertex upsample +
+J_regressor projection) over one batch of synthetic 16-frame clips per GPU, inputs resident in HBM.  The headline
+configuration is the one BASELINE.json's north_star quotes throughput on — (B=256, T=16, J=17, C=512), BASELINE configs[2]
+batch — and the same line carries a second complete record for C=256, the width every reference config ships
+(`/root/reference/lib/core/config.py:59`).  Rank 0 prints ONE JSON line: whole-job clips/s (median of `--windows` timed
+windows of exactly K steps each, every window bracketed by barrier + synchronize, MAX over ranks), the roofline of the
+dominant kernel class and of the north-star cross-attention kernel (HIP events recorded inside this run on the launch
+stream), small-batch latency, and the oracle's CPU baseline on the host cores (rank 0, N = 1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 MFMA == fp32 vector peak
-PEAK_HBM_GBS = 8000.0       # HBM3E peak
+PEAK_HBM_GBS = 8000.0       # HBM3E peak (same guide; ~6.3 TB/s is what a streaming copy reaches)
+CLOCK_GHZ = 2.4
+N_SIMD = 1024               # 256 CUs x 4 SIMDs; one v_mfma_f32_32x32x2_f32 occupies a SIMD's matrix pipe for 64 cycles
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` without a launcher -> N ranks, one per GPU
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n: int, argv) -> int:
+    """Spawn n copies of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, rendezvous on 127.0.0.1), relay rank 0's
+    stdout, return the worst exit code.  A rank that dies takes the others down (no orphan holding a GPU)."""
+    import tempfile
+    port = _free_port()
+    out0 = tempfile.TemporaryFile(mode="w+")
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PMCE_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            time.sleep(0.1)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except Exception:  # noqa: BLE001
+                pass
+    out0.seek(0)
+    sys.stdout.write(out0.read())
+    sys.stdout.flush()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# analytical work (what measured times are divided into)
+# ------------------------------------------------------------------------------------------------------------------
 def gemm_lifter_flops(B, J, C, depth=3, T=16, F=2048):
     M = B * T * J
     return 2.0 * B * T * F * C + depth * 2 * (2.0 * M * C * 3 * C + 2.0 * M * C * C + 2 * 2.0 * M * C * 2 * C)
@@ -62,132 +124,149 @@ def class_work(name, B, J, C):
     return None, None
 
 
-def pmc_traffic_per_launch(kernel):
+def pmc_traffic_per_launch(kernel, C):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC pass of this same command
-    (profiles/pmc_hbm_traffic_per_launch.json, made by scripts/gpu_pmc.sh: separate FETCH_SIZE / WRITE_SIZE passes, KiB
+    (profiles/pmc_hbm_traffic_per_launch_C<C>.json, made by scripts/gpu_pmc.sh: separate FETCH_SIZE / WRITE_SIZE passes, KiB
     units, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction for wide coalesced reads).  bench.py cannot run
     the profiler on itself; without the file the field is null."""
-    path = os.path.join(REPO, "profiles", "pmc_hbm_traffic_per_launch.json")
-    if not os.path.exists(path):
-        return None, None
-    try:
-        data = json.load(open(path))
-        tot_b, tot_n = 0.0, 0
-        for name, v in data.items():
-            if kernel in name and v.get("launches", 0) > 0:
-                tot_b += v["launches"] * (2.0 * v["fetch_kib_raw"] + v["write_kib"]) * 1024.0
-                tot_n += v["launches"]
-        if tot_n == 0:
-            return None, None
-        return round(tot_b / tot_n), "profiles/pmc_hbm_traffic_per_launch.json (2*FETCH_SIZE + WRITE_SIZE, KiB, launch-weighted)"
-    except Exception:
-        return None, None
+    for fn in (f"pmc_hbm_traffic_per_launch_C{C}.json",) + (("pmc_hbm_traffic_per_launch.json",) if C == 256 else ()):
+        path = os.path.join(REPO, "profiles", fn)
+        if not os.path.exists(path):
+            continue
+        try:
+            data = json.load(open(path))
+            tot_b, tot_n = 0.0, 0
+            for name, v in data.items():
+                if kernel in name and v.get("launches", 0) > 0:
+                    tot_b += v["launches"] * (2.0 * v["fetch_kib_raw"] + v["write_kib"]) * 1024.0
+                    tot_n += v["launches"]
+            if tot_n:
+                return round(tot_b / tot_n), f"profiles/{fn} (2*FETCH_SIZE + WRITE_SIZE, KiB, launch-weighted)"
+        except Exception:  # noqa: BLE001
+            pass
+    return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
-    ap.add_argument("--joints", type=int, default=17)
-    ap.add_argument("--embed-dim", type=int, default=256)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--single-stream", action="store_true",
-                    help="keep every launch on one stream (profiling: rocprofv3 then prices each kernel alone)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--pipeline-depth", type=int, default=2,
-                    help="batches in flight (models.PMCE.Pipeline): a step's decoder overlaps the next step's pose lifter; "
-                         "1 = strictly one batch at a time")
-    ap.add_argument("--no-stagger", action="store_true", help="pipeline lanes free-run instead of starting a batch's lifter "
-                                                              "when the previous batch's has finished")
-    ap.add_argument("--no-host-fed", action="store_true", help="skip the extra (untimed-for-value) host-fed measurement")
-    ap.add_argument("--no-variant", action="store_true",
-                    help="skip the second timed configuration (the 512-wide pose encoder that BASELINE.json's north_star quotes "
-                         "throughput on; every reference config ships 256, which is what `value` is measured on)")
-    args = ap.parse_args()
+def north_star_record(kernel_ms, launches, B, J):
+    """The CoEvoDecoder vertex<-joint cross-attention (north_star's kernel) against its two floors.  After round 2 it is
+    fused with its FFN (`vertex_ca_mlp`); both floors are printed: HBM = SURVEY §8a(a8)'s 229,376 B per clip*direction*block
+    at the 8 TB/s peak, MFMA = the matrix instructions the fused kernel must issue (per 32-vertex wave tile: 64 score +
+    16*ceil(J/8) output + 512 FFN v_mfma_f32_32x32x2_f32 of 64 cycles each) spread perfectly over the 1024 SIMDs."""
+    name = "vertex_ca_mlp" if "vertex_ca_mlp" in kernel_ms else ("vertex_ca" if "vertex_ca" in kernel_ms else None)
+    if name is None:
+        return None
+    n = launches[name]
+    ms = kernel_ms[name] / n
+    byt = 229376.0 * B
+    tiles = B * 14
+    mfma_per_tile = 64 + 16 * ((J + 7) // 8) + (512 if name == "vertex_ca_mlp" else 0)
+    t_hbm = byt / (PEAK_HBM_GBS * 1e9) * 1e3
+    t_mfma = tiles * mfma_per_tile * 64 / N_SIMD / (CLOCK_GHZ * 1e9) * 1e3
+    floor = max(t_hbm, t_mfma)
+    ach = byt / (ms * 1e-3) / 1e9
+    return {"kernel": name, "bound": "hbm" if t_hbm >= t_mfma else "mfma", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
+            "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "bytes_per_clip_dir_block": 229376,
+            "avg_launch_ms": round(ms, 5), "hbm_floor_ms": round(t_hbm, 5), "mfma_floor_ms": round(t_mfma, 5),
+            "frac_of_floor": round(floor / ms, 4)}
 
+
+# ------------------------------------------------------------------------------------------------------------------
+def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full=True):
+    """Throughput + per-kernel-class timing of one configuration.  Returns (record, model, pipe, inputs)."""
+    import torch
     from pmce_amd import assets, models, sharding, synth
+    from pmce_amd.workload import flops_per_clip
 
-    rank, local, world = sharding.init_from_env()
-    assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
-    if os.environ.get("PMCE_BENCH_SHARE_GPU"):   # plumbing test of the N>1 path on a 1-GPU box (with PMCE_DIST_BACKEND=gloo)
-        local = 0
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-    B, J, C = args.batch, args.joints, args.embed_dim
-
-    # ---- model (random-init weights of the named architecture; no checkpoints exist offline) ----
-    sd = synth.make_state_dict(synth.pmce_spec(J, C, 3), seed=123)
+    assets.allow_synthetic_base_data()                                  # no SMPL-derived files offline: synthetic template
+    sd = synth.make_state_dict(synth.pmce_spec(J, C, 3), seed=123)      # random-init weights of the named architecture
     model = models.PMCE.get_model(J, C, 3)
     model.load_state_dict(sd)
     model.set_j_regressor(assets.load_j_regressor("h36m"))
     model = model.to(dev)
 
-    # ---- synthetic clips, resident in HBM; each rank gets its own shard of the global clip range ----
-    lo, hi = sharding.shard_range(B * world, rank, world)
-    pose2d_np, feat_np = synth.make_inputs(B, J, seed=1000 + rank)
-    pose2d = torch.from_numpy(pose2d_np).to(dev)
-    img_feat = torch.from_numpy(feat_np).to(dev)
+    # synthetic clips resident in HBM; NB distinct batches are rotated so that the timed loop's inputs (NB x 33.6 MB at
+    # B = 256) do not sit in the 256 MB Infinity Cache from one step to the next
+    NB = max(1, min(8, (288 << 20) // max(1, B * (16 * 2048 + 16 * J * 2) * 4) + 1))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1000 + rank)
+    inputs = []
+    for _ in range(NB):
+        p = torch.rand(B, 16, J, 2, device=dev, generator=gen) * 2 - 1                 # normalised screen coordinates
+        f = torch.relu(torch.randn(B, 16, 2048, device=dev, generator=gen))            # non-negative pooled CNN features
+        inputs.append((p, f))
 
     depth = 1 if args.single_stream else max(1, args.pipeline_depth)
     pipe = model.pipeline(depth, stagger=not args.no_stagger).prepare(B) if depth > 1 else None
-    last = [None]
-
-    def step():
-        # one pass of the hot path over one batch; with a pipeline the call returns once the batch is enqueued on its lane
-        # (every batch of the timed region is complete before the closing synchronize)
-        if pipe is None:
-            return model.forward_with_joints(pose2d, img_feat)
-        last[0] = pipe.submit(pose2d, img_feat)
-        return last[0]
-
     if args.single_stream:
         model.set_concurrency(False)
+    k = [0]
 
-    for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
+    def step():
+        p, f = inputs[k[0] % NB]
+        k[0] += 1
+        if pipe is None:
+            return model.forward_with_joints(p, f)
+        return pipe.submit(p, f)     # returns once the batch is enqueued on its lane; complete before the closing synchronize
+
+    out = None
+    for _ in range(max(warmup, 1)):  # packing / workspace allocation must not be inside the timed region
         out = step()
-    if args.warmup == 0:
-        out = step()   # packing / workspace allocation must not be inside the timed region
-    torch.cuda.synchronize()
-    sharding.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    sharding.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dt = sharding.reduce_max(dt, dev)
-    clips_per_s = B * world * args.steps / dt
+    win_ms = []
+    for _ in range(windows):
+        torch.cuda.synchronize()
+        sharding.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        torch.cuda.synchronize()
+        sharding.barrier()
+        torch.cuda.synchronize()
+        dt = sharding.reduce_max(time.perf_counter() - t0, dev)
+        win_ms.append(dt / steps * 1e3)
+    ms = statistics.median(win_ms)
+    clips_per_s = B * world / (ms * 1e-3)
 
     # final metric reduction — the only collective of the path (RCCL over xGMI): per-rank partial sums
     if pipe is not None:
         out = out.result()
-        step = lambda: model.forward_with_joints(pose2d, img_feat)   # the profiling / host-fed passes below run one batch at a time
     mesh, pose, pose3d, pred = out
     partial = torch.stack([pred.abs().sum().double(), mesh.abs().sum().double(),
                            torch.tensor(float(B), device=dev, dtype=torch.float64)])
     total = sharding.reduce_metric_sums(partial)
-    finite = bool(torch.isfinite(total).all().item())
+    finite = bool(torch.isfinite(total).all().item()) and int(total[2].item()) == B * world
 
-    # ---- per-kernel-class timing with HIP events on the launch stream (a few extra, untimed-for-value steps) ----
+    fpc = flops_per_clip(J, C)["total"]
+    rec = {"value": round(clips_per_s, 1), "unit": "clips/s", "ms_per_step": round(ms, 4),
+           "windows": {"n": windows, "steps_each": steps, "ms_per_step": [round(x, 4) for x in win_ms],
+                       "value_min": round(B * world / (max(win_ms) * 1e-3), 1),
+                       "value_max": round(B * world / (min(win_ms) * 1e-3), 1)},
+           "config": {"workload": f"full two-stream PMCE forward (temporal pose encoder + CoEvoDecoder + 6890-vertex upsample + "
+                                  f"J_regressor), batch={B}/GPU, T=16, J={J}, C={C}, random-init weights",
+                      "global_batch": B * world, "seq_len": 16, "joints": J, "embed_dim": C,
+                      "parallelism": f"clip-sharded dp{world}, weights replicated", "streams": 1 if args.single_stream else 2 * depth,
+                      "batches_in_flight": depth, "distinct_input_batches": NB},
+           "ref_equiv_tflops": round(fpc * clips_per_s / 1e12, 2), "outputs_finite": finite}
+    if not full:
+        return rec, model, pipe, inputs, sd
+
+    # ---- per-kernel-class timing with HIP events on the launch stream (a few extra, untimed-for-value steps, one batch
+    # at a time on one stream so that every launch is priced alone) ----
+    run1 = lambda: model.forward_with_joints(*inputs[0])
     model.profile(True)
     nprof = 3
     for _ in range(nprof):
-        step()
+        run1()
     torch.cuda.synchronize()
     prof = model.profile_read()
     model.profile(False)
     if args.single_stream:
         model.set_concurrency(False)
-    kernel_ms = {k: round(v[0] / nprof, 4) for k, v in prof.items() if v[1] > 0}
-    launches = {k: int(v[1] // nprof) for k, v in prof.items() if v[1] > 0}
-    # group timing classes by kernel function: the dominant KERNEL is what the roofline prices
+    kernel_ms = {k_: round(v[0] / nprof, 4) for k_, v in prof.items() if v[1] > 0}
+    launches = {k_: int(v[1] // nprof) for k_, v in prof.items() if v[1] > 0}
     by_kernel = {}
-    for k, v in kernel_ms.items():
-        by_kernel.setdefault(KERNEL_OF.get(k, k), []).append(k)
+    for k_ in kernel_ms:
+        by_kernel.setdefault(KERNEL_OF.get(k_, k_), []).append(k_)
     dominant = max(by_kernel, key=lambda kn: sum(kernel_ms[c] for c in by_kernel[kn]))
     dom_classes = by_kernel[dominant]
     dom_ms = sum(kernel_ms[c] for c in dom_classes)
@@ -198,7 +277,7 @@ def main():
         kind = works[0][1]
         work = sum(w[0] for w in works)
         secs = dom_ms * 1e-3
-        traffic, traffic_src = pmc_traffic_per_launch(dominant)
+        traffic, traffic_src = pmc_traffic_per_launch(dominant, C)
         common = {"kernel": dominant, "classes": dom_classes, "launches_per_step": dom_launches,
                   "avg_launch_ms": round(dom_ms / dom_launches, 5), "traffic": traffic, "traffic_source": traffic_src,
                   "algorithmic_per_launch": work / dom_launches}
@@ -210,126 +289,213 @@ def main():
             ach = work / secs / 1e9
             roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(ach / PEAK_HBM_GBS, 4), **common}
-    # the north-star kernel, always reported next to the dominant one
-    ca = None
-    if "vertex_ca" in kernel_ms:
-        w_ca, _ = class_work("vertex_ca", B, J, C)
-        ach = w_ca / (kernel_ms["vertex_ca"] * 1e-3) / 1e9
-        ca = {"kernel": "vertex_ca", "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-              "frac": round(ach / PEAK_HBM_GBS, 4), "bytes_per_clip_dir_block": 229376,
-              "avg_launch_ms": round(kernel_ms["vertex_ca"] / launches["vertex_ca"], 5)}
+    rec.update({"roofline": roofline, "roofline_cross_attention": north_star_record(kernel_ms, launches, B, J),
+                "kernel_ms_per_step": kernel_ms, "launches_per_step": launches,
+                "kernel_ms_total_single_stream": round(sum(kernel_ms.values()), 4)})
+    return rec, model, pipe, inputs, sd
 
-    # ---- the same measurement on the 512-wide pose encoder (north_star's "(B,T=16,J=17,C=512)"); all ranks take part ----
+
+def host_fed_record(model, pipe, dev, B, J, nfed):
+    """The same clips start in pageable host memory every step and travel through pmce_amd.staging.PinnedFeeder (memcpy to
+    a pinned ring, async H2D on a copy stream under the previous step's kernels).  Reported next to `value`, never as it."""
+    import torch
+    from pmce_amd import staging, synth
+    pose2d_np, feat_np = synth.make_inputs(B, J, seed=1000)
+    feeder = staging.PinnedFeeder(dev, {"pose2d": ((B, 16, J, 2), torch.float32), "img_feat": ((B, 16, 2048), torch.float32)}, slots=4)
+    it = feeder.run([{"pose2d": pose2d_np, "img_feat": feat_np}] * (nfed + 2))
+
+    def consume(d):
+        if pipe is None:
+            model.forward_with_joints(d["pose2d"], d["img_feat"])
+        else:                                    # two batches in flight here too: the slot is free when ITS lane is done
+            d.release(pipe.submit(d["pose2d"], d["img_feat"]).done)
+
+    for _ in range(2):                           # warm the pinned ring
+        consume(next(it))
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for d in it:
+        consume(d)
+    torch.cuda.synchronize()
+    t_fed = time.perf_counter() - t1
+    return {"value": round(B * nfed / t_fed, 1), "unit": "clips/s", "steps": nfed,
+            "h2d_bytes_per_step": int(pose2d_np.nbytes + feat_np.nbytes),
+            "path": "pageable host -> pinned ring (4 slots) -> async H2D on a copy stream -> forward (same batches in flight as `value`)"}
+
+
+def latency_record(model, dev, J, calls=200):
+    """Small-batch latency (the reference's demo runs the path at batch 1, main/run_demo.py:332,145): host-observed time
+    of one forward_with_joints + synchronize, p50/p99 over `calls` calls, eager launches and hipGraph replay."""
+    import torch
+    out = {}
+    for B in (1, 8):
+        p = torch.rand(B, 16, J, 2, device=dev) * 2 - 1
+        f = torch.relu(torch.randn(B, 16, 2048, device=dev))
+        rec = {}
+        for mode in ("eager", "graph"):
+            try:
+                if mode == "eager":
+                    run = lambda: model.forward_with_joints(p, f)
+                else:
+                    gf = model.graphed(B)
+                    run = lambda: gf(p, f)
+                for _ in range(10):
+                    run()
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(calls):
+                    t0 = time.perf_counter()
+                    run()
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                ts.sort()
+                rec[mode] = {"p50_ms": round(ts[len(ts) // 2], 4), "p99_ms": round(ts[min(len(ts) - 1, int(len(ts) * 0.99))], 4),
+                             "min_ms": round(ts[0], 4)}
+            except Exception as e:  # noqa: BLE001
+                rec[mode] = {"error": str(e)[:200]}
+        out[f"B{B}"] = rec
+    out["calls"] = calls
+    out["what"] = "forward_with_joints + device synchronize, host clock"
+    return out
+
+
+def cpu_baseline_record(sd, vj_relation, J, C, seconds):
+    """The oracle (a port of the reference forward: kind "port") on this box's host cores — a bounded sample."""
+    import torch
+    from oracle import pmce_oracle as O
+    from pmce_amd import synth
+    ncores = os.cpu_count() or 1
+    # torch's intra-op pool degrades badly when oversubscribed on many-core hosts: calibrate the thread count on a small
+    # batch (a few seconds), then time a bounded sample of batch-64 forwards with the best one.
+    p_cpu, f_cpu = (torch.from_numpy(a) for a in synth.make_inputs(64, J, seed=1))
+    best_t, best_rate = 1, 0.0
+    with torch.no_grad():
+        for nt in [t for t in (8, 16, 32, 64, 128) if t <= ncores] or [ncores]:
+            torch.set_num_threads(nt)
+            O.pmce_forward(sd, p_cpu[:2], f_cpu[:2], vj_relation)  # warm the pool
+            t1 = time.perf_counter()
+            O.pmce_forward(sd, p_cpu[:8], f_cpu[:8], vj_relation)
+            rate = 8 / (time.perf_counter() - t1)
+            if rate > best_rate:
+                best_t, best_rate = nt, rate
+        torch.set_num_threads(best_t)
+        cb = 64 if best_rate > 8 else 16
+        n, t_cpu = 0, 0.0
+        while t_cpu < seconds and n < 50:
+            t1 = time.perf_counter()
+            O.pmce_forward(sd, p_cpu[:cb], f_cpu[:cb], vj_relation)
+            t_cpu += time.perf_counter() - t1
+            n += 1
+        lat = []
+        for _ in range(5):                       # the demo's batch: one clip
+            t1 = time.perf_counter()
+            O.pmce_forward(sd, p_cpu[:1], f_cpu[:1], vj_relation)
+            lat.append((time.perf_counter() - t1) * 1e3)
+    return {"value": round(cb * n / t_cpu, 2), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host_logical_cpus": ncores, "ms_per_clip": round(t_cpu / (cb * n) * 1e3, 3),
+            "batch1_latency_ms": round(statistics.median(lat), 2),
+            "sample": f"{n} x batch-{cb} full forwards of oracle/pmce_oracle.py (torch CPU fp32, J={J}, C={C}), thread count "
+                      f"calibrated over 8..128 on batch-8 forwards; batch1_latency_ms = median of 5 single-clip forwards"}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; `value` is the median window")
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
+    ap.add_argument("--joints", type=int, default=17)
+    ap.add_argument("--embed-dim", type=int, default=512,
+                    help="pose-encoder width of the headline record: 512 = BASELINE.json north_star; 256 = the reference's shipped width")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="keep every launch on one stream (profiling: rocprofv3 then prices each kernel alone)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--pipeline-depth", type=int, default=2,
+                    help="batches in flight (models.PMCE.Pipeline): a step's decoder overlaps the next step's pose lifter; "
+                         "1 = strictly one batch at a time")
+    ap.add_argument("--no-stagger", action="store_true", help="pipeline lanes free-run instead of starting a batch's lifter "
+                                                              "when the previous batch's has finished")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the extra (untimed-for-value) host-fed measurement")
+    ap.add_argument("--no-latency", action="store_true", help="skip the B=1 / B=8 latency record")
+    ap.add_argument("--no-variant", action="store_true", help="skip the second complete record (the other pose-encoder width)")
+    ap.add_argument("--dist-check", action="store_true",
+                    help="rendezvous + the path's collectives only (no GPU work): what the non-GPU test of the N>1 entry point runs")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    import torch
+    from pmce_amd import sharding
+
+    rank, local, world = sharding.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}")
+
+    if args.dist_check:
+        import torch.distributed as dist
+        cdev = torch.device("cpu")
+        lo, hi = sharding.shard_range(1000, rank, world)
+        tot = sharding.reduce_metric_sums(torch.tensor([float(hi - lo), 1.0], dtype=torch.float64))
+        rows = sharding.gather_rows(torch.arange(lo, hi, dtype=torch.float32)[:, None])
+        tmax = sharding.reduce_max(float(rank), cdev)
+        sharding.barrier()
+        if rank == 0:
+            print(json.dumps({"dist_check": True, "n_gpus": world, "backend": dist.get_backend() if world > 1 else None,
+                              "clips": int(tot[0].item()), "ranks": int(tot[1].item()), "gathered": int(rows.shape[0]),
+                              "max_rank": int(tmax)}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ndev = torch.cuda.device_count()
+    if os.environ.get("PMCE_BENCH_SHARE_GPU"):   # plumbing runs of the N>1 path on a box with fewer GPUs (ranks share devices)
+        local = local % max(ndev, 1)
+    if local >= ndev:
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local} but only {ndev} GPU(s) are visible "
+                         f"(set PMCE_BENCH_SHARE_GPU=1 PMCE_DIST_BACKEND=gloo to let ranks share a device)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    B, J, C = args.batch, args.joints, args.embed_dim
+
+    head, model, pipe, inputs, sd = measure_config(args, dev, rank, world, J, C, B, args.steps, args.warmup, args.windows)
+
+    solo = rank == 0 and world == 1
+    host_fed = latency = cpu = None
+    if solo and not args.no_host_fed and not args.single_stream:
+        host_fed = host_fed_record(model, pipe, dev, B, J, max(5, min(args.steps, 20)))
+    if solo and not args.no_latency:
+        latency = latency_record(model, dev, J)
+    if solo and not args.no_cpu_baseline:
+        cpu = cpu_baseline_record(sd, model.vj_relation, J, C, args.cpu_seconds)
+    del model, pipe, inputs, sd
+    torch.cuda.empty_cache()
+
     variant = None
-    if not args.no_variant and not args.single_stream and C != 512:
-        C2 = 512
-        sd2 = synth.make_state_dict(synth.pmce_spec(J, C2, 3), seed=123)
-        model2 = models.PMCE.get_model(J, C2, 3)
-        model2.load_state_dict(sd2)
-        model2.set_j_regressor(assets.load_j_regressor("h36m"))
-        model2 = model2.to(dev)
-        pipe2 = model2.pipeline(depth, stagger=not args.no_stagger).prepare(B) if depth > 1 else None
-        run2 = (lambda: pipe2.submit(pose2d, img_feat)) if pipe2 else (lambda: model2.forward_with_joints(pose2d, img_feat))
-        k2 = max(5, min(args.steps, 10))
-        for _ in range(3):
-            o2 = run2()
-        torch.cuda.synchronize()
-        sharding.barrier()
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        for _ in range(k2):
-            o2 = run2()
-        torch.cuda.synchronize()
-        sharding.barrier()
-        torch.cuda.synchronize()
-        dt2 = sharding.reduce_max(time.perf_counter() - t2, dev)
-        o2 = o2.result() if pipe2 else o2
-        from pmce_amd.workload import flops_per_clip as _fpc
-        v2 = B * world * k2 / dt2
-        variant = {"config": {"workload": f"same path, pose encoder width C={C2} (BASELINE.json north_star), batch={B}/GPU, J={J}",
-                              "global_batch": B * world, "seq_len": 16, "joints": J, "embed_dim": C2, "batches_in_flight": depth},
-                   "value": round(v2, 1), "unit": "clips/s", "steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 4),
-                   "ref_equiv_tflops": round(_fpc(J, C2)["total"] * v2 / 1e12, 2),
-                   "outputs_finite": bool(torch.isfinite(o2[0]).all().item())}
-        del model2, pipe2, o2, sd2
+    if world == 1 and not args.no_variant and not args.single_stream and C in (256, 512):
+        C2 = 256 if C == 512 else 512
+        variant, m2, p2, i2, sd2 = measure_config(args, dev, rank, world, J, C2, B, args.steps, args.warmup, args.windows)
+        variant["why"] = ("the width every reference config ships (lib/core/config.py:59)" if C2 == 256
+                          else "BASELINE.json north_star's width")
+        if solo and not args.no_cpu_baseline:
+            variant["cpu_baseline"] = cpu_baseline_record(sd2, m2.vj_relation, J, C2, min(args.cpu_seconds, 8.0))
+        del m2, p2, i2, sd2
         torch.cuda.empty_cache()
 
-    # ---- host-fed rate (reported next to `value`, never as it): the same clips start in pageable host memory every step
-    # and travel through pmce_amd.staging.PinnedFeeder (memcpy to a pinned ring, async H2D on a copy stream that runs
-    # under the previous step's kernels) ----
-    host_fed = None
-    if rank == 0 and world == 1 and not args.no_host_fed and not args.single_stream:
-        from pmce_amd import staging
-        nfed = max(5, min(args.steps, 20))
-        feeder = staging.PinnedFeeder(dev, {"pose2d": ((B, 16, J, 2), torch.float32), "img_feat": ((B, 16, 2048), torch.float32)}, slots=4)
-        host_batches = [{"pose2d": pose2d_np, "img_feat": feat_np}] * (nfed + 2)
-        it = feeder.run(host_batches)
-
-        def consume(d):
-            if pipe is None:
-                model.forward_with_joints(d["pose2d"], d["img_feat"])
-            else:                                    # two batches in flight here too: the slot is free when ITS lane is done
-                d.release(pipe.submit(d["pose2d"], d["img_feat"]).done)
-
-        for _ in range(2):                       # warm the pinned ring
-            consume(next(it))
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for d in it:
-            consume(d)
-        torch.cuda.synchronize()
-        t_fed = time.perf_counter() - t1
-        host_fed = {"value": round(B * nfed / t_fed, 1), "unit": "clips/s", "steps": nfed,
-                    "h2d_bytes_per_step": int(pose2d_np.nbytes + feat_np.nbytes),
-                    "path": "pageable host -> pinned ring (4 slots) -> async H2D on a copy stream -> forward (same batches in flight as `value`)"}
-
-    # ---- CPU baseline: the oracle (a port of the reference forward) on this box's host cores ----
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import pmce_oracle as O
-        ncores = os.cpu_count() or 1
-        # torch's intra-op pool degrades badly when oversubscribed on many-core hosts: calibrate the thread count
-        # on a small batch (a few seconds), then time a bounded sample with the best one.
-        p_cpu, f_cpu = (torch.from_numpy(a) for a in synth.make_inputs(64, J, seed=1))
-        best_t, best_rate = 1, 0.0
-        with torch.no_grad():
-            for nt in [t for t in (8, 16, 32, 64, 128) if t <= ncores] or [ncores]:
-                torch.set_num_threads(nt)
-                O.pmce_forward(sd, p_cpu[:2], f_cpu[:2], model.vj_relation)  # warm the pool
-                t1 = time.perf_counter()
-                O.pmce_forward(sd, p_cpu[:8], f_cpu[:8], model.vj_relation)
-                rate = 8 / (time.perf_counter() - t1)
-                if rate > best_rate:
-                    best_t, best_rate = nt, rate
-            torch.set_num_threads(best_t)
-            cb = 64 if best_rate > 8 else 16
-            n, t_cpu = 0, 0.0
-            while t_cpu < args.cpu_seconds and n < 50:
-                t1 = time.perf_counter()
-                O.pmce_forward(sd, p_cpu[:cb], f_cpu[:cb], model.vj_relation)
-                t_cpu += time.perf_counter() - t1
-                n += 1
-        cpu = {"value": round(cb * n / t_cpu, 2), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-               "host_logical_cpus": ncores,
-               "sample": f"{n} x batch-{cb} full forwards of oracle/pmce_oracle.py (torch CPU fp32, J={J}, C={C}), "
-                         f"thread count calibrated over 8..128"}
-
     if rank == 0:
-        from pmce_amd.workload import flops_per_clip
-        flops_clip = flops_per_clip(J, C)["total"]
         line = {
-            "metric": "16-frame clips/s", "value": round(clips_per_s, 1), "unit": "clips/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "metric": "16-frame clips/s", "value": head["value"], "unit": "clips/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"full two-stream PMCE forward (temporal pose encoder + CoEvoDecoder + 6890-vertex "
-                                   f"upsample + J_regressor), batch={B}/GPU, T=16, J={J}, C={C}, random-init weights",
-                       "global_batch": B * world, "seq_len": 16, "joints": J, "embed_dim": C,
-                       "parallelism": f"clip-sharded dp{world}, weights replicated",
-                       "streams": 1 if args.single_stream else 2 * depth, "batches_in_flight": depth},
-            "roofline": roofline, "roofline_cross_attention": ca, "cpu_baseline": cpu, "host_fed": host_fed, "variant_c512": variant,
-            "kernel_ms_per_step": kernel_ms, "launches_per_step": launches,
-            "ref_equiv_tflops": round(flops_clip * clips_per_s / 1e12, 2) if flops_clip else None,
-            "outputs_finite": finite,
+            "config": head["config"], "roofline": head["roofline"], "roofline_cross_attention": head["roofline_cross_attention"],
+            "cpu_baseline": cpu, "windows": head["windows"], "host_fed": host_fed, "latency": latency,
+            f"variant_c{256 if C == 512 else 512}": variant,
+            "kernel_ms_per_step": head["kernel_ms_per_step"], "launches_per_step": head["launches_per_step"],
+            "kernel_ms_total_single_stream": head["kernel_ms_total_single_stream"],
+            "ref_equiv_tflops": head["ref_equiv_tflops"], "outputs_finite": head["outputs_finite"],
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -77,6 +77,13 @@ int pmce_decoder_forward(pmce_model* m, const float* joints, const float* img_fe
 int pmce_forward(pmce_model* m, const float* pose2d, const float* img_feat, float* cam_mesh, float* cam_pose,
                  float* pose3d, float* pred_pose, int batch, void* ws, size_t ws_bytes, pmce_stream_t stream);
 
+/* CoevoBlock.forward for ONE block k in 1..3 on explicit inputs (reference lib/models/CoevoDecoder.py:175-191):
+ * joints[B,J,3] (m), vt_in[B,431,3], g[B,2048] (AdaLN conditioning = y[seqlen//2], :229) -> vt_out[B,431,3]; joint_out[B,J,3]
+ * only for k == 3 (joints1/joints2 are discarded by Pose2Mesh.forward, :235-237), else NULL. */
+int pmce_coevo_block_forward(pmce_model* m, int k, const float* joints, const float* vt_in, const float* g, float* vt_out,
+                             float* joint_out, int batch, void* ws, size_t ws_bytes, pmce_stream_t stream);
+
+
 /* Streaming (stride-1 windows of ONE long sequence, lib/_img_utils.py:27-57): the window-independent per-frame work
  * (embedding + SpatialBlocks[0] + norm_s of the lifter, PoseEstimation.py:78-85; GRU layer-0 input projections) is done
  * once per frame into x0[L,J,C] and gi0[L,6144]; pmce_stream_forward then serves W windows (int32 win[W,2], inclusive

@@ -30,6 +30,7 @@ PROTOTYPES = {
     "pmce_lifter_forward": [C.c_void_p, _f, _f, _f, _i, _f, C.c_size_t, _s],
     "pmce_decoder_forward": [C.c_void_p, _f, _f, _f, _f, _i, _f, C.c_size_t, _s],
     "pmce_forward": [C.c_void_p, _f, _f, _f, _f, _f, _f, _i, _f, C.c_size_t, _s],
+    "pmce_coevo_block_forward": [C.c_void_p, _i, _f, _f, _f, _f, _f, _i, _f, C.c_size_t, _s],
     "pmce_stream_precompute": [C.c_void_p, _f, _f, _i, _f, _f, _f, C.c_size_t, _s],
     "pmce_stream_forward": [C.c_void_p, _f, _f, _f, _i, _i, _f, _f, _f, _f, _f, C.c_size_t, _s],
     "pmce_window_tokens_f32": [_f, _f, _f, _f, _f, _fl, _f, _f, _i, _i, _i, _i, _i, _s],

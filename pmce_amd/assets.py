@@ -64,10 +64,26 @@ def build_verts_joints_relation(joints: np.ndarray, vertices: np.ndarray) -> np.
     return np.argmin(d, axis=1).astype(np.int64)
 
 
+_ALLOW_SYNTHETIC = [False]
+
+
+def allow_synthetic_base_data(enable: bool = True):
+    """Opt in to the synthetic stand-ins for the SMPL-derived base data (tests, benchmarks and fixtures call this; so does
+    ``PMCE_SYNTHETIC_BASE_DATA=1``).  Without the opt-in a missing ``smpl_mean_vertices.npy`` / ``mesh_downsampling.npz``
+    raises, as the reference's ``np.load`` would (CoevoDecoder.py:194, mesh.py:59): ``vj_relation`` is derived from these
+    files and is not in the checkpoint, so a real checkpoint on a synthetic template gives plausible but wrong meshes."""
+    _ALLOW_SYNTHETIC[0] = bool(enable)
+
+
+def synthetic_base_data_allowed() -> bool:
+    return _ALLOW_SYNTHETIC[0] or os.environ.get("PMCE_SYNTHETIC_BASE_DATA", "") not in ("", "0")
+
+
 def load_base_data(base_dir: str | None = None):
-    """(mean_vertices[6890,3] f32, [D0, D1]) from ``cfg.DATASET.BASE_DATA_DIR`` when the user-supplied
-    SMPL-derived files exist (smpl_mean_vertices.npy, mesh_downsampling.npz — CoevoDecoder.py:194,
-    mesh.py:59), else the synthetic stand-ins of :func:`pmce_amd.synth.make_base_data`."""
+    """(mean_vertices[6890,3] f32, [D0, D1], source) from ``cfg.DATASET.BASE_DATA_DIR``: the user-supplied SMPL-derived
+    files (smpl_mean_vertices.npy, mesh_downsampling.npz — CoevoDecoder.py:194, mesh.py:59).  When they are missing:
+    FileNotFoundError, unless the caller opted in to the synthetic stand-ins of :func:`pmce_amd.synth.make_base_data`
+    (:func:`allow_synthetic_base_data`)."""
     base_dir = base_dir or cfg.DATASET.BASE_DATA_DIR
     mv = osp.join(base_dir, "smpl_mean_vertices.npy")
     md = osp.join(base_dir, "mesh_downsampling.npz")
@@ -77,6 +93,12 @@ def load_base_data(base_dir: str | None = None):
         z = np.load(md, encoding="latin1", allow_pickle=True)
         D = [sp.csr_matrix(d).astype(np.float32) for d in z["D"][:2]]
         return v, D, "files"
+    if not synthetic_base_data_allowed():
+        raise FileNotFoundError(
+            f"{mv} / {md} not found.  vj_relation (which joint every mesh vertex starts from) is derived from these "
+            "SMPL-derived files and is not stored in checkpoints; set cfg.DATASET.BASE_DATA_DIR (env PMCE_BASE_DATA_DIR) to "
+            "the reference's data/base_data.  Tests and benchmarks on synthetic weights opt in to a synthetic template with "
+            "pmce_amd.assets.allow_synthetic_base_data() or PMCE_SYNTHETIC_BASE_DATA=1.")
     from .synth import make_base_data
     v, D = make_base_data()
     return v, D, "synthetic"

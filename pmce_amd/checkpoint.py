@@ -55,11 +55,24 @@ def validate_state_dict(sd):
     return kind, J, C, depth
 
 
-def load_reference_checkpoint(path, map_location="cpu"):
+def torch_load_checkpoint(path, map_location="cpu", allow_pickle=False):
+    """torch.load restricted to tensors and plain containers (``weights_only=True``): a checkpoint file cannot execute
+    code.  Reference checkpoints (``{'epoch', 'model_state_dict', 'optim_state_dict', ...}`` of tensors and numbers,
+    main/train.py:57-64) load this way; ``allow_pickle=True`` is the explicit opt-in to the unrestricted unpickler for
+    files that carry other Python objects."""
+    try:
+        return torch.load(path, map_location=map_location, weights_only=True)
+    except Exception:  # noqa: BLE001
+        if not allow_pickle:
+            raise
+    return torch.load(path, map_location=map_location, weights_only=False)
+
+
+def load_reference_checkpoint(path, map_location="cpu", allow_pickle=False):
     """-> (state_dict, kind, num_joint, embed_dim, depth); raises ValueError("No checkpoint exists!") like the reference's
     load_checkpoint (lib/funcs_utils.py:122-128) when the file cannot be read."""
     try:
-        obj = torch.load(path, map_location=map_location, weights_only=False)
+        obj = torch_load_checkpoint(path, map_location, allow_pickle)
     except Exception as e:  # noqa: BLE001 - same contract as the reference
         raise ValueError("No checkpoint exists!\n", e)
     sd = packing.unwrap_checkpoint(obj)

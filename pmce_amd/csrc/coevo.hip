@@ -669,7 +669,8 @@ __global__ __launch_bounds__(256) void tokens_kv_kernel(const float* __restrict_
 // ======================================================================================================
 // joint_stream: the joint side of coevoblock3, one workgroup per clip (J <= 32 tokens; ~4 MFLOP, VALU).
 //   y = xq + proj(softmax(q K^T / sqrt(8)) V) over the 431 vertex keys, 8 heads of 8     (joint_CA_FFN, :83)
-//   stage 1 stops here (standalone cross-attention op).  Otherwise:
+//   stage 1 stops here (standalone cross-attention op); stage 4 skips the cross-attention block (self-attention block
+//   alone: the reference's Block module).  Otherwise:
 //   y += Mlp(AdaLN(y)) ; y += SA(AdaLN(y)) (8 heads over J) ; y += Mlp(AdaLN(y)) ; cam_pose = Wc*y + bc + jt
 // ======================================================================================================
 struct JointStreamW {
@@ -700,88 +701,90 @@ __global__ __launch_bounds__(256) void joint_stream_kernel(const float* __restri
     s_y[i * JLD + c] = v;
   }
   __syncthreads();
-  adaln_small(s_y, s_a, gb + w.i_normq * 128, J, tid);
-  __syncthreads();
-  lin_small<64, 64>(s_a, JLD, w.wq, w.bq, s_q, JLD, J, tid, false);
-  __syncthreads();
-  // ---- attention over 431 keys: thread (i,h) for i<J, h<8 (J*8 <= 256) ----
-  {
-    const int i = tid >> 3, h = tid & 7;
-    const bool act = i < J;
-    float qv[8], o[8];
-    const float scale = 0.35355339059327376220f * 1.44269504088896340736f;  // 8^-0.5 (8 heads of 8) * log2(e): 2^x softmax
-#pragma unroll
-    for (int d = 0; d < 8; ++d) {
-      qv[d] = act ? s_q[i * JLD + 8 * h + d] * scale : 0.f;
-      o[d] = 0.f;
-    }
-    float m = -INFINITY, l = 0.f;
-    const float* kvb = kv + (long long)b * NV * 128;
-    for (int j0 = 0; j0 < NV; j0 += 64) {
-      const int nj = min(64, NV - j0);
-      __syncthreads();
-      for (int idx = tid; idx < nj * 32; idx += 256) {
-        const int r = idx >> 5, c4 = idx & 31;
-        *reinterpret_cast<f32x4*>(&s_kv[r * 128 + 4 * c4]) =
-            *reinterpret_cast<const f32x4*>(kvb + (long long)(j0 + r) * 128 + 4 * c4);
+  if (stage != 4) {  // stage 4 = joint_SA_FFN alone on xq (the reference's Block module, CoevoDecoder.py:102-105)
+    adaln_small(s_y, s_a, gb + w.i_normq * 128, J, tid);
+    __syncthreads();
+    lin_small<64, 64>(s_a, JLD, w.wq, w.bq, s_q, JLD, J, tid, false);
+    __syncthreads();
+    // ---- attention over 431 keys: thread (i,h) for i<J, h<8 (J*8 <= 256) ----
+    {
+      const int i = tid >> 3, h = tid & 7;
+      const bool act = i < J;
+      float qv[8], o[8];
+      const float scale = 0.35355339059327376220f * 1.44269504088896340736f;  // 8^-0.5 (8 heads of 8) * log2(e): 2^x softmax
+  #pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        qv[d] = act ? s_q[i * JLD + 8 * h + d] * scale : 0.f;
+        o[d] = 0.f;
       }
-      __syncthreads();
-      if (act) {
-        for (int r = 0; r < nj; ++r) {
-          const f32x4 k0 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 8 * h]);
-          const f32x4 k1 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 8 * h + 4]);
-          const float sc = qv[0] * k0.x + qv[1] * k0.y + qv[2] * k0.z + qv[3] * k0.w + qv[4] * k1.x + qv[5] * k1.y +
-                           qv[6] * k1.z + qv[7] * k1.w;
-          const float mn = fmaxf(m, sc);
-          const float corr = __builtin_amdgcn_exp2f(m - mn), pj = __builtin_amdgcn_exp2f(sc - mn);
-          l = l * corr + pj;
-          const f32x4 v0 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 64 + 8 * h]);
-          const f32x4 v1 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 64 + 8 * h + 4]);
-          o[0] = o[0] * corr + pj * v0.x;
-          o[1] = o[1] * corr + pj * v0.y;
-          o[2] = o[2] * corr + pj * v0.z;
-          o[3] = o[3] * corr + pj * v0.w;
-          o[4] = o[4] * corr + pj * v1.x;
-          o[5] = o[5] * corr + pj * v1.y;
-          o[6] = o[6] * corr + pj * v1.z;
-          o[7] = o[7] * corr + pj * v1.w;
-          m = mn;
+      float m = -INFINITY, l = 0.f;
+      const float* kvb = kv + (long long)b * NV * 128;
+      for (int j0 = 0; j0 < NV; j0 += 64) {
+        const int nj = min(64, NV - j0);
+        __syncthreads();
+        for (int idx = tid; idx < nj * 32; idx += 256) {
+          const int r = idx >> 5, c4 = idx & 31;
+          *reinterpret_cast<f32x4*>(&s_kv[r * 128 + 4 * c4]) =
+              *reinterpret_cast<const f32x4*>(kvb + (long long)(j0 + r) * 128 + 4 * c4);
+        }
+        __syncthreads();
+        if (act) {
+          for (int r = 0; r < nj; ++r) {
+            const f32x4 k0 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 8 * h]);
+            const f32x4 k1 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 8 * h + 4]);
+            const float sc = qv[0] * k0.x + qv[1] * k0.y + qv[2] * k0.z + qv[3] * k0.w + qv[4] * k1.x + qv[5] * k1.y +
+                             qv[6] * k1.z + qv[7] * k1.w;
+            const float mn = fmaxf(m, sc);
+            const float corr = __builtin_amdgcn_exp2f(m - mn), pj = __builtin_amdgcn_exp2f(sc - mn);
+            l = l * corr + pj;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 64 + 8 * h]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 64 + 8 * h + 4]);
+            o[0] = o[0] * corr + pj * v0.x;
+            o[1] = o[1] * corr + pj * v0.y;
+            o[2] = o[2] * corr + pj * v0.z;
+            o[3] = o[3] * corr + pj * v0.w;
+            o[4] = o[4] * corr + pj * v1.x;
+            o[5] = o[5] * corr + pj * v1.y;
+            o[6] = o[6] * corr + pj * v1.z;
+            o[7] = o[7] * corr + pj * v1.w;
+            m = mn;
+          }
         }
       }
+      if (act) {
+        const float inv = 1.0f / l;
+  #pragma unroll
+        for (int d = 0; d < 8; ++d) s_a[i * JLD + 8 * h + d] = o[d] * inv;
+      }
     }
-    if (act) {
-      const float inv = 1.0f / l;
-#pragma unroll
-      for (int d = 0; d < 8; ++d) s_a[i * JLD + 8 * h + d] = o[d] * inv;
+    __syncthreads();
+    lin_small<64, 64>(s_a, JLD, w.proj_w, w.proj_b, s_q, JLD, J, tid, false);
+    __syncthreads();
+    for (int idx = tid; idx < J * 64; idx += 256) {
+      const int i = idx >> 6, c = idx & 63;
+      s_y[i * JLD + c] += s_q[i * JLD + c];
     }
-  }
-  __syncthreads();
-  lin_small<64, 64>(s_a, JLD, w.proj_w, w.proj_b, s_q, JLD, J, tid, false);
-  __syncthreads();
-  for (int idx = tid; idx < J * 64; idx += 256) {
-    const int i = idx >> 6, c = idx & 63;
-    s_y[i * JLD + c] += s_q[i * JLD + c];
-  }
-  __syncthreads();
-  if (stage == 1) {
-    for (int idx = tid; idx < J * 64; idx += 256) y_out[(long long)b * J * 64 + idx] = s_y[(idx >> 6) * JLD + (idx & 63)];
-    return;
-  }
-  // ---- FFN of the cross-attention block ----
-  adaln_small(s_y, s_a, gb + w.i_norm2 * 128, J, tid);
-  __syncthreads();
-  lin_small<64, 256>(s_a, JLD, w.fc1_w, w.fc1_b, s_h, 257, J, tid, true);
-  __syncthreads();
-  lin_small<256, 64>(s_h, 257, w.fc2_w, w.fc2_b, s_q, JLD, J, tid, false);
-  __syncthreads();
-  for (int idx = tid; idx < J * 64; idx += 256) {
-    const int i = idx >> 6, c = idx & 63;
-    s_y[i * JLD + c] += s_q[i * JLD + c];
-  }
-  __syncthreads();
-  if (stage == 2) {
-    for (int idx = tid; idx < J * 64; idx += 256) y_out[(long long)b * J * 64 + idx] = s_y[(idx >> 6) * JLD + (idx & 63)];
-    return;
+    __syncthreads();
+    if (stage == 1) {
+      for (int idx = tid; idx < J * 64; idx += 256) y_out[(long long)b * J * 64 + idx] = s_y[(idx >> 6) * JLD + (idx & 63)];
+      return;
+    }
+    // ---- FFN of the cross-attention block ----
+    adaln_small(s_y, s_a, gb + w.i_norm2 * 128, J, tid);
+    __syncthreads();
+    lin_small<64, 256>(s_a, JLD, w.fc1_w, w.fc1_b, s_h, 257, J, tid, true);
+    __syncthreads();
+    lin_small<256, 64>(s_h, 257, w.fc2_w, w.fc2_b, s_q, JLD, J, tid, false);
+    __syncthreads();
+    for (int idx = tid; idx < J * 64; idx += 256) {
+      const int i = idx >> 6, c = idx & 63;
+      s_y[i * JLD + c] += s_q[i * JLD + c];
+    }
+    __syncthreads();
+    if (stage == 2) {
+      for (int idx = tid; idx < J * 64; idx += 256) y_out[(long long)b * J * 64 + idx] = s_y[(idx >> 6) * JLD + (idx & 63)];
+      return;
+    }
   }
   // ---- self-attention block over the J joint tokens (8 heads of 8) ----
   adaln_small(s_y, s_a, gb + w.i_snorm1 * 128, J, tid);
@@ -932,11 +935,8 @@ extern "C" int pmce_adaln_mlp_f32(const float* xin, const float* GB, int gb_stri
   PMCE_REQUIRE(xin && GB && W1 && b1 && W2 && b2 && (yout || vt_out), "adaln_mlp: null pointer");
   PMCE_REQUIRE(!vt_out || (Wc && bc && vt_in), "adaln_mlp: coordinate head needs Wc, bc, vt_in");
   const size_t lds = (size_t)(256 * LDW64 + 64 * LDW256 + 256 + 64) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)adaln_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
+  static std::atomic<unsigned long long> attr{0};
+  PMCE_TRY(pmce_opt_in_lds((const void*)adaln_mlp_kernel, (int)lds, attr, "adaln_mlp"));
   hipLaunchKernelGGL(adaln_mlp_kernel, dim3(mlp_grid(B)), dim3(512), lds, stream, xin, GB, gb_stride, inst, W1, b1, W2, b2,
                      yout, Wc, bc, vt_in, vt_out, B);
   return pmce_check_launch("adaln_mlp");
@@ -969,9 +969,9 @@ extern "C" int pmce_tokens_kv_f32(const float* xk, const float* xv, const float*
 extern "C" int pmce_joint_stream_f32(const float* xq, const float* jQ, const float* kv, const float* GB, int gb_stride,
                                      const float* const* wptr, const int* inst, const float* jt, float* y_out,
                                      float* pose_out, int B, int J, int stage, hipStream_t stream) {
-  PMCE_REQUIRE(xq && kv && GB && wptr && inst, "joint_stream: null pointer");
+  PMCE_REQUIRE(xq && (kv || stage == 4) && GB && wptr && inst, "joint_stream: null pointer");
   PMCE_REQUIRE(J >= 1 && J <= 32 && B > 0, "joint_stream: J must be in 1..32");
-  PMCE_REQUIRE(stage >= 1 && stage <= 3, "joint_stream: stage must be 1 (CA), 2 (CA+FFN) or 3 (full)");
+  PMCE_REQUIRE(stage >= 1 && stage <= 4, "joint_stream: stage must be 1 (CA), 2 (CA+FFN), 3 (full) or 4 (SA block only)");
   JointStreamW w;
   w.wq = wptr[0]; w.bq = wptr[1]; w.proj_w = wptr[2]; w.proj_b = wptr[3];
   w.fc1_w = wptr[4]; w.fc1_b = wptr[5]; w.fc2_w = wptr[6]; w.fc2_b = wptr[7];

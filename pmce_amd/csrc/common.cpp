@@ -1,6 +1,7 @@
 // Host-side error slot + version for libpmce_hip.so (no global mutable state besides a thread-local string).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -20,6 +21,11 @@ int pmce_check_launch(const char* what) {
     return PMCE_ERR_LAUNCH;
   }
   return PMCE_OK;
+}
+
+int pmce_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
 }
 
 extern "C" const char* pmce_last_error_string(void) { return g_err; }

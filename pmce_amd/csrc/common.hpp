@@ -16,6 +16,27 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 void pmce_set_error(const char* fmt, ...);
 int pmce_check_launch(const char* what);
 
+// opt a kernel into > 64 KB of dynamic LDS, once per device (the attribute is per device: a process-wide flag would leave
+// the second GPU of a process without it).  `done` is the call site's static bit mask of devices already set.
+#ifdef __cplusplus
+#include <atomic>
+static inline int pmce_opt_in_lds(const void* fn, int bytes, std::atomic<unsigned long long>& done, const char* what) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) d = 0;
+  const unsigned long long bit = 1ull << d;
+  if (done.load(std::memory_order_relaxed) & bit) return PMCE_OK;
+  const hipError_t rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (rc != hipSuccess) {
+    pmce_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed: %s", what, bytes, hipGetErrorString(rc));
+    return PMCE_ERR_LAUNCH;
+  }
+  done.fetch_or(bit, std::memory_order_relaxed);
+  return PMCE_OK;
+}
+// integer environment knob, read once per process by its (function-local static) caller
+int pmce_env_int(const char* name, int dflt);
+#endif
+
 #define PMCE_REQUIRE(cond, ...)                \
   do {                                         \
     if (!(cond)) {                             \

@@ -410,10 +410,8 @@ static void launch_gemm(const GemmParams& p, int batch, bool cmap, hipStream_t s
 struct TileCfg { int bm, bn, bpc; double ovh; };
 static const TileCfg kTiles[] = {{128, 128, 2, 1.0}, {96, 128, 2, 1.015}, {64, 128, 3, 1.03}, {64, 64, 4, 1.03}};
 static int pick_tile(int M, int N, int batch) {
-  if (const char* e = getenv("PMCE_GEMM_TILE")) {  // tuning/debug knob: force a tile config (0..3)
-    const int v = atoi(e);
-    if (v >= 0 && v < 4) return v;
-  }
+  static const int forced = pmce_env_int("PMCE_GEMM_TILE", -1);  // tuning/debug knob, read once: force a tile config (0..3)
+  if (forced >= 0 && forced < 4) return forced;
   int best = 0;
   double best_cost = 1e300;
   for (int i = 0; i < 4; ++i) {
@@ -456,10 +454,8 @@ extern "C" int pmce_gemm_nt_f32(const float* A, const float* W, const float* bia
   p.ntm = (M + kTiles[ti].bm - 1) / kTiles[ti].bm;
   p.ntn = (N + kTiles[ti].bn - 1) / kTiles[ti].bn;
   p.grid_cap = 256 * kTiles[ti].bpc;
-  if (const char* e = getenv("PMCE_GEMM_GRID")) {  // tuning knob: persistent workgroups per CU
-    const int v = atoi(e);
-    if (v >= 1 && v <= 8) p.grid_cap = 256 * v;
-  }
+  static const int grid_knob = pmce_env_int("PMCE_GEMM_GRID", 0);  // tuning knob, read once: persistent workgroups per CU
+  if (grid_knob >= 1 && grid_knob <= 8) p.grid_cap = 256 * grid_knob;
   switch (ti) {
     case 0: launch_gemm<128, 128, 2>(p, batch, cmap, stream); break;
     case 1: launch_gemm<96, 128, 1>(p, batch, cmap, stream); break;

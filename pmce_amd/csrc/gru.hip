@@ -207,7 +207,7 @@ extern "C" int pmce_gru_step_f32(const float* gi0, const float* gi1, const float
   a.hprev[0] = hp0; a.hprev[1] = hp1; a.hout[0] = ho0; a.hout[1] = ho1;
   a.gi_rs = gi_rs; a.h_rs = h_rs; a.B = B; a.H = H;
   PMCE_REQUIRE((long long)B * h_rs * 4 < (1ll << 32) && 3ll * H * H * 4 < (1ll << 32), "gru_step: h or W_hh spans 4 GiB or more");
-  static const int nq = getenv("PMCE_GRU_NQ") ? atoi(getenv("PMCE_GRU_NQ")) : 4;  // tuning knob
+  static const int nq = pmce_env_int("PMCE_GRU_NQ", 4);  // tuning knob, read once
   if (nq == 2)
     hipLaunchKernelGGL((gru_step_kernel<2>), dim3(H / 32, (B + 63) / 64, ndir), dim3(256), 0, stream, a);
   else

@@ -332,19 +332,13 @@ extern "C" int pmce_seq_attention_f32(const float* qkv, float* out, int nseq, in
   if (seq_div <= 0) seq_div = 0x7fffffff;
   const size_t lds = (size_t)2 * N * C * sizeof(float);
   if (C == 256) {
-    static bool attr256 = false;
-    if (!attr256) {
-      (void)hipFuncSetAttribute((const void*)seq_attention_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-      attr256 = true;
-    }
+    static std::atomic<unsigned long long> attr256{0};
+    PMCE_TRY(pmce_opt_in_lds((const void*)seq_attention_kernel<32>, 65536, attr256, "seq_attention"));
     hipLaunchKernelGGL((seq_attention_kernel<32>), dim3(nseq), dim3(256), lds, stream, qkv, out, N, seq_div, seq_lo, seq_hi,
                        tok_stride);
   } else {
-    static bool attr512 = false;
-    if (!attr512) {
-      (void)hipFuncSetAttribute((const void*)seq_attention_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      attr512 = true;
-    }
+    static std::atomic<unsigned long long> attr512{0};
+    PMCE_TRY(pmce_opt_in_lds((const void*)seq_attention_kernel<64>, 131072, attr512, "seq_attention"));
     hipLaunchKernelGGL((seq_attention_kernel<64>), dim3(nseq), dim3(256), lds, stream, qkv, out, N, seq_div, seq_lo, seq_hi,
                        tok_stride);
   }

@@ -2,8 +2,10 @@
 // sequences of GraphormerNet.forward (reference lib/models/PoseEstimation.py:95-115), Pose2Mesh.forward
 // (lib/models/CoevoDecoder.py:226-246), PMCE.forward (lib/models/PMCE.py:15-20) and the caller's J_regressor
 // projection (lib/core/base.py:223-225).  No device memory is allocated here: weights and workspace belong to
-// the caller.  Everything is launched on the caller's stream, in order, with no host synchronisation, so a
-// forward is hipGraph-capturable.
+// the caller.  Launches go to the caller's stream and - for the branches that are independent of it - to one
+// internally created side stream, forked and joined with events (no host synchronisation: a forward is
+// hipGraph-capturable).  Every tensor pointer is resolved into a plain struct at pmce_model_finalize, so a launch
+// sequence does no string or map work (it matters at batch 1, the reference demo's batch: main/run_demo.py:332).
 #include <hip/hip_runtime.h>
 
 #include <stdlib.h>
@@ -36,12 +38,45 @@ struct Ev {
   int cls;
 };
 
+
+// ---- resolved tensor pointers (filled by pmce_model_finalize from the registered names) -----------------------
+struct LifterBlockW {
+  const float *norm1_w, *norm1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2_w, *norm2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+};
+struct VertexBlockW {  // vertex side of CoevoBlock k (+ the joint-side preparation every block needs)
+  const float *joint_proj_w, *joint_proj_b, *joint_pos, *j2v_w, *j2v_b, *j2v_K, *vertx_proj_w, *Eq;
+  const float *vca_wq_w, *vca_wq_b, *vca_wk_w, *vca_wk_b, *vca_wv_w, *vca_wv_b, *vca_proj_w, *vca_proj_b;
+  const float *vca_fc1_w, *vca_fc1_b, *vca_fc2_w, *vca_fc2_b;
+  const float *vsa_qkv_w, *vsa_qkv_b, *vsa_proj_w, *vsa_proj_b, *vsa_fc1_w, *vsa_fc1_b, *vsa_fc2_w, *vsa_fc2_b;
+  const float *vcoor_w, *vcoor_b;
+};
+struct JointBlockW {  // joint stream of CoevoBlock 3 (the only live one)
+  const float *Ev, *v2j_w, *Ek, *j_Q, *jca_wk_w, *jca_wk_b, *jca_wv_w, *jca_wv_b;
+  const float* stream[18];  // joint_stream's weight table (order: see pmce_joint_stream_f32)
+};
+struct Weights {
+  const float *je_w, *je_b, *ie_w, *ie_b, *spos, *tpos;
+  LifterBlockW blk[2][8];  // [0 spatial | 1 temporal][depth]
+  const float *ns_w, *ns_b, *nt_w, *nt_b, *reg0_w, *reg0_b, *reg1_w, *reg1_b, *fus_w, *fus_b;
+  const int* vj;
+  const float *wih0, *bih0, *whh0, *bhh0, *wih1, *bih1, *whh1, *bhh1, *ada_w, *ada_b;
+  VertexBlockW vb[3];
+  JointBlockW jb;
+  const float *final_w, *final_b;
+};
+struct Slot {
+  std::string name;
+  const void** dst;
+};
+
 }  // namespace
 
 struct pmce_model {
   int J, C, depth;
   std::vector<std::string> names;
+  std::vector<Slot> slots;  // names[i] -> field of `w`
   std::unordered_map<std::string, const void*> ptr;
+  Weights w = {};
   bool finalized = false;
   bool has_lifter = false, has_decoder = false;
   // second stream for the image-feature branch (created on first use, destroyed with the model)
@@ -61,8 +96,6 @@ struct pmce_model {
   double prof_ms[P_COUNT] = {0};
   long long prof_n[P_COUNT] = {0};
 
-  const float* f(const std::string& n) const { return static_cast<const float*>(ptr.at(n)); }
-  const int* i32(const std::string& n) const { return static_cast<const int*>(ptr.at(n)); }
 };
 
 namespace {
@@ -91,53 +124,139 @@ struct ProfScope {
   }
 };
 
+// fork/join primitives with checked return codes: a failed record/wait would silently race the two streams
+int ev_record(hipEvent_t e, hipStream_t s, const char* what) {
+  const hipError_t rc = hipEventRecord(e, s);
+  if (rc != hipSuccess) {
+    pmce_set_error("%s: hipEventRecord failed: %s", what, hipGetErrorString(rc));
+    return PMCE_ERR_LAUNCH;
+  }
+  return PMCE_OK;
+}
+int ev_wait(hipStream_t s, hipEvent_t e, const char* what) {
+  const hipError_t rc = hipStreamWaitEvent(s, e, 0);
+  if (rc != hipSuccess) {
+    pmce_set_error("%s: hipStreamWaitEvent failed: %s", what, hipGetErrorString(rc));
+    return PMCE_ERR_LAUNCH;
+  }
+  return PMCE_OK;
+}
+
 #define RUN(cls, call)             \
   do {                             \
     ProfScope _ps(m, cls, stream); \
     PMCE_TRY(call);                \
   } while (0)
 
-std::string blk(const char* kind, int i, const char* leaf) {
-  return std::string("lifter.") + kind + "Blocks." + std::to_string(i) + "." + leaf;
-}
-
+// Tensor names (what pmce_model_tensor_name enumerates) and, for each, the field of m->w it resolves into.
 void build_names(pmce_model* m) {
-  auto& n = m->names;
-  for (const char* s : {"lifter.joint_embed.weight", "lifter.joint_embed.bias", "lifter.imgfeat_embed.weight",
-                        "lifter.imgfeat_embed.bias", "lifter.spatial_pos_embed", "lifter.temporal_pos_embed"})
-    n.push_back(s);
-  for (const char* kind : {"Spatial", "Temporal"})
-    for (int i = 0; i < m->depth; ++i)
-      for (const char* leaf : {"norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight",
-                               "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias",
-                               "mlp.fc2.weight", "mlp.fc2.bias"})
-        n.push_back(blk(kind, i, leaf));
-  for (const char* s : {"lifter.norm_s.weight", "lifter.norm_s.bias", "lifter.norm_t.weight", "lifter.norm_t.bias",
-                        "lifter.regression.0.weight", "lifter.regression.0.bias", "lifter.regression.1.weight",
-                        "lifter.regression.1.bias", "lifter.fusion.weight", "lifter.fusion.bias"})
-    n.push_back(s);
-  for (const char* s : {"dec.vj_relation", "dec.gru.w_ih_l0", "dec.gru.b_ih_l0", "dec.gru.w_hh_l0", "dec.gru.b_hh_l0",
-                        "dec.gru.w_ih_l1", "dec.gru.b_ih_l1", "dec.gru.w_hh_l1", "dec.gru.b_hh_l1", "dec.ada.weight",
-                        "dec.ada.bias"})
-    n.push_back(s);
+  Weights& w = m->w;
+  auto add = [&](const std::string& n, const float*& field) {
+    m->names.push_back(n);
+    m->slots.push_back({n, reinterpret_cast<const void**>(&field)});
+  };
+  add("lifter.joint_embed.weight", w.je_w);
+  add("lifter.joint_embed.bias", w.je_b);
+  add("lifter.imgfeat_embed.weight", w.ie_w);
+  add("lifter.imgfeat_embed.bias", w.ie_b);
+  add("lifter.spatial_pos_embed", w.spos);
+  add("lifter.temporal_pos_embed", w.tpos);
+  for (int kind = 0; kind < 2; ++kind)
+    for (int i = 0; i < m->depth; ++i) {
+      const std::string p = std::string("lifter.") + (kind == 0 ? "Spatial" : "Temporal") + "Blocks." + std::to_string(i) + ".";
+      LifterBlockW& b = w.blk[kind][i];
+      add(p + "norm1.weight", b.norm1_w);
+      add(p + "norm1.bias", b.norm1_b);
+      add(p + "attn.qkv.weight", b.qkv_w);
+      add(p + "attn.qkv.bias", b.qkv_b);
+      add(p + "attn.proj.weight", b.proj_w);
+      add(p + "attn.proj.bias", b.proj_b);
+      add(p + "norm2.weight", b.norm2_w);
+      add(p + "norm2.bias", b.norm2_b);
+      add(p + "mlp.fc1.weight", b.fc1_w);
+      add(p + "mlp.fc1.bias", b.fc1_b);
+      add(p + "mlp.fc2.weight", b.fc2_w);
+      add(p + "mlp.fc2.bias", b.fc2_b);
+    }
+  add("lifter.norm_s.weight", w.ns_w);
+  add("lifter.norm_s.bias", w.ns_b);
+  add("lifter.norm_t.weight", w.nt_w);
+  add("lifter.norm_t.bias", w.nt_b);
+  add("lifter.regression.0.weight", w.reg0_w);
+  add("lifter.regression.0.bias", w.reg0_b);
+  add("lifter.regression.1.weight", w.reg1_w);
+  add("lifter.regression.1.bias", w.reg1_b);
+  add("lifter.fusion.weight", w.fus_w);
+  add("lifter.fusion.bias", w.fus_b);
+  m->names.push_back("dec.vj_relation");
+  m->slots.push_back({"dec.vj_relation", reinterpret_cast<const void**>(&w.vj)});
+  add("dec.gru.w_ih_l0", w.wih0);
+  add("dec.gru.b_ih_l0", w.bih0);
+  add("dec.gru.w_hh_l0", w.whh0);
+  add("dec.gru.b_hh_l0", w.bhh0);
+  add("dec.gru.w_ih_l1", w.wih1);
+  add("dec.gru.b_ih_l1", w.bih1);
+  add("dec.gru.w_hh_l1", w.whh1);
+  add("dec.gru.b_hh_l1", w.bhh1);
+  add("dec.ada.weight", w.ada_w);
+  add("dec.ada.bias", w.ada_b);
   for (int k = 1; k <= 3; ++k) {
     const std::string p = "dec.b" + std::to_string(k) + ".";
-    for (const char* leaf :
-         {"joint_proj.weight", "joint_proj.bias", "joint_pos_embed", "proj_j2v_dim.weight", "proj_j2v_dim.bias",
-          "j2v_K_embed", "vertx_proj.weight", "Eq", "vca.wq.weight", "vca.wq.bias", "vca.wk.weight", "vca.wk.bias",
-          "vca.wv.weight", "vca.wv.bias", "vca.proj.weight", "vca.proj.bias", "vca.mlp.fc1.weight", "vca.mlp.fc1.bias",
-          "vca.mlp.fc2.weight", "vca.mlp.fc2.bias", "vsa.qkv.weight", "vsa.qkv.bias", "vsa.proj.weight", "vsa.proj.bias",
-          "vsa.mlp.fc1.weight", "vsa.mlp.fc1.bias", "vsa.mlp.fc2.weight", "vsa.mlp.fc2.bias", "vcoor.weight", "vcoor.bias"})
-      n.push_back(p + leaf);
+    VertexBlockW& v = w.vb[k - 1];
+    add(p + "joint_proj.weight", v.joint_proj_w);
+    add(p + "joint_proj.bias", v.joint_proj_b);
+    add(p + "joint_pos_embed", v.joint_pos);
+    add(p + "proj_j2v_dim.weight", v.j2v_w);
+    add(p + "proj_j2v_dim.bias", v.j2v_b);
+    add(p + "j2v_K_embed", v.j2v_K);
+    add(p + "vertx_proj.weight", v.vertx_proj_w);
+    add(p + "Eq", v.Eq);
+    add(p + "vca.wq.weight", v.vca_wq_w);
+    add(p + "vca.wq.bias", v.vca_wq_b);
+    add(p + "vca.wk.weight", v.vca_wk_w);
+    add(p + "vca.wk.bias", v.vca_wk_b);
+    add(p + "vca.wv.weight", v.vca_wv_w);
+    add(p + "vca.wv.bias", v.vca_wv_b);
+    add(p + "vca.proj.weight", v.vca_proj_w);
+    add(p + "vca.proj.bias", v.vca_proj_b);
+    add(p + "vca.mlp.fc1.weight", v.vca_fc1_w);
+    add(p + "vca.mlp.fc1.bias", v.vca_fc1_b);
+    add(p + "vca.mlp.fc2.weight", v.vca_fc2_w);
+    add(p + "vca.mlp.fc2.bias", v.vca_fc2_b);
+    add(p + "vsa.qkv.weight", v.vsa_qkv_w);
+    add(p + "vsa.qkv.bias", v.vsa_qkv_b);
+    add(p + "vsa.proj.weight", v.vsa_proj_w);
+    add(p + "vsa.proj.bias", v.vsa_proj_b);
+    add(p + "vsa.mlp.fc1.weight", v.vsa_fc1_w);
+    add(p + "vsa.mlp.fc1.bias", v.vsa_fc1_b);
+    add(p + "vsa.mlp.fc2.weight", v.vsa_fc2_w);
+    add(p + "vsa.mlp.fc2.bias", v.vsa_fc2_b);
+    add(p + "vcoor.weight", v.vcoor_w);
+    add(p + "vcoor.bias", v.vcoor_b);
   }
-  for (const char* leaf :
-       {"Ev", "proj_v2j_dim.weight", "Ek", "j_Q_embed", "jca.wq.weight", "jca.wq.bias", "jca.wk.weight", "jca.wk.bias",
-        "jca.wv.weight", "jca.wv.bias", "jca.proj.weight", "jca.proj.bias", "jca.mlp.fc1.weight", "jca.mlp.fc1.bias",
-        "jca.mlp.fc2.weight", "jca.mlp.fc2.bias", "jsa.qkv.weight", "jsa.qkv.bias", "jsa.proj.weight", "jsa.proj.bias",
-        "jsa.mlp.fc1.weight", "jsa.mlp.fc1.bias", "jsa.mlp.fc2.weight", "jsa.mlp.fc2.bias", "jcoor.weight", "jcoor.bias"})
-    n.push_back(std::string("dec.b3.") + leaf);
-  n.push_back("dec.final.weight");
-  n.push_back("dec.final.bias");
+  {
+    const std::string p = "dec.b3.";
+    JointBlockW& j = w.jb;
+    add(p + "Ev", j.Ev);
+    add(p + "proj_v2j_dim.weight", j.v2j_w);
+    add(p + "Ek", j.Ek);
+    add(p + "j_Q_embed", j.j_Q);
+    const char* leaves[18] = {"jca.wq.weight",      "jca.wq.bias",      "jca.proj.weight",    "jca.proj.bias",
+                              "jca.mlp.fc1.weight", "jca.mlp.fc1.bias", "jca.mlp.fc2.weight", "jca.mlp.fc2.bias",
+                              "jsa.qkv.weight",     "jsa.qkv.bias",     "jsa.proj.weight",    "jsa.proj.bias",
+                              "jsa.mlp.fc1.weight", "jsa.mlp.fc1.bias", "jsa.mlp.fc2.weight", "jsa.mlp.fc2.bias",
+                              "jcoor.weight",       "jcoor.bias"};
+    // registration order of round 1 kept (jca.wk/wv sit between wq and proj there)
+    add(p + leaves[0], j.stream[0]);
+    add(p + leaves[1], j.stream[1]);
+    add(p + "jca.wk.weight", j.jca_wk_w);
+    add(p + "jca.wk.bias", j.jca_wk_b);
+    add(p + "jca.wv.weight", j.jca_wv_w);
+    add(p + "jca.wv.bias", j.jca_wv_b);
+    for (int i = 2; i < 18; ++i) add(p + leaves[i], j.stream[i]);
+  }
+  add("dec.final.weight", w.final_w);
+  add("dec.final.bias", w.final_b);
 }
 
 // ---- workspace carving ---------------------------------------------------------------------------------
@@ -201,21 +320,21 @@ int gemm(const float* A, const float* W, const float* bias, const float* R, floa
 // attention + MLP of one block (pre-norm input in w.XN, residual stream in w.X); kind 0 spatial, 1 temporal
 int lifter_block_body(pmce_model* m, int kind, int i, long long M, int nframes, int B, LifterWs& w, hipStream_t stream) {
   const int J = m->J, C = m->C;
-  const char* kn = kind == 0 ? "Spatial" : "Temporal";
-  RUN(P_GEMM_LIFTER, gemm(w.XN, m->f(blk(kn, i, "attn.qkv.weight")), m->f(blk(kn, i, "attn.qkv.bias")), nullptr, w.QKV,
+  const LifterBlockW& bw = m->w.blk[kind][i];
+  RUN(P_GEMM_LIFTER, gemm(w.XN, bw.qkv_w, bw.qkv_b, nullptr, w.QKV,
                           (int)M, 3 * C, C, C, 3 * C, 0, stream));
   if (kind == 0)  // sequences = frames, tokens j contiguous                        (PoseEstimation.py:78,101)
     RUN(P_SEQ_ATTN, pmce_seq_attention_f32(w.QKV, w.AO, nframes, J, C, 0, J, 0, 1, stream));
   else  // sequences = (b,j), tokens t at stride J                                  (PoseEstimation.py:87,104)
     RUN(P_SEQ_ATTN, pmce_seq_attention_f32(w.QKV, w.AO, B * J, T, C, J, 1, (long long)T * J, J, stream));
-  RUN(P_GEMM_LIFTER, gemm(w.AO, m->f(blk(kn, i, "attn.proj.weight")), m->f(blk(kn, i, "attn.proj.bias")), w.X, w.X, (int)M, C,
+  RUN(P_GEMM_LIFTER, gemm(w.AO, bw.proj_w, bw.proj_b, w.X, w.X, (int)M, C,
                           C, C, C, 0, stream));
-  RUN(P_LN, pmce_ln_chain_f32(w.X, M, C, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, m->f(blk(kn, i, "norm2.weight")),
-                              m->f(blk(kn, i, "norm2.bias")), 1e-6f, w.XN, stream));
+  RUN(P_LN, pmce_ln_chain_f32(w.X, M, C, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, bw.norm2_w,
+                              bw.norm2_b, 1e-6f, w.XN, stream));
   float* Hid = w.QKV;
-  RUN(P_GEMM_LIFTER, gemm(w.XN, m->f(blk(kn, i, "mlp.fc1.weight")), m->f(blk(kn, i, "mlp.fc1.bias")), nullptr, Hid, (int)M,
+  RUN(P_GEMM_LIFTER, gemm(w.XN, bw.fc1_w, bw.fc1_b, nullptr, Hid, (int)M,
                           2 * C, C, C, 2 * C, 1, stream));
-  RUN(P_GEMM_LIFTER, gemm(Hid, m->f(blk(kn, i, "mlp.fc2.weight")), m->f(blk(kn, i, "mlp.fc2.bias")), w.X, w.X, (int)M, C,
+  RUN(P_GEMM_LIFTER, gemm(Hid, bw.fc2_w, bw.fc2_b, w.X, w.X, (int)M, C,
                           2 * C, 2 * C, C, 0, stream));
   return PMCE_OK;
 }
@@ -225,12 +344,12 @@ int lifter_frames(pmce_model* m, const float* pose2d, const float* img_feat, int
   const int J = m->J, C = m->C;
   const long long M = (long long)nframes * J;
   PMCE_REQUIRE(M < (1ll << 31), "lifter: too many tokens");
-  RUN(P_GEMM_LIFTER, gemm(img_feat, m->f("lifter.imgfeat_embed.weight"), m->f("lifter.imgfeat_embed.bias"), nullptr, w.E,
+  RUN(P_GEMM_LIFTER, gemm(img_feat, m->w.ie_w, m->w.ie_b, nullptr, w.E,
                           nframes, C, F, F, C, 0, stream));
-  RUN(P_EMBED, pmce_embed_tokens_f32(pose2d, w.E, m->f("lifter.joint_embed.weight"), m->f("lifter.joint_embed.bias"),
-                                     m->f("lifter.spatial_pos_embed"), w.X, M, J, C, stream));
+  RUN(P_EMBED, pmce_embed_tokens_f32(pose2d, w.E, m->w.je_w, m->w.je_b,
+                                     m->w.spos, w.X, M, J, C, stream));
   RUN(P_LN, pmce_ln_chain_f32(w.X, M, C, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr,
-                              m->f(blk("Spatial", 0, "norm1.weight")), m->f(blk("Spatial", 0, "norm1.bias")), 1e-6f, w.XN,
+                              m->w.blk[0][0].norm1_w, m->w.blk[0][0].norm1_b, 1e-6f, w.XN,
                               stream));
   return lifter_block_body(m, 0, 0, M, nframes, 0, w, stream);
 }
@@ -239,16 +358,16 @@ int lifter_frames(pmce_model* m, const float* pose2d, const float* img_feat, int
 // spatial block, fused with the NEXT block's norm1
 int lifter_post_norm(pmce_model* m, int kind, int i, long long M, LifterWs& w, hipStream_t stream) {
   const int J = m->J, C = m->C;
-  const float* nw = m->f(kind == 0 ? "lifter.norm_s.weight" : "lifter.norm_t.weight");
-  const float* nb = m->f(kind == 0 ? "lifter.norm_s.bias" : "lifter.norm_t.bias");
-  const float* add = (kind == 0 && i == 0) ? m->f("lifter.temporal_pos_embed") : nullptr;
+  const float* nw = kind == 0 ? m->w.ns_w : m->w.nt_w;
+  const float* nb = kind == 0 ? m->w.ns_b : m->w.nt_b;
+  const float* add = (kind == 0 && i == 0) ? m->w.tpos : nullptr;
   const float *w2 = nullptr, *b2 = nullptr;
   if (kind == 0) {
-    w2 = m->f(blk("Temporal", i, "norm1.weight"));
-    b2 = m->f(blk("Temporal", i, "norm1.bias"));
+    w2 = m->w.blk[1][i].norm1_w;
+    b2 = m->w.blk[1][i].norm1_b;
   } else if (i + 1 < m->depth) {
-    w2 = m->f(blk("Spatial", i + 1, "norm1.weight"));
-    b2 = m->f(blk("Spatial", i + 1, "norm1.bias"));
+    w2 = m->w.blk[0][i + 1].norm1_w;
+    b2 = m->w.blk[0][i + 1].norm1_b;
   }
   RUN(P_LN, pmce_ln_chain_f32(w.X, M, C, nw, nb, 1e-6f, add, J, T, w.X, w2, b2, 1e-6f, w2 ? w.XN : nullptr, stream));
   return PMCE_OK;
@@ -265,9 +384,9 @@ int lifter_rest(pmce_model* m, float* pose3d, int B, LifterWs& w, hipStream_t st
       PMCE_TRY(lifter_post_norm(m, kind, i, M, w, stream));
     }
   }
-  RUN(P_HEAD, pmce_lifter_head_f32(w.X, m->f("lifter.regression.0.weight"), m->f("lifter.regression.0.bias"),
-                                   m->f("lifter.regression.1.weight"), m->f("lifter.regression.1.bias"),
-                                   m->f("lifter.fusion.weight"), m->f("lifter.fusion.bias"), pose3d, B, T, J, C, stream));
+  RUN(P_HEAD, pmce_lifter_head_f32(w.X, m->w.reg0_w, m->w.reg0_b,
+                                   m->w.reg1_w, m->w.reg1_b,
+                                   m->w.fus_w, m->w.fus_b, pose3d, B, T, J, C, stream));
   return PMCE_OK;
 }
 
@@ -282,9 +401,8 @@ int lifter_impl(pmce_model* m, const float* pose2d, const float* img_feat, float
 int gru_layer(pmce_model* m, int layer, const float* gi_f, const float* gi_b, long long gi_rs, int t_f0, int t_b0,
               int nsteps_f, int nsteps_b, float* Y, int B, hipStream_t stream) {
   // direction 0 walks t = t_f0, t_f0+1, ...; direction 1 walks t = t_b0, t_b0-1, ...  Y is [T][B][2*GH].
-  const std::string l = std::to_string(layer);
-  const float* whh = m->f("dec.gru.w_hh_l" + l);
-  const float* bhh = m->f("dec.gru.b_hh_l" + l);
+  const float* whh = layer == 0 ? m->w.whh0 : m->w.whh1;
+  const float* bhh = layer == 0 ? m->w.bhh0 : m->w.bhh1;
   const long long YS = (long long)B * 2 * GH;
   const int nsteps = nsteps_f > nsteps_b ? nsteps_f : nsteps_b;
   for (int s = 0; s < nsteps; ++s) {
@@ -318,7 +436,7 @@ int gru_rest(pmce_model* m, int B, DecoderWs& w, hipStream_t stream);
 int gru_part(pmce_model* m, const float* img_feat, int B, DecoderWs& w, hipStream_t stream) {
   // ---- bi-GRU over the 16 frames (CoevoDecoder.py:228); buffers are time-major [t][b][.] ----
   // layer 0 input projections for both directions in one product: rows (b,t) of img_feat -> rows (t,b) of GI0
-  RUN(P_GEMM_GRU_IN, pmce_gemm_nt_f32(img_feat, m->f("dec.gru.w_ih_l0"), m->f("dec.gru.b_ih_l0"), nullptr, w.GI0, B * T,
+  RUN(P_GEMM_GRU_IN, pmce_gemm_nt_f32(img_feat, m->w.wih0, m->w.bih0, nullptr, w.GI0, B * T,
                                       6 * GH, F, F, F, 6 * GH, 0, 0, 0, 0, T, (long long)B * 6 * GH, 6 * GH, 1, 0, 0, 0, 0,
                                       stream));
   return gru_rest(m, B, w, stream);
@@ -330,15 +448,15 @@ int gru_rest(pmce_model* m, int B, DecoderWs& w, hipStream_t stream) {
   // layer 1: only y[8] is consumed (CoevoDecoder.py:229,241-243) -> fwd needs t = 0..8, bwd t = 15..8.
   float* GI1f = w.GI1;
   float* GI1b = w.GI1 + (long long)9 * B * 3 * GH;
-  RUN(P_GEMM_GRU_IN, gemm(w.Y0, m->f("dec.gru.w_ih_l1"), m->f("dec.gru.b_ih_l1"), nullptr, GI1f, 9 * B, 3 * GH, 2 * GH, 2 * GH,
+  RUN(P_GEMM_GRU_IN, gemm(w.Y0, m->w.wih1, m->w.bih1, nullptr, GI1f, 9 * B, 3 * GH, 2 * GH, 2 * GH,
                           3 * GH, 0, stream));
-  RUN(P_GEMM_GRU_IN, gemm(w.Y0 + (long long)8 * B * 2 * GH, m->f("dec.gru.w_ih_l1") + (long long)3 * GH * 2 * GH,
-                          m->f("dec.gru.b_ih_l1") + 3 * GH, nullptr, GI1b, 8 * B, 3 * GH, 2 * GH, 2 * GH, 3 * GH, 0, stream));
+  RUN(P_GEMM_GRU_IN, gemm(w.Y0 + (long long)8 * B * 2 * GH, m->w.wih1 + (long long)3 * GH * 2 * GH,
+                          m->w.bih1 + 3 * GH, nullptr, GI1b, 8 * B, 3 * GH, 2 * GH, 2 * GH, 3 * GH, 0, stream));
   PMCE_TRY(gru_layer(m, 1, GI1f, GI1b, 3 * GH, 0, T - 1, 9, 8, w.Y1, B, stream));
   const float* g = w.Y1 + (long long)8 * B * 2 * GH;  // img_feat = y[seqlen // 2], [B, 2048]
 
   // ---- all live AdaLN gamma/beta in one product (CoevoDecoder.py:19-20,27-28) ----
-  RUN(P_GEMM_ADA, gemm(g, m->f("dec.ada.weight"), m->f("dec.ada.bias"), nullptr, w.GB, B, N_ADA * 128, 2 * GH, 2 * GH,
+  RUN(P_GEMM_ADA, gemm(g, m->w.ada_w, m->w.ada_b, nullptr, w.GB, B, N_ADA * 128, 2 * GH, 2 * GH,
                        N_ADA * 128, 0, stream));
   return PMCE_OK;
 }
@@ -347,15 +465,15 @@ int gru_rest(pmce_model* m, int B, DecoderWs& w, hipStream_t stream) {
 // cross-attention.  Depends only on the joints and the AdaLN parameters, not on the vertex stream.
 int joint_prep(pmce_model* m, int k, const float* joints, int B, DecoderWs& w, hipStream_t stream) {
   const int J = m->J;
-  const std::string p = "dec.b" + std::to_string(k) + ".";
+  const VertexBlockW& v = m->w.vb[k - 1];
   const int ib = (k - 1) * 6, gbs = N_ADA * 128;
-  RUN(P_JOINT_EMBED, pmce_joint_embed_f32(joints, m->f(p + "joint_proj.weight"), m->f(p + "joint_proj.bias"),
-                                          m->f(p + "joint_pos_embed"), m->f(p + "proj_j2v_dim.weight"),
-                                          m->f(p + "proj_j2v_dim.bias"), m->f(p + "j2v_K_embed"), w.JF[k - 1], w.XK[k - 1], B,
+  RUN(P_JOINT_EMBED, pmce_joint_embed_f32(joints, v.joint_proj_w, v.joint_proj_b,
+                                          v.joint_pos, v.j2v_w,
+                                          v.j2v_b, v.j2v_K, w.JF[k - 1], w.XK[k - 1], B,
                                           J, stream));
-  RUN(P_CA_FOLD, pmce_ca_fold_f32(w.XK[k - 1], w.JF[k - 1], w.GB, gbs, ib + 0, ib + 1, ib + 2, m->f(p + "vca.wq.weight"),
-                                  m->f(p + "vca.wq.bias"), m->f(p + "vca.wk.weight"), m->f(p + "vca.wk.bias"),
-                                  m->f(p + "vca.wv.weight"), m->f(p + "vca.wv.bias"), m->f(p + "vca.proj.weight"),
+  RUN(P_CA_FOLD, pmce_ca_fold_f32(w.XK[k - 1], w.JF[k - 1], w.GB, gbs, ib + 0, ib + 1, ib + 2, v.vca_wq_w,
+                                  v.vca_wq_b, v.vca_wk_w, v.vca_wk_b,
+                                  v.vca_wv_w, v.vca_wv_b, v.vca_proj_w,
                                   w.KF[k - 1], w.S0[k - 1], w.VF[k - 1], B, J, stream));
   return PMCE_OK;
 }
@@ -364,20 +482,34 @@ int joint_prep(pmce_model* m, int k, const float* joints, int B, DecoderWs& w, h
 int joint_branch(pmce_model* m, const float* joints, const float* vt_in, float* cam_pose, int B, DecoderWs& w,
                  hipStream_t stream) {
   const int J = m->J, gbs = N_ADA * 128;
-  const std::string p = "dec.b3.";
-  RUN(P_TOKENS_KV, pmce_tokens_kv_f32(nullptr, nullptr, vt_in, m->f(p + "vertx_proj.weight"), m->f(p + "Ev"),
-                                      m->f(p + "proj_v2j_dim.weight"), m->f(p + "Ek"), w.GB, gbs, 19, 20,
-                                      m->f(p + "jca.wk.weight"), m->f(p + "jca.wk.bias"), m->f(p + "jca.wv.weight"),
-                                      m->f(p + "jca.wv.bias"), w.KVJ, B, stream));
-  const float* wp[18] = {m->f(p + "jca.wq.weight"),      m->f(p + "jca.wq.bias"),      m->f(p + "jca.proj.weight"),
-                         m->f(p + "jca.proj.bias"),      m->f(p + "jca.mlp.fc1.weight"), m->f(p + "jca.mlp.fc1.bias"),
-                         m->f(p + "jca.mlp.fc2.weight"), m->f(p + "jca.mlp.fc2.bias"), m->f(p + "jsa.qkv.weight"),
-                         m->f(p + "jsa.qkv.bias"),       m->f(p + "jsa.proj.weight"),  m->f(p + "jsa.proj.bias"),
-                         m->f(p + "jsa.mlp.fc1.weight"), m->f(p + "jsa.mlp.fc1.bias"), m->f(p + "jsa.mlp.fc2.weight"),
-                         m->f(p + "jsa.mlp.fc2.bias"),   m->f(p + "jcoor.weight"),     m->f(p + "jcoor.bias")};
+  const JointBlockW& jw = m->w.jb;
+  RUN(P_TOKENS_KV, pmce_tokens_kv_f32(nullptr, nullptr, vt_in, m->w.vb[2].vertx_proj_w, jw.Ev,
+                                      jw.v2j_w, jw.Ek, w.GB, gbs, 19, 20,
+                                      jw.jca_wk_w, jw.jca_wk_b, jw.jca_wv_w,
+                                      jw.jca_wv_b, w.KVJ, B, stream));
   const int inst[4] = {18, 21, 22, 23};
-  RUN(P_JOINT_STREAM, pmce_joint_stream_f32(w.JF[2], m->f(p + "j_Q_embed"), w.KVJ, w.GB, gbs, wp, inst, joints, nullptr,
+  RUN(P_JOINT_STREAM, pmce_joint_stream_f32(w.JF[2], jw.j_Q, w.KVJ, w.GB, gbs, jw.stream, inst, joints, nullptr,
                                             cam_pose, B, J, 3, stream));
+  return PMCE_OK;
+}
+
+// vertex stream of CoevoBlock k (CoevoDecoder.py:183-189, vertex side): cross-attention from the joints (folded operands
+// of joint_prep), its FFN, the self-attention block, coordinate head + residual.  vt_cur -> vt_next ([B,431,3]).
+int vertex_block(pmce_model* m, int k, const float* vt_cur, float* vt_next, int B, DecoderWs& w, hipStream_t stream) {
+  const int J = m->J, gbs = N_ADA * 128;
+  const VertexBlockW& v = m->w.vb[k - 1];
+  const int ib = (k - 1) * 6;  // AdaLN instances: vca.normq,normk,normv,norm2, vsa.norm1,norm2
+  RUN(P_VERTEX_CA, pmce_vertex_ca_f32(nullptr, vt_cur, v.vertx_proj_w, v.Eq, w.KF[k - 1],
+                                      w.S0[k - 1], w.VF[k - 1], v.vca_proj_b, w.F1, B, J, stream));
+  RUN(P_ADALN_MLP, pmce_adaln_mlp_f32(w.F1, w.GB, gbs, ib + 3, v.vca_fc1_w, v.vca_fc1_b,
+                                      v.vca_fc2_w, v.vca_fc2_b, w.F2, nullptr, nullptr,
+                                      nullptr, nullptr, B, stream));
+  RUN(P_ADALN_QKV, pmce_adaln_qkv_f32(w.F2, w.GB, gbs, ib + 4, v.vsa_qkv_w, v.vsa_qkv_b, w.QKV, B,
+                                      stream));
+  RUN(P_VERTEX_SA, pmce_vertex_sa_f32(w.F2, w.QKV, v.vsa_proj_w, v.vsa_proj_b, w.F1, B, stream));
+  RUN(P_ADALN_MLP, pmce_adaln_mlp_f32(w.F1, w.GB, gbs, ib + 5, v.vsa_fc1_w, v.vsa_fc1_b,
+                                      v.vsa_fc2_w, v.vsa_fc2_b, nullptr,
+                                      v.vcoor_w, v.vcoor_b, vt_cur, vt_next, B, stream));
   return PMCE_OK;
 }
 
@@ -388,64 +520,64 @@ int coevo_part(pmce_model* m, const float* joints, float* cam_pose, float* cam_m
                hipStream_t stream, hipStream_t side) {
   const int J = m->J;
   const float* g = w.Y1 + (long long)8 * B * 2 * GH;
-  const int gbs = N_ADA * 128;
   if (side) {
-    (void)hipEventRecord(m->ev_a, stream);  // joints and AdaLN parameters are ready
-    (void)hipStreamWaitEvent(side, m->ev_a, 0);
+    PMCE_TRY(ev_record(m->ev_a, stream, "coevo fork a"));  // joints and AdaLN parameters are ready
+    PMCE_TRY(ev_wait(side, m->ev_a, "coevo fork a"));
     PMCE_TRY(joint_prep(m, 2, joints, B, w, side));
     PMCE_TRY(joint_prep(m, 3, joints, B, w, side));
-    (void)hipEventRecord(m->ev_b, side);
+    PMCE_TRY(ev_record(m->ev_b, side, "coevo join b"));
   }
   // ---- vertex init (CoevoDecoder.py:232) ----
-  RUN(P_GATHER, pmce_vertex_init_gather_f32(joints, m->i32("dec.vj_relation"), w.VT[0], B, J, stream));
+  RUN(P_GATHER, pmce_vertex_init_gather_f32(joints, m->w.vj, w.VT[0], B, J, stream));
   PMCE_TRY(joint_prep(m, 1, joints, B, w, stream));
   float* vt_cur = w.VT[0];
   for (int k = 1; k <= 3; ++k) {
-    const std::string p = "dec.b" + std::to_string(k) + ".";
     float* vt_next = w.VT[k % 3];
-    const int ib = (k - 1) * 6;  // AdaLN instances: vca.normq,normk,normv,norm2, vsa.norm1,norm2
     if (k > 1) {
       if (side) {
-        if (k == 2) (void)hipStreamWaitEvent(stream, m->ev_b, 0);
+        if (k == 2) PMCE_TRY(ev_wait(stream, m->ev_b, "coevo join b"));
       } else {
         PMCE_TRY(joint_prep(m, k, joints, B, w, stream));
       }
     }
     if (k == 3) {
       if (side) {
-        (void)hipEventRecord(m->ev_c, stream);  // block-3 input vertices are ready
-        (void)hipStreamWaitEvent(side, m->ev_c, 0);
+        PMCE_TRY(ev_record(m->ev_c, stream, "coevo fork c"));  // block-3 input vertices are ready
+        PMCE_TRY(ev_wait(side, m->ev_c, "coevo fork c"));
         PMCE_TRY(joint_branch(m, joints, vt_cur, cam_pose, B, w, side));
-        (void)hipEventRecord(m->ev_d, side);
+        PMCE_TRY(ev_record(m->ev_d, side, "coevo join d"));
       }
     }
-    RUN(P_VERTEX_CA, pmce_vertex_ca_f32(nullptr, vt_cur, m->f(p + "vertx_proj.weight"), m->f(p + "Eq"), w.KF[k - 1],
-                                        w.S0[k - 1], w.VF[k - 1], m->f(p + "vca.proj.bias"), w.F1, B, J, stream));
-    RUN(P_ADALN_MLP, pmce_adaln_mlp_f32(w.F1, w.GB, gbs, ib + 3, m->f(p + "vca.mlp.fc1.weight"), m->f(p + "vca.mlp.fc1.bias"),
-                                        m->f(p + "vca.mlp.fc2.weight"), m->f(p + "vca.mlp.fc2.bias"), w.F2, nullptr, nullptr,
-                                        nullptr, nullptr, B, stream));
-    RUN(P_ADALN_QKV, pmce_adaln_qkv_f32(w.F2, w.GB, gbs, ib + 4, m->f(p + "vsa.qkv.weight"), m->f(p + "vsa.qkv.bias"), w.QKV, B,
-                                        stream));
-    RUN(P_VERTEX_SA, pmce_vertex_sa_f32(w.F2, w.QKV, m->f(p + "vsa.proj.weight"), m->f(p + "vsa.proj.bias"), w.F1, B, stream));
-    RUN(P_ADALN_MLP, pmce_adaln_mlp_f32(w.F1, w.GB, gbs, ib + 5, m->f(p + "vsa.mlp.fc1.weight"), m->f(p + "vsa.mlp.fc1.bias"),
-                                        m->f(p + "vsa.mlp.fc2.weight"), m->f(p + "vsa.mlp.fc2.bias"), nullptr,
-                                        m->f(p + "vcoor.weight"), m->f(p + "vcoor.bias"), vt_cur, vt_next, B, stream));
+    PMCE_TRY(vertex_block(m, k, vt_cur, vt_next, B, w, stream));
     if (k == 3 && !side) PMCE_TRY(joint_branch(m, joints, vt_cur, cam_pose, B, w, stream));
     vt_cur = vt_next;
   }
   // ---- 431 -> 6890 upsample conv + 3 residual Linear(2048->6890) as ONE product (CoevoDecoder.py:238-244) ----
   RUN(P_FINAL_OP, pmce_build_final_operand_f32(g, vt_cur, w.FA, B, FINAL_K, stream));
-  RUN(P_GEMM_FINAL, gemm(w.FA, m->f("dec.final.weight"), m->f("dec.final.bias"), nullptr, cam_mesh, B, NVF * 3, FINAL_K,
+  RUN(P_GEMM_FINAL, gemm(w.FA, m->w.final_w, m->w.final_b, nullptr, cam_mesh, B, NVF * 3, FINAL_K,
                          FINAL_K, NVF * 3, 0, stream));
-  if (side) (void)hipStreamWaitEvent(stream, m->ev_d, 0);  // cam_pose is written by the side stream
+  if (side) PMCE_TRY(ev_wait(stream, m->ev_d, "coevo join d"));  // cam_pose is written by the side stream
   return PMCE_OK;
 }
 
 // second stream + fork/join events, created on first use
 // pmce_model_wait_lifter: the point of a forward after which only its decoder is left
-void mark_lifter_done(pmce_model* m, hipStream_t stream) {
-  if (!m->ev_lifter) (void)hipEventCreateWithFlags(&m->ev_lifter, hipEventDisableTiming);
-  if (m->ev_lifter) (void)hipEventRecord(m->ev_lifter, stream);
+int mark_lifter_done(pmce_model* m, hipStream_t stream) {
+  if (!m->ev_lifter && hipEventCreateWithFlags(&m->ev_lifter, hipEventDisableTiming) != hipSuccess) {
+    m->ev_lifter = nullptr;
+    pmce_set_error("could not create the lifter-done event: %s", hipGetErrorString(hipGetLastError()));
+    return PMCE_ERR_LAUNCH;
+  }
+  return ev_record(m->ev_lifter, stream, "lifter done");
+}
+
+// A launch sequence that failed after its fork leaves the side stream un-joined: the next forward on this handle would
+// race it on the shared workspace.  Drain both streams before reporting the error (error path only; never taken inside a
+// successful, capturable forward).
+int fail_after_fork(pmce_model* m, hipStream_t stream, int rc) {
+  if (m->side) (void)hipStreamSynchronize(m->side);
+  (void)hipStreamSynchronize(stream);
+  return rc;
 }
 
 int ensure_side(pmce_model* m) {
@@ -547,6 +679,11 @@ int pmce_model_finalize(pmce_model* m) {
   PMCE_REQUIRE(!any_d || all_d, "model_finalize: decoder tensor '%s' was never registered", missing_d ? missing_d : "?");
   m->has_lifter = all_l && any_l;
   m->has_decoder = all_d && any_d;
+  // resolve every registered name into its field of m->w: launch sequences read plain pointers from here on
+  for (auto& sl : m->slots) {
+    auto it = m->ptr.find(sl.name);
+    *sl.dst = it == m->ptr.end() ? nullptr : it->second;
+  }
   m->finalized = true;
   return PMCE_OK;
 }
@@ -572,6 +709,7 @@ long long pmce_model_workspace_offset(const pmce_model* m, int batch, const char
   const float* p = nullptr;
   if (n == "X") p = lw.X;                                                  // lifter tokens [B,16,J,C]
   else if (n == "Y0") p = dw.Y0;                                           // GRU layer-0 output [16,B,2048]
+  else if (n == "Y1") p = dw.Y1;                                           // GRU layer-1 output [16,B,2048] (pruned steps unset)
   else if (n == "g") p = dw.Y1 + (long long)8 * batch * 2 * GH;            // y[8] [B,2048]
   else if (n == "GB") p = dw.GB;                                           // AdaLN gamma|beta [B,24*128]
   else if (n == "VT0") p = dw.VT[0];                                       // after a forward: v3
@@ -618,7 +756,55 @@ int pmce_decoder_forward(pmce_model* m, const float* joints, const float* img_fe
   carve_decoder(c, m, batch, dw);
   PMCE_TRY(gru_part(m, img_feat, batch, dw, stream));
   if (m->concurrent) PMCE_TRY(ensure_side(m));
-  return coevo_part(m, joints, cam_pose, cam_mesh, batch, dw, stream, m->concurrent ? m->side : nullptr);
+  const int rc = coevo_part(m, joints, cam_pose, cam_mesh, batch, dw, stream, m->concurrent ? m->side : nullptr);
+  return rc == PMCE_OK ? rc : fail_after_fork(m, stream, rc);
+}
+
+// CoevoBlock.forward for ONE block k in 1..3 (CoevoDecoder.py:175-191) on explicit inputs: joints[B,J,3] (m), vt_in[B,431,3],
+// g[B,2048] (the AdaLN conditioning, y[seqlen//2]) -> vt_out[B,431,3] and, for k == 3 (the only block whose joint stream is
+// live at inference), joint_out[B,J,3].  Operator-level entry for parity tests against the reference module's own outputs.
+int pmce_coevo_block_forward(pmce_model* m, int k, const float* joints, const float* vt_in, const float* g, float* vt_out,
+                             float* joint_out, int batch, void* ws, size_t ws_bytes, pmce_stream_t stream) {
+  PMCE_TRY(check_ws(m, batch, ws, ws_bytes));
+  PMCE_REQUIRE(m->has_decoder, "coevo_block_forward: decoder tensors not registered");
+  PMCE_REQUIRE(k >= 1 && k <= 3, "coevo_block_forward: k must be 1, 2 or 3");
+  PMCE_REQUIRE(joints && vt_in && g && vt_out, "coevo_block_forward: null pointer");
+  PMCE_REQUIRE(!joint_out || k == 3, "coevo_block_forward: the joint stream is live in block 3 only (CoevoDecoder.py:235-237)");
+  Carver c(ws, ws_bytes);
+  LifterWs lw;
+  DecoderWs dw;
+  carve_lifter(c, m, batch, lw);
+  carve_decoder(c, m, batch, dw);
+  RUN(P_GEMM_ADA, gemm(g, m->w.ada_w, m->w.ada_b, nullptr, dw.GB, batch, N_ADA * 128, 2 * GH, 2 * GH, N_ADA * 128, 0, stream));
+  PMCE_TRY(joint_prep(m, k, joints, batch, dw, stream));
+  if (joint_out) PMCE_TRY(joint_branch(m, joints, vt_in, joint_out, batch, dw, stream));
+  return vertex_block(m, k, vt_in, vt_out, batch, dw, stream);
+}
+
+static int forward_impl(pmce_model* m, const float* pose2d, const float* img_feat, float* cam_mesh, float* cam_pose,
+                        float* pose3d, float* pred_pose, int batch, LifterWs& lw, DecoderWs& dw, hipStream_t stream) {
+  // Fork: the GRU / AdaLN-parameter branch depends only on img_feat; it runs on a second (high-priority) stream
+  // under the pose lifter, whose long matrix-core kernels leave the gaps its 25 short dependent steps need.
+  // pmce_model_set_concurrency(m, 0) (or PMCE_SINGLE_STREAM=1 at create time) keeps everything on one stream.
+  const bool single = !m->concurrent;
+  if (!single) {
+    PMCE_TRY(ev_record(m->ev_fork, stream, "forward fork"));
+    PMCE_TRY(ev_wait(m->side, m->ev_fork, "forward fork"));
+    PMCE_TRY(gru_part(m, img_feat, batch, dw, m->side));
+    PMCE_TRY(ev_record(m->ev_join, m->side, "forward join"));
+  } else {
+    PMCE_TRY(gru_part(m, img_feat, batch, dw, stream));
+  }
+  PMCE_TRY(lifter_impl(m, pose2d, img_feat, pose3d, batch, lw, stream));
+  // pose3d.reshape(-1, J, 3) / 1000  (PMCE.py:17-18)
+  RUN(P_MISC, pmce_div_scalar_f32(pose3d, dw.JM, (long long)batch * m->J * 3, 1000.0f, stream));
+  PMCE_TRY(mark_lifter_done(m, stream));
+  if (!single) PMCE_TRY(ev_wait(stream, m->ev_join, "forward join"));
+  PMCE_TRY(coevo_part(m, dw.JM, cam_pose, cam_mesh, batch, dw, stream, single ? nullptr : m->side));
+  if (pred_pose)
+    RUN(P_JREG, pmce_j_regress_f32(cam_mesh, m->jr_indptr, m->jr_indices, m->jr_data, pred_pose, batch, m->jr_rows, NVF,
+                                   1000.0f, stream));
+  return PMCE_OK;
 }
 
 int pmce_forward(pmce_model* m, const float* pose2d, const float* img_feat, float* cam_mesh, float* cam_pose,
@@ -626,37 +812,16 @@ int pmce_forward(pmce_model* m, const float* pose2d, const float* img_feat, floa
   PMCE_TRY(check_ws(m, batch, ws, ws_bytes));
   PMCE_REQUIRE(m->has_lifter && m->has_decoder, "forward: needs both lifter and decoder tensors");
   PMCE_REQUIRE(pose2d && img_feat && cam_mesh && cam_pose && pose3d, "forward: null pointer");
+  PMCE_REQUIRE(!pred_pose || (m->jr_indptr && m->jr_indices && m->jr_data && m->jr_rows > 0),
+               "forward: pred_pose requested but no J_regressor registered (jreg.indptr/indices/data + rows)");
   Carver c(ws, ws_bytes);
   LifterWs lw;
   DecoderWs dw;
   carve_lifter(c, m, batch, lw);
   carve_decoder(c, m, batch, dw);
-  // Fork: the GRU / AdaLN-parameter branch depends only on img_feat; it runs on a second (high-priority) stream
-  // under the pose lifter, whose long matrix-core kernels leave the gaps its 25 short dependent steps need.
-  // pmce_model_set_concurrency(m, 0) (or PMCE_SINGLE_STREAM=1 at create time) keeps everything on one stream.
-  const bool single = !m->concurrent;
-  if (!single) PMCE_TRY(ensure_side(m));
-  if (!single) {
-    (void)hipEventRecord(m->ev_fork, stream);
-    (void)hipStreamWaitEvent(m->side, m->ev_fork, 0);
-    PMCE_TRY(gru_part(m, img_feat, batch, dw, m->side));
-    (void)hipEventRecord(m->ev_join, m->side);
-  } else {
-    PMCE_TRY(gru_part(m, img_feat, batch, dw, stream));
-  }
-  PMCE_TRY(lifter_impl(m, pose2d, img_feat, pose3d, batch, lw, stream));
-  // pose3d.reshape(-1, J, 3) / 1000  (PMCE.py:17-18)
-  RUN(P_MISC, pmce_div_scalar_f32(pose3d, dw.JM, (long long)batch * m->J * 3, 1000.0f, stream));
-  mark_lifter_done(m, stream);
-  if (!single) (void)hipStreamWaitEvent(stream, m->ev_join, 0);  // join
-  PMCE_TRY(coevo_part(m, dw.JM, cam_pose, cam_mesh, batch, dw, stream, single ? nullptr : m->side));
-  if (pred_pose) {
-    PMCE_REQUIRE(m->jr_indptr && m->jr_indices && m->jr_data && m->jr_rows > 0,
-                 "forward: pred_pose requested but no J_regressor registered (jreg.indptr/indices/data + rows)");
-    RUN(P_JREG, pmce_j_regress_f32(cam_mesh, m->jr_indptr, m->jr_indices, m->jr_data, pred_pose, batch, m->jr_rows, NVF,
-                                   1000.0f, stream));
-  }
-  return PMCE_OK;
+  if (m->concurrent) PMCE_TRY(ensure_side(m));
+  const int rc = forward_impl(m, pose2d, img_feat, cam_mesh, cam_pose, pose3d, pred_pose, batch, lw, dw, stream);
+  return rc == PMCE_OK ? rc : fail_after_fork(m, stream, rc);
 }
 
 // ---- streaming (stride-1 windows over one long sequence) -------------------------------------------
@@ -676,30 +841,22 @@ int pmce_stream_precompute(pmce_model* m, const float* pose2d_frames, const floa
   carve_lifter(c, m, bf, lw);
   // window-independent lifter work: embedding + SpatialBlocks[0] + norm_s, once per frame (PoseEstimation.py:78-85)
   PMCE_TRY(lifter_frames(m, pose2d_frames, feat_frames, L, lw, stream));
-  RUN(P_LN, pmce_ln_chain_f32(lw.X, (long long)L * m->J, m->C, m->f("lifter.norm_s.weight"), m->f("lifter.norm_s.bias"), 1e-6f,
+  RUN(P_LN, pmce_ln_chain_f32(lw.X, (long long)L * m->J, m->C, m->w.ns_w, m->w.ns_b, 1e-6f,
                               nullptr, 1, 1, x0, nullptr, nullptr, 0.f, nullptr, stream));
   // window-independent GRU work: layer-0 input projections of both directions, once per frame (CoevoDecoder.py:216-221)
-  RUN(P_GEMM_GRU_IN, gemm(feat_frames, m->f("dec.gru.w_ih_l0"), m->f("dec.gru.b_ih_l0"), nullptr, gi0, L, 6 * GH, F, F, 6 * GH,
+  RUN(P_GEMM_GRU_IN, gemm(feat_frames, m->w.wih0, m->w.bih0, nullptr, gi0, L, 6 * GH, F, F, 6 * GH,
                           0, stream));
   return PMCE_OK;
 }
 
-int pmce_stream_forward(pmce_model* m, const float* x0, const float* gi0, const int* win, int W, int L, float* cam_mesh,
-                        float* cam_pose, float* pose3d, float* pred_pose, void* ws, size_t ws_bytes, pmce_stream_t stream) {
-  PMCE_TRY(check_ws(m, W, ws, ws_bytes));
-  PMCE_REQUIRE(m->has_lifter && m->has_decoder, "stream_forward: needs both lifter and decoder tensors");
-  PMCE_REQUIRE(x0 && gi0 && win && cam_mesh && cam_pose && pose3d && L > 0, "stream_forward: null pointer");
-  Carver c(ws, ws_bytes);
-  LifterWs lw;
-  DecoderWs dw;
-  carve_lifter(c, m, W, lw);
-  carve_decoder(c, m, W, dw);
+static int stream_forward_impl(pmce_model* m, const float* x0, const float* gi0, const int* win, int W, int L,
+                               float* cam_mesh, float* cam_pose, float* pose3d, float* pred_pose, LifterWs& lw, DecoderWs& dw,
+                               hipStream_t stream) {
   const bool single = !m->concurrent;
-  if (!single) PMCE_TRY(ensure_side(m));
   hipStream_t gs = single ? stream : m->side;
   if (!single) {
-    (void)hipEventRecord(m->ev_fork, stream);
-    (void)hipStreamWaitEvent(m->side, m->ev_fork, 0);
+    PMCE_TRY(ev_record(m->ev_fork, stream, "stream_forward fork"));
+    PMCE_TRY(ev_wait(m->side, m->ev_fork, "stream_forward fork"));
   }
   {
     hipStream_t stream_save = stream;
@@ -708,20 +865,35 @@ int pmce_stream_forward(pmce_model* m, const float* x0, const float* gi0, const 
     stream = stream_save;
   }
   PMCE_TRY(gru_rest(m, W, dw, gs));
-  if (!single) (void)hipEventRecord(m->ev_join, m->side);
-  RUN(P_LN, pmce_window_tokens_f32(x0, win, m->f("lifter.temporal_pos_embed"), m->f(blk("Temporal", 0, "norm1.weight")),
-                                   m->f(blk("Temporal", 0, "norm1.bias")), 1e-6f, lw.X, lw.XN, W, L, T, m->J, m->C, stream));
+  if (!single) PMCE_TRY(ev_record(m->ev_join, m->side, "stream_forward join"));
+  RUN(P_LN, pmce_window_tokens_f32(x0, win, m->w.tpos, m->w.blk[1][0].norm1_w, m->w.blk[1][0].norm1_b, 1e-6f, lw.X, lw.XN, W, L,
+                                   T, m->J, m->C, stream));
   PMCE_TRY(lifter_rest(m, pose3d, W, lw, stream));
   RUN(P_MISC, pmce_div_scalar_f32(pose3d, dw.JM, (long long)W * m->J * 3, 1000.0f, stream));
-  mark_lifter_done(m, stream);
-  if (!single) (void)hipStreamWaitEvent(stream, m->ev_join, 0);
+  PMCE_TRY(mark_lifter_done(m, stream));
+  if (!single) PMCE_TRY(ev_wait(stream, m->ev_join, "stream_forward join"));
   PMCE_TRY(coevo_part(m, dw.JM, cam_pose, cam_mesh, W, dw, stream, single ? nullptr : m->side));
-  if (pred_pose) {
-    PMCE_REQUIRE(m->jr_indptr && m->jr_indices && m->jr_data && m->jr_rows > 0, "stream_forward: no J_regressor registered");
+  if (pred_pose)
     RUN(P_JREG, pmce_j_regress_f32(cam_mesh, m->jr_indptr, m->jr_indices, m->jr_data, pred_pose, W, m->jr_rows, NVF, 1000.0f,
                                    stream));
-  }
   return PMCE_OK;
+}
+
+int pmce_stream_forward(pmce_model* m, const float* x0, const float* gi0, const int* win, int W, int L, float* cam_mesh,
+                        float* cam_pose, float* pose3d, float* pred_pose, void* ws, size_t ws_bytes, pmce_stream_t stream) {
+  PMCE_TRY(check_ws(m, W, ws, ws_bytes));
+  PMCE_REQUIRE(m->has_lifter && m->has_decoder, "stream_forward: needs both lifter and decoder tensors");
+  PMCE_REQUIRE(x0 && gi0 && win && cam_mesh && cam_pose && pose3d && L > 0, "stream_forward: null pointer");
+  PMCE_REQUIRE(!pred_pose || (m->jr_indptr && m->jr_indices && m->jr_data && m->jr_rows > 0),
+               "stream_forward: no J_regressor registered");
+  Carver c(ws, ws_bytes);
+  LifterWs lw;
+  DecoderWs dw;
+  carve_lifter(c, m, W, lw);
+  carve_decoder(c, m, W, dw);
+  if (m->concurrent) PMCE_TRY(ensure_side(m));
+  const int rc = stream_forward_impl(m, x0, gi0, win, W, L, cam_mesh, cam_pose, pose3d, pred_pose, lw, dw, stream);
+  return rc == PMCE_OK ? rc : fail_after_fork(m, stream, rc);
 }
 
 int pmce_model_wait_lifter(pmce_model* m, pmce_stream_t stream) {

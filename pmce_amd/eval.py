@@ -16,7 +16,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib, assets, ops, sharding
+from . import _lib, assets, sharding
 
 H36M_EVAL_JOINT = (1, 2, 3, 4, 5, 6, 8, 10, 11, 12, 13, 14, 15, 16)   # data/PW3D/dataset.py:35
 P = _lib.ptr
@@ -36,6 +36,21 @@ class Evaluator:
         self.rowsum = torch.from_numpy(self.jr.astype(np.float64).sum(1).astype(np.float32)).to(self.device)
         self.eval_idx = torch.tensor(list(eval_joint), dtype=torch.int32, device=self.device)
         self.n_eval, self.root_joint = len(eval_joint), root_joint
+        # CSR forms of both regressors, built and uploaded ONCE: per_sample runs per batch and must not touch the host
+        self._csr_jr = self._upload_csr(self.jr)
+        self._csr_root = self._upload_csr(self.root_row)
+
+    def _upload_csr(self, dense):
+        indptr, indices, data = assets.regressor_to_csr(dense)
+        return tuple(torch.from_numpy(a).to(self.device) for a in (indptr, indices, data)) + (int(dense.shape[0]),)
+
+    def _regress(self, mesh, csr, scale=1000.0):
+        """J_regressor @ (mesh * scale) with a cached CSR (no host work, stream-asynchronous)."""
+        ip, ix, dt, rows = csr
+        out = torch.empty(mesh.shape[0], rows, 3, device=mesh.device, dtype=torch.float32)
+        _lib.check(self.lib.pmce_j_regress_f32(P(mesh), P(ip), P(ix), P(dt), P(out), mesh.shape[0], rows, mesh.shape[1], scale,
+                                               _lib.current_stream()), "j_regress")
+        return out
 
     def _sample_errors(self, pm, gm, scale, rp, rg, pj, gj, rowsum, want_joints):
         B, V, _ = pm.shape
@@ -66,11 +81,11 @@ class Evaluator:
         regressed from the ground-truth mesh."""
         c = lambda t: t.to(self.device, torch.float32).contiguous()
         pm, gm = c(pred_mesh_m), c(gt_mesh_m)
-        pj = ops.j_regress(pm, self.jr, 1000.0)
-        rp = ops.j_regress(pm, self.root_row, 1000.0).reshape(-1, 3).contiguous()
-        rg = ops.j_regress(gm, self.root_row, 1000.0).reshape(-1, 3).contiguous()
+        pj = self._regress(pm, self._csr_jr)
+        rp = self._regress(pm, self._csr_root).reshape(-1, 3)
+        rg = self._regress(gm, self._csr_root).reshape(-1, 3)
         if gt_joints_mm is None:
-            gj = ops.j_regress(gm, self.jr, 1000.0)
+            gj = self._regress(gm, self._csr_jr)
         else:
             # The kernel aligns joint k as  j[k] - rowsum[k]*root  (joints regressed from a root-aligned mesh).  Annotated
             # joints are plain coordinates aligned by their own joint 0, so the root term is added here and cancels there.

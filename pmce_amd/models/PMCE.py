@@ -91,6 +91,50 @@ class PMCE(HipModuleBase):
         """Several batches in flight at once on shared weights; see :class:`Pipeline`."""
         return Pipeline(self, depth, stagger)
 
+    def graphed(self, batch: int, want_joints: bool = True) -> "GraphedForward":
+        """The forward for a fixed small batch captured once as a hipGraph; see :class:`GraphedForward`."""
+        return GraphedForward(self, batch, want_joints)
+
+
+class GraphedForward:
+    """``forward_with_joints`` for ONE batch size, captured as a hipGraph and replayed: the ~110 launches of a forward (and
+    its internal fork/join onto the side stream) become one graph launch.  For the launch-bound small batches of the
+    reference's demo (batch 1, main/run_demo.py:332,145); results are bit-identical to the eager call.
+
+        gf = model.graphed(1)
+        mesh, pose, pose3d, pred = gf(pose2d, img_feat)     # outputs are the graph's static buffers: consume or clone
+                                                            # them before the next call
+    """
+
+    def __init__(self, model: "PMCE", batch: int, want_joints: bool = True):
+        main = model._ensure_packed()
+        dev = main.device
+        self.model, self._main, self.batch = model, main, batch
+        self.eng = main.clone_shared()           # a handle of its own: the graph owns its workspace, side stream and events
+        want = want_joints and self.eng.regressor_rows > 0
+        self.pose2d = torch.zeros(batch, SEQLEN, model.num_joint, 2, device=dev)
+        self.img_feat = torch.zeros(batch, SEQLEN, FEAT_DIM, device=dev)
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s), torch.no_grad():
+            for _ in range(2):                   # outside capture: workspace allocation, side stream and event creation
+                model._run(self.pose2d, self.img_feat, want, self.eng)
+        s.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=s), torch.no_grad():
+            self.outputs = model._run(self.pose2d, self.img_feat, want, self.eng)
+
+    @torch.no_grad()
+    def __call__(self, pose2d, img_feat):
+        if self.model._engine is not self._main or self.model._dirty:
+            raise _lib.PmceError("the model's weights were re-packed after this graph was captured: call model.graphed() again")
+        if tuple(pose2d.shape) != tuple(self.pose2d.shape) or tuple(img_feat.shape) != tuple(self.img_feat.shape):
+            raise ValueError(f"this graph was captured for batch {self.batch}: got {tuple(pose2d.shape)} / {tuple(img_feat.shape)}")
+        self.pose2d.copy_(pose2d)
+        self.img_feat.copy_(img_feat)
+        self.graph.replay()
+        return self.outputs
+
 
 class Pipeline:
     """Keeps ``depth`` forwards of independent batches in flight (clips are independent, reference lib/_img_utils.py:74-78):

@@ -21,7 +21,8 @@ class GraphormerNet(HipModuleBase):
         build_param_tree(self, synth.lifter_spec(num_joints, embed_dim, depth))
         self.eval()
         if pretrained:   # PoseEstimation.py:71-74
-            ckpt = torch.load(cfg.MODEL.posenet_path, map_location="cpu")
+            from ..checkpoint import torch_load_checkpoint
+            ckpt = torch_load_checkpoint(cfg.MODEL.posenet_path, map_location="cpu")   # tensors only: no code execution
             self.load_state_dict(ckpt["model_state_dict"])
 
     def _build_engine(self, dev):

@@ -161,6 +161,53 @@ def joint_stream(xq, xk, xv, g, sd, blk, stage, jt=None):
     return y, pose, kv
 
 
+def joint_self_attn_block(x, g, sd, blk):
+    """joint_SA_FFN alone: x + SA(AdaLN(x)); x + Mlp(AdaLN(x)) on [B,J,64], 8 heads (the reference's Block module,
+    CoevoDecoder.py:102-105) - joint_stream's stage 4."""
+    lib = _lib.load()
+    x = _c(x)
+    B, J, _ = x.shape
+    sa = blk + ".joint_SA_FFN"
+    GB = adaln_params(g, sd, [sa + ".norm1", sa + ".norm2"])
+    names = [sa + ".attn.qkv.weight"] * 8 + [sa + ".attn.qkv.weight", sa + ".attn.qkv.bias", sa + ".attn.proj.weight",
+                                             sa + ".attn.proj.bias", sa + ".mlp.fc1.weight", sa + ".mlp.fc1.bias",
+                                             sa + ".mlp.fc2.weight", sa + ".mlp.fc2.bias"] + [sa + ".attn.qkv.weight"] * 2
+    ws = [_c(sd[n]) for n in names]            # slots 0-7 (cross-attention block) and 16-17 (coordinate head) are unused
+    wptr = (C.c_void_p * 18)(*[w.data_ptr() for w in ws])
+    inst = (C.c_int * 4)(0, 0, 0, 1)
+    y = torch.empty_like(x)
+    _lib.check(lib.pmce_joint_stream_f32(P(x), None, None, P(GB), GB.shape[1], wptr, inst, None, P(y), None, B, J, 4, _st()),
+               "joint_stream(stage 4)")
+    return y
+
+
+def coevo_block(model, k, joints, vt_in, g):
+    """CoevoBlock k of a pmce_amd.models.{PMCE,CoevoDecoder} instance on explicit inputs (CoevoDecoder.py:175-191):
+    -> (vt_out[B,431,3], joint_out[B,J,3] or None for k < 3)."""
+    eng = model._ensure_packed()
+    joints, vt_in, g = _c(joints), _c(vt_in), _c(g)
+    B = joints.shape[0]
+    vt_out = torch.empty_like(vt_in)
+    j_out = torch.empty_like(joints) if k == 3 else None
+    ws = eng.workspace(B)
+    _lib.check(eng.lib.pmce_coevo_block_forward(eng.handle, k, P(joints), P(vt_in), P(g), P(vt_out), P(j_out), B,
+                                                C.c_void_p(ws.data_ptr()), ws.numel(), _st()), "coevo_block_forward")
+    return vt_out, j_out
+
+
+def final_product(model, vt, g):
+    """cam_mesh[B,6890,3] = upsample_conv(vt) + cat(linear_cur1..3(relu(g)))  (CoevoDecoder.py:238-244) through the packed
+    [20670, 3360] operand of a pmce_amd model."""
+    lib = _lib.load()
+    eng = model._ensure_packed()
+    vt, g = _c(vt), _c(g)
+    B = vt.shape[0]
+    KP = eng.packed["dec.final.weight"].shape[1]
+    A = torch.empty(B, KP, device=vt.device, dtype=torch.float32)
+    _lib.check(lib.pmce_build_final_operand_f32(P(g), P(vt), P(A), B, KP, _st()), "build_final_operand")
+    return gemm_nt(A, eng.packed["dec.final.weight"], eng.packed["dec.final.bias"]).reshape(B, 6890, 3)
+
+
 def j_regress(cam_mesh_m, j_regressor, scale=1000.0):
     """J_regressor[None] @ (cam_mesh*1000) (lib/core/base.py:223-225); j_regressor dense [R,6890] (numpy or tensor)."""
     from .assets import regressor_to_csr

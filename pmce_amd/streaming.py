@@ -36,11 +36,34 @@ def window_indices(num_frames: int, seqlen: int = SEQLEN, stride: int = 1, match
 def demo_window_list(num_frames: int, seqlen: int = SEQLEN) -> np.ndarray:
     """One window per frame as the demo builds them (lib/utils/_dataset_demo.py:91-96): frames 0..seqlen/2-1 and the last
     seqlen/2-1 frames use a single frame repeated seqlen times ([i,i]), the others the window whose middle they are."""
+    if num_frames < seqlen:
+        # the reference's list (head 0..7, tail -7..-1) is not one window per frame below seqlen frames: frames repeat or
+        # index out of range.  Refuse instead of returning wrong clips.
+        raise ValueError(f"demo_window_list needs at least {seqlen} frames (got {num_frames})")
     h = seqlen // 2
     mid = [[i, i + seqlen - 1] for i in range(num_frames - seqlen + 1)]
     head = [[i, i] for i in range(h)]
     tail = [[num_frames - h + i, num_frames - h + i] for i in range(1, h)]
     return np.asarray(head + mid + tail, dtype=np.int64)
+
+
+def validate_windows(windows, num_frames: int, seqlen: int = SEQLEN) -> np.ndarray:
+    """int32[W,2] window table checked on the host before any launch: 0 <= start <= end < num_frames and a window is
+    either ``seqlen`` consecutive frames or one repeated frame (start == end).  The kernels clamp frame indices, so an
+    out-of-range table (e.g. ``demo_window_list`` of a sequence shorter than ``seqlen``) would otherwise yield wrong clips
+    silently."""
+    w = np.asarray(windows)
+    if w.size == 0:
+        return np.zeros((0, 2), dtype=np.int32)
+    if w.ndim != 2 or w.shape[1] != 2:
+        raise ValueError(f"windows must be [W,2] (start, end inclusive), got shape {w.shape}")
+    s, e = w[:, 0].astype(np.int64), w[:, 1].astype(np.int64)
+    bad = (s < 0) | (e >= num_frames) | (s > e) | ((e - s != 0) & (e - s != seqlen - 1))
+    if bad.any():
+        i = int(np.argmax(bad))
+        raise ValueError(f"window {i} = [{int(s[i])}, {int(e[i])}] is invalid for a sequence of {num_frames} frames "
+                         f"(need 0 <= start <= end < {num_frames} and end - start in {{0, {seqlen - 1}}})")
+    return np.ascontiguousarray(w, dtype=np.int32)
 
 
 def assemble_windows(pose2d_frames: torch.Tensor, feat_frames: torch.Tensor, windows) -> tuple:
@@ -51,7 +74,7 @@ def assemble_windows(pose2d_frames: torch.Tensor, feat_frames: torch.Tensor, win
     p = pose2d_frames.to(torch.float32).contiguous()
     f = feat_frames.to(torch.float32).contiguous()
     L, J, _ = p.shape
-    w = torch.as_tensor(np.asarray(windows, dtype=np.int32), device=dev).contiguous()
+    w = torch.as_tensor(validate_windows(windows, L), device=dev).contiguous()
     W = w.shape[0]
     out_p = torch.empty(W, SEQLEN, J, 2, device=dev, dtype=torch.float32)
     out_f = torch.empty(W, SEQLEN, FEAT_DIM, device=dev, dtype=torch.float32)
@@ -94,7 +117,7 @@ def stream_forward_cached(model, cache: FrameCache, windows=None, batch: int = 2
     import ctypes as C
     from .config import NUM_VERTS_FULL
     main = model._ensure_packed()
-    windows = window_indices(cache.L) if windows is None else np.asarray(windows)
+    windows = validate_windows(window_indices(cache.L) if windows is None else windows, cache.L)
     dev = cache.x0.device
     J = model.num_joint
     nb = (len(windows) + batch - 1) // batch

@@ -4,6 +4,7 @@ north-star cross-attention kernel against the HBM roof (the CPU baseline of the 
 import argparse, json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("PMCE_SYNTHETIC_BASE_DATA", "1")   # synthetic weights on the synthetic template (explicit opt-in)
 
 
 def main():

@@ -1,6 +1,7 @@
 """Check that a forward (including its internal fork/join onto the side stream) can be captured in a HIP graph and replayed."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("PMCE_SYNTHETIC_BASE_DATA", "1")   # synthetic weights on the synthetic template (explicit opt-in)
 import torch
 from pmce_amd import assets, models, synth
 dev = torch.device("cuda:0")

@@ -1,5 +1,6 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ.setdefault("PMCE_SYNTHETIC_BASE_DATA", "1")   # synthetic weights on the synthetic template (explicit opt-in)
 import numpy as np, torch
 from pmce_amd import assets, models, synth, staging
 dev = torch.device("cuda:0"); B, J, C = 256, 17, 256

@@ -1,6 +1,7 @@
 """Pipeline depth x staggering x in-forward two-stream mode, interleaved rounds in one process (GPU only)."""
 import os, sys, time, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ.setdefault("PMCE_SYNTHETIC_BASE_DATA", "1")   # synthetic weights on the synthetic template (explicit opt-in)
 import torch
 from pmce_amd import assets, models, synth
 dev = torch.device("cuda:0"); B, J = 256, 17

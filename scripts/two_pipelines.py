@@ -1,6 +1,7 @@
 """Experiment: does running two half-batches as two concurrent pipelines (two model handles, two streams) beat one full batch?"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("PMCE_SYNTHETIC_BASE_DATA", "1")   # synthetic weights on the synthetic template (explicit opt-in)
 import torch
 from pmce_amd import assets, models, synth
 dev = torch.device("cuda:0")

@@ -9,6 +9,8 @@ REPO = osp.dirname(osp.dirname(osp.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 GOLDEN = osp.join(REPO, "tests", "golden")
+# no SMPL-derived base data exists offline: the fixtures and tests run on the synthetic template (an explicit opt-in)
+os.environ.setdefault("PMCE_SYNTHETIC_BASE_DATA", "1")
 
 
 def pytest_configure(config):

@@ -173,3 +173,58 @@ def test_workload_flops_agree_with_oracle_count():
     for J, C in ((17, 256), (19, 256), (17, 512)):
         assert flops_per_clip(J, C) == O.flops_per_clip(J, C)
     assert abs(flops_per_clip(17, 256)["total"] - 3.552e9) < 5e6
+
+
+def test_synthetic_template_is_opt_in(monkeypatch):
+    """a missing smpl_mean_vertices.npy / mesh_downsampling.npz must raise (vj_relation is derived from them and
+    is not in the checkpoint); the synthetic stand-ins are an explicit opt-in."""
+    from pmce_amd import assets, models
+    monkeypatch.setenv("PMCE_SYNTHETIC_BASE_DATA", "0")
+    assets.allow_synthetic_base_data(False)
+    with pytest.raises(FileNotFoundError):
+        assets.build_template("/nonexistent")
+    with pytest.raises(FileNotFoundError):
+        models.PMCE.get_model(17, 256, 3)
+    assets.allow_synthetic_base_data(True)
+    try:
+        assert assets.build_template("/nonexistent")[2] == "synthetic"
+    finally:
+        assets.allow_synthetic_base_data(False)
+    monkeypatch.setenv("PMCE_SYNTHETIC_BASE_DATA", "1")
+    assert assets.build_template("/nonexistent")[2] == "synthetic"
+
+
+def test_window_tables_are_validated():
+    from pmce_amd import streaming
+    ok = streaming.validate_windows(streaming.demo_window_list(40), 40)
+    assert ok.dtype == np.int32 and ok.shape == (40, 2)
+    assert streaming.validate_windows(np.zeros((0, 2)), 10).shape == (0, 2)
+    for bad, L in (([[0, 15]], 15),            # runs past the sequence
+                   ([[-1, 14]], 40),           # negative start
+                   ([[3, 10]], 40),            # neither 16 consecutive frames nor a repeated frame
+                   ([[9, 2]], 40)):            # start > end
+        with pytest.raises(ValueError):
+            streaming.validate_windows(bad, L)
+    with pytest.raises(ValueError):            # demo list of a sequence shorter than one window
+        streaming.demo_window_list(10)
+
+
+def test_checkpoint_loading_does_not_unpickle_code(tmp_path):
+    """reference-style checkpoint dicts load with weights_only=True; a file that needs the unrestricted unpickler is
+    refused unless the caller opts in."""
+    import torch
+    from pmce_amd import checkpoint, synth
+    sd = synth.make_state_dict(synth.lifter_spec(17, 256, 3), seed=1)
+    f = tmp_path / "pose.pth.tar"
+    torch.save({"epoch": 3, "model_state_dict": {"module." + k: v for k, v in sd.items()}}, f)
+    got, kind, J, C, depth = checkpoint.load_reference_checkpoint(str(f))
+    assert (kind, J, C, depth) == ("lifter", 17, 256, 3) and set(got) == set(sd)
+
+    class Evil:
+        def __reduce__(self):
+            return (print, ("code ran while unpickling",))
+
+    g = tmp_path / "evil.pth.tar"
+    torch.save({"model_state_dict": sd, "extra": Evil()}, g)
+    with pytest.raises(ValueError):
+        checkpoint.load_reference_checkpoint(str(g))
