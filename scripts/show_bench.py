@@ -3,11 +3,25 @@ import json
 import sys
 
 src = open(sys.argv[1]) if len(sys.argv) > 1 else sys.stdin
+
+
+def rec(tag, d):
+    print(f"[{tag}] {d['value']} clips/s  {d['ms_per_step']} ms/step  windows {d.get('windows', {}).get('ms_per_step')}")
+    print("   roofline:", {k: v for k, v in (d.get("roofline") or {}).items() if k not in ("classes", "traffic_source")})
+    print("   north-star:", d.get("roofline_cross_attention"))
+    print("   kernels (ms/step):", {k: v for k, v in (d.get("kernel_ms_per_step") or {}).items() if v > 0.04},
+          "sum", d.get("kernel_ms_total_single_stream"))
+    print("   cpu:", d.get("cpu_baseline"))
+
+
 for l in src:
     if l.startswith("{"):
         d = json.loads(l)
-        print(d["value"], "clips/s", d["ms_per_step"], "ms/step", d["roofline"])
-        print({k: v for k, v in d["kernel_ms_per_step"].items() if v > 0.04})
-        print("cpu:", d.get("cpu_baseline"))
+        rec(f"C={d['config']['embed_dim']} n_gpus={d['n_gpus']}", d)
+        print("   host_fed:", d.get("host_fed"))
+        print("   latency:", d.get("latency"))
+        for k, v in d.items():
+            if k.startswith("variant_") and v:
+                rec(k, v)
     else:
         print(l.strip()[:200])

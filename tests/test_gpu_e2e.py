@@ -128,14 +128,14 @@ def test_checkpoint_forms_and_errors(tmp_path):
         m.train()
 
 
-@pytest.mark.parametrize("B", [64, 256])
-def test_full_size_properties(B):
-    """BASELINE configs[1]/[2] sizes: properties that need no oracle run.
+@pytest.mark.parametrize("B,C", [(64, 256), (256, 256), (256, 512)])
+def test_full_size_properties(B, C):
+    """BASELINE configs[1]/[2] sizes, at the reference's width and at north_star's C = 512: properties that need no oracle run.
     (1) clips are independent: clip i of a big batch == the same clip run in a batch of 2;
     (2) permuting clips permutes outputs; (3) J_regressor projection is linear in the mesh."""
     from pmce_amd import assets, ops, synth
     J = 17
-    model = get_model(J, 256)
+    model = get_model(J, C)
     pose2d, img_feat = synth.make_inputs(B, J, 123)
     p, f = T(pose2d).to(dev()), T(img_feat).to(dev())
     mesh, pose, pose3d, pred = model.forward_with_joints(p, f)
@@ -312,3 +312,107 @@ def test_streaming_frame_reuse_other_configs(J, C):
     out = streaming.stream_forward_cached(model, cache, windows=win, batch=20, with_joints=True, lanes=2)
     e = [maxabs(a, b) for a, b in zip(out, ref)]
     assert e[0] < 1e-5 and e[1] < 1e-5 and e[2] < 1e-2 and e[3] < 1e-2, e
+
+
+@pytest.mark.parametrize("C", [256, 512])
+def test_full_forward_batch64_vs_oracle(C):
+    """BASELINE configs[1]'s batch through the FULL path, compared with the oracle on every 8th clip (the oracle does 8 clips
+    in about a second); C = 512 is north_star's width.  Clips are independent, so the oracle runs the 8 sampled clips as
+    one batch of their own."""
+    from oracle import pmce_oracle as O
+    from pmce_amd import synth
+    J, B = 17, 64
+    model = get_model(J, C)
+    sd = cached_state_dict(J, C)
+    pose2d, img_feat = synth.make_inputs(B, J, 2024)
+    mesh, pose, pose3d, pred = model.forward_with_joints(T(pose2d).to(dev()), T(img_feat).to(dev()))
+    idx = list(range(0, B, 8))
+    with torch.no_grad():
+        rm, rp, rl = O.pmce_forward(sd, T(pose2d[idx]), T(img_feat[idx]), model.vj_relation)
+    e = (maxabs(mesh[idx], rm), maxabs(pose[idx], rp), maxabs(pose3d[idx], rl))
+    print(f"B=64 C={C} full forward vs oracle (every 8th clip): mesh %.2e m, pose %.2e m, pose3d %.2e mm" % e)
+    assert e[0] < TIGHT_M and e[1] < TIGHT_M and e[2] < TOL_MM
+
+
+def test_decoder_only_batch64_vs_oracle():
+    """BASELINE configs[1] literally: CoEvoDecoder-only forward at batch 64, HIP kernels vs the CPU reference restatement
+    (every 8th clip)."""
+    from oracle import pmce_oracle as O
+    from pmce_amd import models, synth
+    J, B = 17, 64
+    sd = cached_state_dict(J, 256)
+    dec = models.CoevoDecoder.get_model(J, 256)
+    dec.load_state_dict({k[len("pose_mesh_coevo."):]: v for k, v in sd.items() if k.startswith("pose_mesh_coevo.")})
+    dec = dec.to(dev())
+    joints, feats = synth.make_decoder_inputs(B, J, 64)
+    pose, mesh = dec(T(joints).to(dev()), T(feats).to(dev()))
+    idx = list(range(0, B, 8))
+    with torch.no_grad():
+        rj, rm = O.decoder_forward(sd, T(joints[idx]), T(feats[idx]), dec.vj_relation, "pose_mesh_coevo.")
+    e = (maxabs(pose[idx], rj), maxabs(mesh[idx], rm))
+    print("decoder-only B=64 vs oracle (every 8th clip): pose %.2e m, mesh %.2e m" % e)
+    assert e[0] < TIGHT_M and e[1] < TIGHT_M
+
+
+@pytest.mark.parametrize("J,L", [(17, 40), (19, 64)])
+def test_streaming_matches_oracle(J, L):
+    """SURVEY 8f rank 2 pinned to the ORACLE (not to the HIP forward): a sequence of L frames served through the frame-reuse
+    path - one window per frame, the demo's list with its repeated-frame head/tail windows (lib/utils/_dataset_demo.py:91-104;
+    a window predicts its middle frame, lib/_img_utils.py:27-55, CoevoDecoder.py:229) - must equal the oracle forward of the
+    same windows assembled on the host, and the acceleration error of the streamed middle-frame joints must equal
+    oracle/metrics_oracle.compute_error_accel (coord_utils.py:218-245)."""
+    from oracle import metrics_oracle as MO
+    from oracle import pmce_oracle as O
+    from pmce_amd import assets, streaming, synth
+    from pmce_amd.eval import Evaluator, H36M_EVAL_JOINT
+    model = get_model(J, 256)
+    sd = cached_state_dict(J, 256)
+    nclip = (L + 15) // 16
+    p_np, f_np = synth.make_inputs(nclip, J, 90 + J)
+    pose_fr, feat_fr = p_np.reshape(-1, J, 2)[:L], f_np.reshape(-1, 2048)[:L]
+    win = streaming.demo_window_list(L)
+    assert len(win) == L and (win[:8, 0] == win[:8, 1]).all() and (win[-7:, 0] == win[-7:, 1]).all()
+    # host-side assembly of the windows exactly as the reference's get_sequence does it
+    wp = np.stack([pose_fr[[s] * 16] if s == e else pose_fr[s:e + 1] for s, e in win])
+    wf = np.stack([feat_fr[[s] * 16] if s == e else feat_fr[s:e + 1] for s, e in win])
+    with torch.no_grad():
+        rm, rp, rl = O.pmce_forward(sd, T(wp), T(wf), model.vj_relation)
+    cache = streaming.precompute_frames(model, T(pose_fr).to(dev()), T(feat_fr).to(dev()))
+    mesh, pose, pose3d, pred = streaming.stream_forward_cached(model, cache, windows=win, batch=24, with_joints=True, lanes=2)
+    e = (maxabs(mesh, rm), maxabs(pose, rp), maxabs(pose3d, rl))
+    print(f"streamed J={J} L={L} vs oracle: mesh %.2e m, pose %.2e m, pose3d %.2e mm" % e)
+    assert e[0] < TIGHT_M and e[1] < TIGHT_M and e[2] < TOL_MM
+    # acceleration error of the streamed predictions against a synthetic ground truth, device vs oracle
+    jr = torch.from_numpy(assets.load_j_regressor("h36m").astype(np.float32))
+    ref_j = torch.einsum("jv,bvl->bjl", jr.double(), rm.double() * 1000)
+    ref_j = (ref_j - ref_j[:, :1])[:, list(H36M_EVAL_JOINT)].numpy()
+    gt_j = ref_j + np.random.default_rng(0).standard_normal(ref_j.shape) * 5.0
+    acc_ref = MO.compute_error_accel(joints_gt=gt_j, joints_pred=ref_j)                     # [L-2]
+    pj = pred - pred[:, :1]
+    ev = Evaluator(dev())
+    acc = ev.accel(pj[:, list(H36M_EVAL_JOINT)].contiguous(), torch.from_numpy(gt_j.astype(np.float32)).to(dev()), np.zeros(L, np.int64))
+    ea = float(np.abs(acc.cpu().numpy()[1:-1] - acc_ref).max())
+    print(f"   acceleration error of the {L - 2} inner frames: max diff {ea:.2e} mm/frame^2 (mean {acc_ref.mean():.3f})")
+    assert ea < 5e-3 and float(acc[0]) == 0.0 and float(acc[-1]) == 0.0
+
+
+@pytest.mark.parametrize("B", [1, 8])
+def test_graphed_forward_matches_eager(B):
+    """models.PMCE.graphed(B): the small-batch forward replayed from a hipGraph is bit-identical to the eager call, also
+    after the inputs change, and refuses to run on stale weights."""
+    from pmce_amd import _lib, synth
+    J = 17
+    model = get_model(J, 256)
+    gf = model.graphed(B)
+    for seed in (5, 6):
+        p, f = (T(a).to(dev()) for a in synth.make_inputs(B, J, seed))
+        ref = [t.clone() for t in model.forward_with_joints(p, f)]
+        got = gf(p, f)
+        torch.cuda.synchronize()
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        gf(torch.zeros(B + 1, 16, J, 2, device=dev()), torch.zeros(B + 1, 16, 2048, device=dev()))
+    model.load_state_dict(cached_state_dict(J, 256))          # re-pack
+    with pytest.raises(_lib.PmceError):
+        gf(p, f)

@@ -46,6 +46,11 @@ def sd_dev(sd, keys_prefix):
     (69632, 256, 256, 0, True),      # proj + residual, 64x64 tiles
     (69632, 512, 256, 1, False),     # fc1 + GELU, 64x128 tiles
     (69650, 256, 512, 0, True),      # fc2 + residual, ragged last row tile
+    # the same four products at north_star's width C = 512 (B=256): K = 512 / 1024, N = 1536 / 512 / 1024
+    (69632, 1536, 512, 0, False),    # qkv
+    (69632, 512, 512, 0, True),      # proj + residual
+    (69632, 1024, 512, 1, False),    # fc1 + GELU
+    (69632, 512, 1024, 0, True),     # fc2 + residual
 ])
 def test_gemm_nt(M, N, K, act, res):
     from pmce_amd import ops
@@ -54,12 +59,15 @@ def test_gemm_nt(M, N, K, act, res):
     b = rnd("gemm.b", (N,)).to(dev())
     R = rnd("gemm.R", (M, N)).to(dev()) if res else None
     out = ops.gemm_nt(A, W, b, R, act)
-    ref = A.double() @ W.double().t() + b.double()
-    if act:
-        ref = torch.nn.functional.gelu(ref)
-    if res:
-        ref = ref + R.double()
-    e = maxabs(out, ref)
+    e = 0.0
+    for r0 in range(0, M, 16384):             # fp64 reference in row chunks (the C = 512 cases would need 1.7 GB at once)
+        sl = slice(r0, min(M, r0 + 16384))
+        ref = A[sl].double() @ W.double().t() + b.double()
+        if act:
+            ref = torch.nn.functional.gelu(ref)
+        if res:
+            ref = ref + R[sl].double()
+        e = max(e, float((out[sl].double() - ref).abs().max()))
     print(f"gemm {M}x{N}x{K} act={act} res={res}: max-abs {e:.2e}")
     assert e < 2e-5       # fp32 accumulation over K <= 2048 of O(1) terms
 
@@ -255,3 +263,109 @@ def test_j_regress(golden):
     e = maxabs(out, T(z["pred_pose"]))
     print(f"j_regress vs reference: {e:.2e} mm")
     assert e < 2e-3           # millimetres (values ~1e3); 1e-3 m contract == 1 mm
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the remaining reference-module fixtures of tests/golden/modules_J17_C256.npz (made by the reference's own modules)
+# ------------------------------------------------------------------------------------------------------------
+_PM = {}
+
+
+def _pmce17():
+    from pmce_amd import assets, models
+    if "m" not in _PM:
+        m = models.PMCE.get_model(17, 256, 3)
+        m.load_state_dict(cached_state_dict(17, 256))
+        m.set_j_regressor(assets.load_j_regressor("h36m"))
+        _PM["m"] = m.to(dev())
+    return _PM["m"]
+
+
+def test_upsample_conv_fixture(golden):
+    """a11: Conv1d(431 -> 6890, k=3, pad=1 over xyz) through the packed final product, vs dec.upsample_conv's own output.
+    With g = 0 the residual branch contributes relu(0) = 0 times its weights plus the three Linear biases, removed here."""
+    from pmce_amd import ops, synth
+    sd = cached_state_dict(17, 256)
+    vt = T(synth.uniform_pm1("mod.vt", 431 * 3, 11).reshape(1, 431, 3) * 0.5).to(dev())
+    out = ops.final_product(_pmce17(), vt, torch.zeros(1, 2048, device=dev()))
+    lin_b = torch.stack([sd[f"pose_mesh_coevo.linear_cur{i}.bias"] for i in (1, 2, 3)], 1)       # [6890, 3]
+    e = maxabs(out.cpu() - lin_b[None], T(golden("modules_J17_C256.npz")["upsample"]))
+    print(f"upsample_conv vs reference fixture: {e:.2e}")
+    assert e < 2e-5
+
+
+def test_joint_self_attn_block_fixture(golden):
+    """a9 on the joint stream: joint_SA_FFN (Block, 8 heads over J tokens) vs the reference module's own output."""
+    from oracle import pmce_oracle as O
+    from pmce_amd import ops
+    sd = cached_state_dict(17, 256)
+    g, _, xj = _mod_inputs()
+    y = ops.joint_self_attn_block(xj.to(dev()), g.to(dev()), sd_dev(sd, BLK + ".joint_SA_FFN"), BLK)
+    with torch.no_grad():
+        ref = O.ada_block(xj, g, sd, BLK + ".joint_SA_FFN", 8)
+    e1, e2 = maxabs(y, ref), maxabs(y, T(golden("modules_J17_C256.npz")["sab_j"]))
+    print(f"joint SA block: vs oracle {e1:.2e}, vs reference fixture {e2:.2e}")
+    assert e1 < 2e-5 and e2 < 3e-5
+
+
+def test_coevo_block_fixture(golden):
+    """a10: one whole CoevoBlock (block 3: both streams live) on explicit (joints, vertices, g), vs the reference module's
+    own outputs coevo_v / coevo_j; blocks 1-2 (vertex stream only) vs the oracle."""
+    from oracle import pmce_oracle as O
+    from pmce_amd import ops, synth
+    u = synth.uniform_pm1
+    sd = cached_state_dict(17, 256)
+    g, _, _ = _mod_inputs()
+    jt = T(u("mod.jt", 17 * 3, 11).reshape(1, 17, 3) * 0.5)
+    vt = T(u("mod.vt", 431 * 3, 11).reshape(1, 431, 3) * 0.5)
+    z = golden("modules_J17_C256.npz")
+    vo, jo = ops.coevo_block(_pmce17(), 3, jt.to(dev()), vt.to(dev()), g.to(dev()))
+    ev, ej = maxabs(vo, T(z["coevo_v"])), maxabs(jo, T(z["coevo_j"]))
+    print(f"CoevoBlock 3 vs reference fixture: vertices {ev:.2e}, joints {ej:.2e}")
+    assert ev < 2e-5 and ej < 2e-5
+    B = 3
+    g3, j3, v3 = rnd("cb.g", (B, 2048), 0.8), rnd("cb.j", (B, 17, 3), 0.5), rnd("cb.v", (B, 431, 3), 0.5)
+    for k in (1, 2):
+        vo, jo = ops.coevo_block(_pmce17(), k, j3.to(dev()), v3.to(dev()), g3.to(dev()))
+        with torch.no_grad():
+            _, rv = O.coevo_block(j3, v3, g3, sd, f"pose_mesh_coevo.coevoblock{k}")
+        e = maxabs(vo, rv)
+        print(f"CoevoBlock {k} (B=3) vs oracle: vertices {e:.2e}")
+        assert jo is None and e < 2e-5
+
+
+def test_gru_all_steps_fixture(golden):
+    """a5: every time step the pruned layer 1 still computes (forward half for t <= 8, backward half for t >= 8) vs the
+    reference nn.GRU's full output y[:, 0, :]; y[8] is the only row Pose2Mesh.forward consumes (CoevoDecoder.py:229)."""
+    from pmce_amd import synth
+    model = _pmce17()
+    p2d, feats = synth.make_inputs(2, 17, 21)
+    model(T(p2d).to(dev()), T(feats).to(dev()))
+    torch.cuda.synchronize()
+    y1 = model._engine.intermediate("Y1", 2, (16, 2, 2048)).cpu()
+    ref = T(golden("modules_J17_C256.npz")["gru_y_all_b0"])           # [16, 2048], batch element 0
+    e_f = maxabs(y1[:9, 0, :1024], ref[:9, :1024])
+    e_b = maxabs(y1[8:, 0, 1024:], ref[8:, 1024:])
+    e_8 = maxabs(y1[8], T(golden("modules_J17_C256.npz")["gru_y8"]))
+    print(f"GRU layer-1 steps vs reference: forward t<=8 {e_f:.2e}, backward t>=8 {e_b:.2e}, y[8] (both clips) {e_8:.2e}")
+    assert e_f < 5e-5 and e_b < 5e-5 and e_8 < 5e-5
+
+
+def test_lifter_block_fixture(golden):
+    """a2/a3: one lifter Block (SpatialBlocks[1]: pre-LN attention over the J tokens + MLP) composed from the path's own
+    operators, vs the reference module's own output."""
+    from pmce_amd import ops, synth
+    sd = cached_state_dict(17, 256)
+    p = "pose_lifter.SpatialBlocks.1."
+    w = {k[len(p):]: v.to(dev()) for k, v in sd.items() if k.startswith(p)}
+    x = T(synth.uniform_pm1("mod.xl", 3 * 17 * 256, 11).reshape(3 * 17, 256)).to(dev())
+    _, xn = ops.ln_chain(x, None, None, 0.0, None, 1, 1, False, w["norm1.weight"], w["norm1.bias"], 1e-6)
+    qkv = ops.gemm_nt(xn, w["attn.qkv.weight"], w["attn.qkv.bias"])
+    ao = ops.seq_attention(qkv, 3, 17, 256, 0, 17, 0, 1)
+    x1 = ops.gemm_nt(ao, w["attn.proj.weight"], w["attn.proj.bias"], residual=x)
+    _, xn2 = ops.ln_chain(x1, None, None, 0.0, None, 1, 1, False, w["norm2.weight"], w["norm2.bias"], 1e-6)
+    h = ops.gemm_nt(xn2, w["mlp.fc1.weight"], w["mlp.fc1.bias"], act=1)
+    x2 = ops.gemm_nt(h, w["mlp.fc2.weight"], w["mlp.fc2.bias"], residual=x1)
+    e = maxabs(x2.reshape(3, 17, 256), T(golden("modules_J17_C256.npz")["lifter_block_s1"]))
+    print(f"lifter block vs reference fixture: {e:.2e}")
+    assert e < 2e-5
