@@ -203,6 +203,185 @@ __global__ __launch_bounds__(256) void seq_attention_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------
+// The same attention for the sequence lengths the path actually runs (N = 16 frames, 17 or 19 joints), second version.
+// The first kernel above is issue- and latency-bound, not memory-bound: one query per lane keeps 17 of every 32 lanes
+// busy, the online softmax rescales the output at every key (3 FMA per key and channel), every lane re-reads all of K
+// and V from LDS, and a sequence's K and V (70 KB at C = 512) leave room for two workgroups per CU only.
+// Here a lane owns TWO queries of one head, so every K/V read from LDS serves two dot products and every multiply-add is
+// a packed v_pk_fma_f32 over the query pair; N is a compile-time constant, so the N scores of a query live in registers
+// and the softmax is two-pass (exact max, one exp per score, no rescaling: 2 FMA per key and channel).  All global
+// traffic is full-row and coalesced: each of q, k, v of the sequence (C contiguous floats per token) is fetched into
+// registers by all 128 threads and spread into LDS as [token][head][HD + 4]; the 4-float pad puts the 8 heads on disjoint
+// bank groups, so a ds_read_b128 whose 16-lane service group spans several heads stays conflict-free.  ONE LDS region
+// is used in turn for Q (until every lane holds its pair in registers), K (pass 1), V (pass 2) and the output tile:
+// 37 KB per sequence at C = 512, four workgroups per CU, and the next array is already in registers (or in flight)
+// when the region changes hands.  Used at C = 512 (HD = 64): 151 / 139 us per spatial / temporal launch against 195 /
+// 179 us (B = 256); at C = 256 the first kernel already runs 16 waves per CU and both sit at ~4 TB/s, so it stays.
+// ------------------------------------------------------------------------------------------------------
+template <int HD, int N>
+__global__ __launch_bounds__(128, 2) void seq_attention_pair_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                 int seq_div, long long seq_lo, long long seq_hi,
+                                                                 long long tok_stride) {
+  constexpr int C = HD * 8, HDP = HD + 4, C4 = C / 4, H4 = HD / 4;
+  constexpr int NP = (N + 1) / 2;      // query pairs per head
+  constexpr int CNT = N * C4;          // float4 per staged array (q, k or v of the whole sequence)
+  constexpr int NIT = (CNT + 127) / 128;
+  extern __shared__ __attribute__((aligned(16))) float R[];  // [N][8][HDP]: Q, then K, then V, then the output tile
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const long long base = (long long)(s % seq_div) * seq_lo + (long long)(s / seq_div) * seq_hi;
+
+  // element idx = tid + 128 u of a staged array is float4 c4 of token j; it lands at [j][head][HD + 4] in LDS
+  auto lds_off = [&](int u) {
+    const int idx = tid + 128 * u;
+    const int j = idx / C4, c4 = idx % C4;
+    return (j * 8 + c4 / H4) * HDP + 4 * (c4 % H4);
+  };
+  auto row_of = [&](int u) {  // tail threads re-read the last row (never stored)
+    const int idx = tid + 128 * u;
+    return qkv + (base + min(idx / C4, N - 1) * tok_stride) * (3 * C) + 4 * (idx % C4);
+  };
+  auto fetch_rows = [&](f32x4(&r)[NIT], int col) {
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) r[u] = *reinterpret_cast<const f32x4*>(row_of(u) + col);
+  };
+  auto spread = [&](const f32x4(&r)[NIT]) {
+#pragma unroll
+    for (int u = 0; u < NIT; ++u)
+      if (tid + 128 * u < CNT) *reinterpret_cast<f32x4*>(R + lds_off(u)) = r[u];
+  };
+
+  // ---- q, then k: every load of an array is issued before the first is used ----
+  f32x4 ra[NIT], rb[NIT];
+  fetch_rows(ra, 0);
+  fetch_rows(rb, C);
+  spread(ra);
+  __syncthreads();
+
+  // ---- this lane's query pair (dense over the 8 * NP pairs of the sequence) ----
+  const bool active = tid < 8 * NP;
+  const int h = active ? tid / NP : 0, pp = active ? tid % NP : 0;
+  const int i0 = 2 * pp, i1 = min(2 * pp + 1, N - 1);
+  // hd^-0.5 * log2(e): scores in log2 units, softmax on the hardware 2^x
+  constexpr float scale = (HD == 32 ? 0.17677669529663688110f : 0.125f) * 1.44269504088896340736f;
+  f32x2 qp[HD];
+  if (active) {
+#pragma unroll
+    for (int d4 = 0; d4 < H4; ++d4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(R + (i0 * 8 + h) * HDP + 4 * d4);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(R + (i1 * 8 + h) * HDP + 4 * d4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) qp[4 * d4 + k] = f32x2{a[k] * scale, b[k] * scale};
+    }
+  }
+  __syncthreads();  // every lane holds its queries: the region takes K
+  spread(rb);
+  __syncthreads();
+
+  // The two passes are software-pipelined by hand: the waves of a CU are few here (one or two per SIMD), so little but a
+  // wave's own instruction order hides the ~100-cycle ds_read latency.  A step is 16 or 32 channels of one key: its four or
+  // eight ds_read_b128 are issued one step ahead into the other half of a two-deep register buffer, and sched_barrier keeps
+  // hipcc from sinking them back next to their uses (left alone it keeps two reads in flight and waits after every
+  // fourth FMA).
+  constexpr int RD = HD == 32 ? 8 : 4;  // ds_read_b128 per step (at HD = 64 the query pair leaves room for 2 x 4 only)
+  constexpr int CPS = 4 * RD;           // channels per step
+  constexpr int SPK = HD / CPS;         // steps per key
+  constexpr int NST = N * SPK;
+  f32x4 buf[2][RD];
+  auto fetch = [&](int st, f32x4(&dst)[RD]) {
+    const float* p = R + ((st / SPK) * 8 + h) * HDP + CPS * (st % SPK);
+#pragma unroll
+    for (int i = 0; i < RD; ++i) dst[i] = *reinterpret_cast<const f32x4*>(p + 4 * i);
+  };
+
+  // ---- pass 1: the N scores of both queries (four independent accumulator chains per key) ----
+  f32x2 sc[N];
+  if (active) {
+    f32x2 a0, a1, a2, a3;
+    fetch(0, buf[0]);
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      if (st + 1 < NST) fetch(st + 1, buf[(st + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (st % SPK == 0) a0 = a1 = a2 = a3 = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < RD; ++i) {
+        const f32x4 k = buf[st & 1][i];
+        const int d = CPS * (st % SPK) + 4 * i;
+        a0 += qp[d + 0] * f32x2{k.x, k.x};
+        a1 += qp[d + 1] * f32x2{k.y, k.y};
+        a2 += qp[d + 2] * f32x2{k.z, k.z};
+        a3 += qp[d + 3] * f32x2{k.w, k.w};
+      }
+      if (st % SPK == SPK - 1) sc[st / SPK] = (a0 + a1) + (a2 + a3);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  fetch_rows(ra, 2 * C);  // the queries are dead: v's loads fly under the softmax and the other workgroups' passes
+  if (active) {
+    // exact two-pass softmax over the N keys, per query
+    f32x2 m = sc[0];
+#pragma unroll
+    for (int j = 1; j < N; ++j) m = f32x2{fmaxf(m.x, sc[j].x), fmaxf(m.y, sc[j].y)};
+    f32x2 sum = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      sc[j] = f32x2{__builtin_amdgcn_exp2f(sc[j].x - m.x), __builtin_amdgcn_exp2f(sc[j].y - m.y)};
+      sum += sc[j];
+    }
+    const f32x2 inv = {1.0f / sum.x, 1.0f / sum.y};
+#pragma unroll
+    for (int j = 0; j < N; ++j) sc[j] *= inv;
+  }
+  __syncthreads();  // nobody reads K any more: the region takes V
+  spread(ra);
+  __syncthreads();
+
+  // ---- pass 2: out = P V (HD independent accumulators per query) ----
+  f32x2 o[HD];
+  if (active) {
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = f32x2{0.f, 0.f};
+    fetch(0, buf[0]);
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      if (st + 1 < NST) fetch(st + 1, buf[(st + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < RD; ++i) {
+        const f32x4 v = buf[st & 1][i];
+        const int d = CPS * (st % SPK) + 4 * i;
+        o[d + 0] += sc[st / SPK] * f32x2{v.x, v.x};
+        o[d + 1] += sc[st / SPK] * f32x2{v.y, v.y};
+        o[d + 2] += sc[st / SPK] * f32x2{v.z, v.z};
+        o[d + 3] += sc[st / SPK] * f32x2{v.w, v.w};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();  // nobody reads V any more: the region takes the output tile, [token][head][HDP] like the inputs
+  if (active) {
+#pragma unroll
+    for (int d4 = 0; d4 < H4; ++d4) {
+      *reinterpret_cast<f32x4*>(R + (i0 * 8 + h) * HDP + 4 * d4) =
+          f32x4{o[4 * d4].x, o[4 * d4 + 1].x, o[4 * d4 + 2].x, o[4 * d4 + 3].x};
+      // odd N: the last pair's second query duplicates its first (i1 == i0), so this rewrites the same values - an
+      // unconditional store (a predicated one makes hipcc spill hundreds of registers here)
+      *reinterpret_cast<f32x4*>(R + (i1 * 8 + h) * HDP + 4 * d4) =
+          f32x4{o[4 * d4].y, o[4 * d4 + 1].y, o[4 * d4 + 2].y, o[4 * d4 + 3].y};
+    }
+  }
+  __syncthreads();
+  // ---- LDS -> global, full rows ----
+#pragma unroll
+  for (int u = 0; u < NIT; ++u) {
+    const int idx = tid + 128 * u;
+    if (idx < CNT)
+      *reinterpret_cast<f32x4*>(out + (base + (idx / C4) * tok_stride) * C + 4 * (idx % C4)) =
+          *reinterpret_cast<const f32x4*>(R + lds_off(u));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // regression head + frame fusion (PoseEstimation.py:62-66,109-113): one wavefront per (b, j):
 //   p[t] = Wr * LN_{1e-5}(x[b,t,j,:]) + br ;  pose3d[b,j,:] = sum_t wf[t]*p[t] + bf
 // ------------------------------------------------------------------------------------------------------
@@ -325,11 +504,34 @@ extern "C" int pmce_window_rows_f32(const float* src, const int* win, float* dst
   return pmce_check_launch("window_rows");
 }
 
+template <int HD, int N>
+static int launch_seq_attention_pair(const float* qkv, float* out, int nseq, int seq_div, long long seq_lo, long long seq_hi,
+                                     long long tok_stride, hipStream_t stream) {
+  constexpr int lds = N * 8 * (HD + 4) * (int)sizeof(float);
+  if (lds > 65536) {
+    static std::atomic<unsigned long long> attr{0};
+    PMCE_TRY(pmce_opt_in_lds((const void*)seq_attention_pair_kernel<HD, N>, lds, attr, "seq_attention"));
+  }
+  hipLaunchKernelGGL((seq_attention_pair_kernel<HD, N>), dim3(nseq), dim3(128), lds, stream, qkv, out, seq_div, seq_lo,
+                     seq_hi, tok_stride);
+  return pmce_check_launch("seq_attention");
+}
+
 extern "C" int pmce_seq_attention_f32(const float* qkv, float* out, int nseq, int N, int C, int seq_div, long long seq_lo,
                                       long long seq_hi, long long tok_stride, hipStream_t stream) {
   PMCE_REQUIRE(C == 256 || C == 512, "seq_attention: C must be 256 or 512 (8 heads of 32/64)");
   PMCE_REQUIRE(N >= 1 && N <= 32 && nseq > 0, "seq_attention: N must be in 1..32 (got %d)", N);
   if (seq_div <= 0) seq_div = 0x7fffffff;
+  static const int force_v1 = pmce_env_int("PMCE_SEQ_ATTN_V1", 0);  // A/B knob, read once
+  if (!force_v1) {  // the sequence lengths of the path: 16 frames, 17 (H36M) or 19 (COCO + pelvis, neck) joints
+    // C = 512 only: at C = 256 both kernels sit at the same ~4 TB/s (the first one already has 16 waves per CU there)
+#define PMCE_PAIR(HD_, N_) \
+  if (C == 8 * HD_ && N == N_) return launch_seq_attention_pair<HD_, N_>(qkv, out, nseq, seq_div, seq_lo, seq_hi, tok_stride, stream)
+    PMCE_PAIR(64, 16);
+    PMCE_PAIR(64, 17);
+    PMCE_PAIR(64, 19);
+#undef PMCE_PAIR
+  }
   const size_t lds = (size_t)2 * N * C * sizeof(float);
   if (C == 256) {
     static std::atomic<unsigned long long> attr256{0};

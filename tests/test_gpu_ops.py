@@ -112,7 +112,7 @@ def test_ln_chain(C):
     assert maxabs(o3, F.layer_norm(x.double(), (C,), w2.double(), b2.double(), 1e-6)) < 5e-6
 
 
-@pytest.mark.parametrize("C,J", [(256, 17), (256, 19), (512, 17)])
+@pytest.mark.parametrize("C,J", [(256, 17), (256, 19), (512, 17), (512, 19)])
 def test_seq_attention(C, J):
     from pmce_amd import ops
     B, Tn, H = 2, 16, 8
