@@ -353,6 +353,15 @@ def latency_record(model, dev, J, calls=200):
                              "min_ms": round(ts[0], 4)}
             except Exception as e:  # noqa: BLE001
                 rec[mode] = {"error": str(e)[:200]}
+        # where a single small forward spends its time: HIP events around every launch, one stream (3 forwards)
+        model.profile(True)
+        for _ in range(3):
+            model.forward_with_joints(p, f)
+        torch.cuda.synchronize()
+        prof = model.profile_read()
+        model.profile(False)
+        rec["kernel_ms_single_stream"] = {k: round(v[0] / 3, 4) for k, v in prof.items() if v[1] > 0 and v[0] / 3 >= 0.01}
+        rec["kernel_ms_total_single_stream"] = round(sum(v[0] for v in prof.values()) / 3, 4)
         out[f"B{B}"] = rec
     out["calls"] = calls
     out["what"] = "forward_with_joints + device synchronize, host clock"

@@ -172,6 +172,17 @@ int pmce_vertex_ca_f32(const float* xq, const float* vt, const float* Wv3, const
 int pmce_adaln_mlp_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* W1, const float* b1,
                        const float* W2, const float* b2, float* yout, const float* Wc, const float* bc, const float* vt_in,
                        float* vt_out, int B, pmce_stream_t stream);
+
+/* The whole CrossAttentionBlock of the vertex stream in one launch (reference CoevoDecoder.py:82-87): vertex_ca followed by
+ * its FFN (adaln_mlp with AdaLN instance `inst` of GB), the intermediate never leaving registers; arguments as those two.
+ * Same arithmetic in the same order as pmce_vertex_ca_f32 + pmce_adaln_mlp_f32.  J <= 23 runs fused; beyond that one clip's
+ * folded operands do not fit beside the FFN weights in LDS and the call runs the two kernels through `scratch` [B,431,64]
+ * (may be NULL when J <= 23). */
+int pmce_vertex_ca_mlp_f32(const float* xq, const float* vt, const float* Wv3, const float* Eq, const float* Kf,
+                           const float* s0, const float* Vf, const float* bp, const float* GB, int gb_stride, int inst,
+                           const float* W1, const float* b1, const float* W2, const float* b2, float* yout, float* scratch,
+                           int B, int J, pmce_stream_t stream);
+
 /* qkv = Linear(64->192)(AdaLN(x)) on [B,431,64] (CoevoDecoder.py:103,120). */
 int pmce_adaln_qkv_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* Wqkv, const float* bqkv,
                        float* qkv, int B, pmce_stream_t stream);

@@ -381,6 +381,194 @@ __global__ __launch_bounds__(512) void adaln_mlp_kernel(const float* __restrict_
 }
 
 // ======================================================================================================
+// vertex_ca_mlp - the whole CrossAttentionBlock of the vertex stream in one launch (CoevoDecoder.py:82-87):
+//   F1 = xq + CA(AdaLN_q(xq), AdaLN_k(xk), AdaLN_v(xv))   (vertex_ca above, key/value side pre-folded by ca_fold)
+//   F2 = F1 + Mlp(AdaLN_2(F1))                             (adaln_mlp above)
+// F1 never leaves the registers of the wave that made it.  Persistent workgroups of 7 waves keep fc1/fc2 in LDS (137 KB) for
+// the whole launch, which leaves 26 KB: enough for ONE clip's folded operands in compact form - of Kf only the J live
+// rows per head, of Vf only the key groups below J (3 of 4 per head up to J = 24) - so a work item is half a clip
+// (7 wave tiles, one per wave, like vertex_ca's grid) and the operands are re-staged between items.  J <= 23; the
+// launcher falls back to the two kernels above beyond that.  Same arithmetic in the same order as vertex_ca + adaln_mlp.
+// ======================================================================================================
+#define CAM_VLD 52  // Vf compact row stride: 2 heads x 24 keys + 4 (conflict-free ds_read_b128 across 32 rows)
+__global__ __launch_bounds__(448) void vertex_ca_mlp_kernel(const float* __restrict__ xq, const float* __restrict__ vt,
+                                                            const float* __restrict__ Wv3, const float* __restrict__ Eq,
+                                                            const float* __restrict__ Kf, const float* __restrict__ s0,
+                                                            const float* __restrict__ Vf, const float* __restrict__ bp,
+                                                            const float* __restrict__ GB, int gb_stride, int inst,
+                                                            const float* __restrict__ W1, const float* __restrict__ b1,
+                                                            const float* __restrict__ W2, const float* __restrict__ b2,
+                                                            float* __restrict__ yout, int B, int J) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sW1 = smem;                    // [256][68]
+  float* sW2 = sW1 + 256 * LDW64;       // [64][260]
+  float* sB1 = sW2 + 64 * LDW256;       // [256]
+  float* sB2 = sB1 + 256;               // [64]
+  float* sS0 = sB2 + 64;                // [2][32]
+  float* sV = sS0 + 64;                 // [64][CAM_VLD]   Vf[c][h*24 + i], i < 24
+  float* sK = sV + 64 * CAM_VLD;        // [2*J][68]       Kf[h*J + i][c], i < J
+  const int tid = threadIdx.x;
+  stage_weight<64>(sW1, W1, 256, tid, 448);
+  stage_weight<256>(sW2, W2, 64, tid, 448);
+  if (tid < 256) sB1[tid] = b1[tid];
+  if (tid < 64) sB2[tid] = b2[tid];
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n0 = lane & 31, hb = lane >> 5;
+  const int krow = min(n0, J - 1);  // rows >= J of a head's score tile are masked below: any finite operand will do
+  for (int item = blockIdx.x; item < 2 * B; item += gridDim.x) {
+    const int b = item >> 1;
+    const int tile = (item & 1) * 7 + wave;
+    const int v = tile * 32 + n0;
+    const bool valid = v < NV;
+    const int vc = valid ? v : NV - 1;
+    const long long tok = (long long)b * NV + vc;
+    // this wave's 32 query tokens first: their latency hides under the staging of the clip's folded operands
+    float x[32];
+    if (xq) {
+      load_slots(xq + tok * 64, x, hb);
+    } else {
+      const float* p = vt + tok * 3;
+      const float p0 = p[0], p1 = p[1], p2 = p[2];
+      load_slots(Eq + (long long)vc * 64, x, hb);
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        const int c = slot_channel(s, hb);
+        x[s] = (Wv3[c * 3] * p0 + Wv3[c * 3 + 1] * p1 + Wv3[c * 3 + 2] * p2) + x[s];
+      }
+    }
+    __syncthreads();  // the previous item's operands are no longer read (and, first time, the weights are staged)
+    {
+      const float* Kb = Kf + (long long)b * 4096;
+      const float* Vb = Vf + (long long)b * 4096;
+      for (int i = tid; i < 2 * J * 16; i += 448) {  // Kf rows (h, i < J), 16 float4 each
+        const int r = i >> 4, c4 = i & 15;
+        const int h = r / J, ii = r - h * J;
+        *reinterpret_cast<f32x4*>(sK + r * LDW64 + 4 * c4) = *reinterpret_cast<const f32x4*>(Kb + (h * 32 + ii) * 64 + 4 * c4);
+      }
+      for (int i = tid; i < 64 * 12; i += 448) {  // Vf row c: keys 0..23 of both heads, 12 float4
+        const int c = i / 12, k4 = i - c * 12;
+        const int h = k4 / 6, j4 = k4 - h * 6;
+        *reinterpret_cast<f32x4*>(sV + c * CAM_VLD + h * 24 + 4 * j4) = *reinterpret_cast<const f32x4*>(Vb + c * 64 + h * 32 + 4 * j4);
+      }
+      if (tid < 64) sS0[tid] = s0[(long long)b * 64 + tid];
+    }
+    // ---- cross-attention (vertex_ca_kernel) ----
+    {
+      float n[32];
+      {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) s += x[i];
+        const float mean = pair_sum(s) * (1.0f / 64.0f);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          const float d = x[i] - mean;
+          ss += d * d;
+        }
+        const float inv = 1.0f / (sqrtf(pair_sum(ss) * (1.0f / 63.0f)) + 1e-6f);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) n[i] = (x[i] - mean) * inv;
+      }
+      __syncthreads();
+      f32x16 sc[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[h][r] = sS0[h * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(sK + (nt * J + krow) * LDW64 + 8 * q + 4 * hb);
+          sc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, n[4 * q + 0], sc[nt], 0, 0, 0);
+          sc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, n[4 * q + 1], sc[nt], 0, 0, 0);
+          sc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, n[4 * q + 2], sc[nt], 0, 0, 0);
+          sc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, n[4 * q + 3], sc[nt], 0, 0, 0);
+        }
+      }
+      float p[32];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * hb;
+          const float sv = (i < J) ? sc[h][r] : -INFINITY;
+          sc[h][r] = sv;
+          m = fmaxf(m, sv);
+        }
+        m = pair_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(sc[h][r] - m);  // scores are in log2 units (ca_fold)
+          p[16 * h + r] = e;
+          sum += e;
+        }
+        const float inv = 1.0f / pair_sum(sum);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[16 * h + r] *= inv;
+      }
+      f32x16 o[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[nt][r] = bp[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if ((q & 3) < 3 && 8 * (q & 3) < J) {  // wave-uniform: key groups beyond J carry P = 0 (J <= 23: at most 3 per head)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const f32x4 w =
+                *reinterpret_cast<const f32x4*>(sV + (nt * 32 + n0) * CAM_VLD + (q >> 2) * 24 + 8 * (q & 3) + 4 * hb);
+            o[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, p[4 * q + 0], o[nt], 0, 0, 0);
+            o[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, p[4 * q + 1], o[nt], 0, 0, 0);
+            o[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, p[4 * q + 2], o[nt], 0, 0, 0);
+            o[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, p[4 * q + 3], o[nt], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[16 * nt + r] = x[16 * nt + r] + o[nt][r];  // F1 (stays in registers)
+    }
+    // ---- FFN (adaln_mlp_kernel) ----
+    float a[32];
+    adaln_slots(x, a, GB + (long long)b * gb_stride + inst * 128, hb);
+    f32x16 acc2[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[nt][r] = sB2[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb] + x[16 * nt + r];
+#pragma unroll 1
+    for (int ht = 0; ht < 8; ++ht) {
+      f32x16 acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[r] = sB1[ht * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb];
+      tl_gemm<8, 1, LDW64>(sW1 + ht * 32 * LDW64, a, &acc1, n0, hb);
+      float hreg[16];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 g = gelu_erf2(f32x2{acc1[r], acc1[r + 1]});
+        hreg[r] = g.x;
+        hreg[r + 1] = g.y;
+      }
+      tl_gemm<4, 2, LDW256>(sW2 + ht * 32, hreg, acc2, n0, hb);
+    }
+    if (valid) {
+      float y[32];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[16 * nt + r] = acc2[nt][r];
+      store_slots(yout + tok * 64, y, hb);
+    }
+  }
+}
+
+// ======================================================================================================
 // adaln_qkv: qkv[tok][0:192] = Wqkv * AdaLN(x) + bqkv   (vertex self-attention input, CoevoDecoder.py:103,120)
 // ======================================================================================================
 __global__ __launch_bounds__(256) void adaln_qkv_kernel(const float* __restrict__ xin, const float* __restrict__ GB,
@@ -940,6 +1128,27 @@ extern "C" int pmce_adaln_mlp_f32(const float* xin, const float* GB, int gb_stri
   hipLaunchKernelGGL(adaln_mlp_kernel, dim3(mlp_grid(B)), dim3(512), lds, stream, xin, GB, gb_stride, inst, W1, b1, W2, b2,
                      yout, Wc, bc, vt_in, vt_out, B);
   return pmce_check_launch("adaln_mlp");
+}
+
+extern "C" int pmce_vertex_ca_mlp_f32(const float* xq, const float* vt, const float* Wv3, const float* Eq, const float* Kf,
+                                      const float* s0, const float* Vf, const float* bp, const float* GB, int gb_stride,
+                                      int inst, const float* W1, const float* b1, const float* W2, const float* b2, float* yout,
+                                      float* scratch, int B, int J, hipStream_t stream) {
+  PMCE_REQUIRE((xq || (vt && Wv3 && Eq)) && Kf && s0 && Vf && bp && GB && W1 && b1 && W2 && b2 && yout,
+               "vertex_ca_mlp: null pointer");
+  PMCE_REQUIRE(J >= 1 && J <= 32 && B > 0, "vertex_ca_mlp: J must be in 1..32");
+  if (J > 23) {  // one clip's folded operands no longer fit beside the FFN weights: the two-launch form
+    PMCE_REQUIRE(scratch, "vertex_ca_mlp: J > 23 needs a [B,431,64] scratch buffer");
+    PMCE_TRY(pmce_vertex_ca_f32(xq, vt, Wv3, Eq, Kf, s0, Vf, bp, scratch, B, J, stream));
+    return pmce_adaln_mlp_f32(scratch, GB, gb_stride, inst, W1, b1, W2, b2, yout, nullptr, nullptr, nullptr, nullptr, B, stream);
+  }
+  const size_t lds = (size_t)(256 * LDW64 + 64 * LDW256 + 256 + 64 + 64 + 64 * CAM_VLD + 2 * J * LDW64) * sizeof(float);
+  static std::atomic<unsigned long long> attr{0};
+  PMCE_TRY(pmce_opt_in_lds((const void*)vertex_ca_mlp_kernel, 163840, attr, "vertex_ca_mlp"));
+  const int g = 2 * B < 256 ? 2 * B : 256;
+  hipLaunchKernelGGL(vertex_ca_mlp_kernel, dim3(g), dim3(448), lds, stream, xq, vt, Wv3, Eq, Kf, s0, Vf, bp, GB, gb_stride, inst,
+                     W1, b1, W2, b2, yout, B, J);
+  return pmce_check_launch("vertex_ca_mlp");
 }
 
 extern "C" int pmce_adaln_qkv_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* Wqkv,

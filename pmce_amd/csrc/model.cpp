@@ -25,12 +25,12 @@ constexpr int N_ADA = 24;      // live AdaLN instances (joint stream
 
 enum ProfClass {
   P_GEMM_LIFTER, P_GEMM_GRU_IN, P_GRU_STEP, P_GEMM_ADA, P_GEMM_FINAL, P_LN, P_SEQ_ATTN, P_EMBED, P_HEAD,
-  P_GATHER, P_JOINT_EMBED, P_CA_FOLD, P_VERTEX_CA, P_ADALN_MLP, P_ADALN_QKV, P_VERTEX_SA, P_TOKENS_KV, P_JOINT_STREAM,
+  P_GATHER, P_JOINT_EMBED, P_CA_FOLD, P_VERTEX_CA, P_VERTEX_CA_MLP, P_ADALN_MLP, P_ADALN_QKV, P_VERTEX_SA, P_TOKENS_KV, P_JOINT_STREAM,
   P_FINAL_OP, P_JREG, P_MISC, P_COUNT
 };
 const char* kProfNames[P_COUNT] = {
     "gemm_lifter", "gemm_gru_in", "gru_step", "gemm_ada", "gemm_final", "ln_chain", "seq_attention", "embed_tokens",
-    "lifter_head", "vertex_init_gather", "joint_embed", "ca_fold", "vertex_ca", "adaln_mlp", "adaln_qkv",
+    "lifter_head", "vertex_init_gather", "joint_embed", "ca_fold", "vertex_ca", "vertex_ca_mlp", "adaln_mlp", "adaln_qkv",
     "vertex_sa", "tokens_kv", "joint_stream", "build_final_operand", "j_regress", "misc"};
 
 struct Ev {
@@ -84,6 +84,7 @@ struct pmce_model {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
   hipEvent_t ev_lifter = nullptr;  // recorded by pmce_forward when its pose lifter is enqueued (pmce_model_wait_lifter)
   bool concurrent = true;  // pmce_model_set_concurrency
+  bool fused_ca = true;    // CrossAttentionBlock of the vertex stream as one launch (PMCE_VERTEX_FUSED=0 at create: two)
   // regressor (optional)
   const int* jr_indptr = nullptr;
   const int* jr_indices = nullptr;
@@ -499,11 +500,16 @@ int vertex_block(pmce_model* m, int k, const float* vt_cur, float* vt_next, int 
   const int J = m->J, gbs = N_ADA * 128;
   const VertexBlockW& v = m->w.vb[k - 1];
   const int ib = (k - 1) * 6;  // AdaLN instances: vca.normq,normk,normv,norm2, vsa.norm1,norm2
-  RUN(P_VERTEX_CA, pmce_vertex_ca_f32(nullptr, vt_cur, v.vertx_proj_w, v.Eq, w.KF[k - 1],
-                                      w.S0[k - 1], w.VF[k - 1], v.vca_proj_b, w.F1, B, J, stream));
-  RUN(P_ADALN_MLP, pmce_adaln_mlp_f32(w.F1, w.GB, gbs, ib + 3, v.vca_fc1_w, v.vca_fc1_b,
-                                      v.vca_fc2_w, v.vca_fc2_b, w.F2, nullptr, nullptr,
-                                      nullptr, nullptr, B, stream));
+  if (m->fused_ca) {  // CrossAttentionBlock (CoevoDecoder.py:82-87) in one launch, bit-identical to the two below
+    RUN(P_VERTEX_CA_MLP, pmce_vertex_ca_mlp_f32(nullptr, vt_cur, v.vertx_proj_w, v.Eq, w.KF[k - 1], w.S0[k - 1], w.VF[k - 1],
+                                                v.vca_proj_b, w.GB, gbs, ib + 3, v.vca_fc1_w, v.vca_fc1_b, v.vca_fc2_w,
+                                                v.vca_fc2_b, w.F2, w.F1, B, J, stream));
+  } else {
+    RUN(P_VERTEX_CA, pmce_vertex_ca_f32(nullptr, vt_cur, v.vertx_proj_w, v.Eq, w.KF[k - 1], w.S0[k - 1], w.VF[k - 1],
+                                        v.vca_proj_b, w.F1, B, J, stream));
+    RUN(P_ADALN_MLP, pmce_adaln_mlp_f32(w.F1, w.GB, gbs, ib + 3, v.vca_fc1_w, v.vca_fc1_b, v.vca_fc2_w, v.vca_fc2_b, w.F2, nullptr,
+                                        nullptr, nullptr, nullptr, B, stream));
+  }
   RUN(P_ADALN_QKV, pmce_adaln_qkv_f32(w.F2, w.GB, gbs, ib + 4, v.vsa_qkv_w, v.vsa_qkv_b, w.QKV, B,
                                       stream));
   RUN(P_VERTEX_SA, pmce_vertex_sa_f32(w.F2, w.QKV, v.vsa_proj_w, v.vsa_proj_b, w.F1, B, stream));
@@ -609,6 +615,7 @@ int pmce_model_create(int num_joint, int embed_dim, int depth, pmce_model** out)
   m->C = embed_dim;
   m->depth = depth;
   m->concurrent = getenv("PMCE_SINGLE_STREAM") == nullptr;
+  m->fused_ca = pmce_env_int("PMCE_VERTEX_FUSED", 1) != 0;
   build_names(m);
   *out = m;
   return PMCE_OK;

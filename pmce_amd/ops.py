@@ -96,6 +96,33 @@ def cross_attn_vertex(xq, xk, xv, g, sd, p):
     return out
 
 
+def cross_attn_block_vertex(xq, xk, xv, g, sd, p):
+    """The whole vertex-stream CrossAttentionBlock in one launch (CoevoDecoder.py:82-87), p = '...vertx_CA_FFN':
+    xq + CA(...) then + Mlp(AdaLN_2(.)).  Bit-identical to cross_attn_vertex followed by adaln_mlp."""
+    lib = _lib.load()
+    xq, xk, xv = _c(xq), _c(xk), _c(xv)
+    B, Nq, _ = xq.shape
+    J = xk.shape[1]
+    assert Nq == 431
+    GB = adaln_params(g, sd, [p + ".normq", p + ".normk", p + ".normv", p + ".norm2"])
+    dev = xq.device
+    Kf = torch.empty(B, 64, 64, device=dev)
+    s0 = torch.empty(B, 64, device=dev)
+    Vf = torch.empty(B, 64, 64, device=dev)
+    w = {k: _c(sd[f"{p}.attn.{k}"]) for k in ("wq.weight", "wq.bias", "wk.weight", "wk.bias", "wv.weight", "wv.bias",
+                                              "proj.weight", "proj.bias")}
+    _lib.check(lib.pmce_ca_fold_f32(P(xk), P(xv), P(GB), GB.shape[1], 0, 1, 2, P(w["wq.weight"]), P(w["wq.bias"]),
+                                    P(w["wk.weight"]), P(w["wk.bias"]), P(w["wv.weight"]), P(w["wv.bias"]),
+                                    P(w["proj.weight"]), P(Kf), P(s0), P(Vf), B, J, _st()), "ca_fold")
+    m = [_c(sd[p + k]) for k in (".mlp.fc1.weight", ".mlp.fc1.bias", ".mlp.fc2.weight", ".mlp.fc2.bias")]
+    out = torch.empty_like(xq)
+    scratch = torch.empty_like(xq) if J > 23 else None
+    _lib.check(lib.pmce_vertex_ca_mlp_f32(P(xq), None, None, None, P(Kf), P(s0), P(Vf), P(w["proj.bias"]), P(GB), GB.shape[1],
+                                          3, P(m[0]), P(m[1]), P(m[2]), P(m[3]), P(out), P(scratch), B, J, _st()),
+               "vertex_ca_mlp")
+    return out
+
+
 def adaln_mlp(x, g, sd, p_norm, p_mlp, coor=None, vt_in=None, want_features=True):
     """x + Mlp(AdaLN(x)) on [B,431,64]; optional coordinate head (Wc[3,64], bc[3]) + vt_in residual."""
     lib = _lib.load()

@@ -185,6 +185,34 @@ def test_cross_attn_vertex(golden):
     assert maxabs(out3, ref3) < 2e-5
 
 
+def test_cross_attn_block_vertex_fused(golden):
+    """The whole vertex-stream CrossAttentionBlock in one launch (CoevoDecoder.py:82-87): vs the reference module's own
+    output (cab_v_from_j), vs the oracle on a batch with a ragged tail, and against the two-launch form (same arithmetic in
+    the same order; hipcc contracts a few multiply-adds differently in the fused body, so equal to an ulp or two, not bitwise);
+    J = 25 takes the launcher's two-kernel fallback (one clip's folded operands no longer fit beside the FFN weights)."""
+    from oracle import pmce_oracle as O
+    from pmce_amd import ops
+    sd = cached_state_dict(17, 256)
+    p = BLK + ".vertx_CA_FFN"
+    sdd = sd_dev(sd, p)
+    g, xv, xj = _mod_inputs()
+    out = ops.cross_attn_block_vertex(xv.to(dev()), xj.to(dev()), xj.to(dev()), g.to(dev()), sdd, p)
+    e_ref = maxabs(out, T(golden("modules_J17_C256.npz")["cab_v_from_j"]))
+    B = 5
+    for J in (17, 19, 23, 25):
+        g3, xq3, xk3 = rnd("cab.g", (B, 2048), 0.8), rnd("cab.xq", (B, 431, 64), 1.5), rnd("cab.xk", (B, J, 64), 1.5)
+        fused = ops.cross_attn_block_vertex(xq3.to(dev()), xk3.to(dev()), xk3.to(dev()), g3.to(dev()), sdd, p)
+        f1 = ops.cross_attn_vertex(xq3.to(dev()), xk3.to(dev()), xk3.to(dev()), g3.to(dev()), sdd, p)
+        two, _ = ops.adaln_mlp(f1, g3.to(dev()), sdd, p + ".norm2", p + ".mlp")
+        with torch.no_grad():
+            ref3 = O.cross_attention_block(xq3, xk3, xk3, g3, sd, p, 2)
+        e_or, e_two = maxabs(fused, ref3), maxabs(fused, two)
+        print(f"fused CrossAttentionBlock J={J}: vs oracle {e_or:.2e}; vs vertex_ca + adaln_mlp {e_two:.2e}")
+        assert e_or < 2e-5 and e_two < 5e-6
+    print(f"fused CrossAttentionBlock vs reference fixture {e_ref:.2e}")
+    assert e_ref < 2e-5
+
+
 def test_adaln_mlp(golden):
     from oracle import pmce_oracle as O
     from pmce_amd import ops
