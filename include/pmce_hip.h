@@ -128,6 +128,9 @@ int pmce_gemm_nt_f32(const float* A, const float* W, const float* bias, const fl
                      long long lda, int ldw, long long ldc, int act, int a_div, long long a_lo, long long a_hi, int c_div,
                      long long c_lo, long long c_hi, int batch, long long bsA, long long bsW, long long bsBias,
                      long long bsC, pmce_stream_t stream);
+/* Tuning aid only: force the tile configuration (0..3, -1 = automatic) and the persistent workgroups per CU (1..8, 0 =
+ * automatic) of pmce_gemm_nt_f32 for the whole process (initial values: PMCE_GEMM_TILE / PMCE_GEMM_GRID, read once). */
+int pmce_gemm_set_tuning(int tile, int grid_per_cu);
 
 /* PoseEstimation.py:78-81 — x[tok] = joint_embed(pose2d) + imgfeat_embed(img_feat)[b,t] + spatial_pos[j]. */
 int pmce_embed_tokens_f32(const float* pose2d, const float* E, const float* Wje, const float* bje, const float* spos,

@@ -407,10 +407,20 @@ static void launch_gemm(const GemmParams& p, int batch, bool cmap, hipStream_t s
 // ceil(ceil(tiles / 8) / 32) tiles of BM x BN.  M = B*16*J is rarely a multiple of 128*256 (B=256, J=17: 544 row tiles
 // of 128), so the shape that quantises best wins; `ovh` is the measured per-area handicap of the smaller tiles at large
 // K (twice the operand traffic per FLOP for 64x64).  Blocks per CU (LDS: 2 x (BM+BN) x 128 B; VGPRs) only size the grid.
+// Tuning overrides (never set in production): initialised ONCE from PMCE_GEMM_TILE / PMCE_GEMM_GRID, changed only through
+// pmce_gemm_set_tuning (scripts/gemm_sweep.py) - no environment reads on the launch path.
+static std::atomic<int> g_force_tile{pmce_env_int("PMCE_GEMM_TILE", -1)};
+static std::atomic<int> g_force_grid{pmce_env_int("PMCE_GEMM_GRID", 0)};
+extern "C" int pmce_gemm_set_tuning(int tile, int grid_per_cu) {
+  g_force_tile.store(tile, std::memory_order_relaxed);
+  g_force_grid.store(grid_per_cu, std::memory_order_relaxed);
+  return PMCE_OK;
+}
+
 struct TileCfg { int bm, bn, bpc; double ovh; };
 static const TileCfg kTiles[] = {{128, 128, 2, 1.0}, {96, 128, 2, 1.015}, {64, 128, 3, 1.03}, {64, 64, 4, 1.03}};
 static int pick_tile(int M, int N, int batch) {
-  static const int forced = pmce_env_int("PMCE_GEMM_TILE", -1);  // tuning/debug knob, read once: force a tile config (0..3)
+  const int forced = g_force_tile.load(std::memory_order_relaxed);  // tuning/debug knob: force a tile config (0..3)
   if (forced >= 0 && forced < 4) return forced;
   int best = 0;
   double best_cost = 1e300;
@@ -454,7 +464,7 @@ extern "C" int pmce_gemm_nt_f32(const float* A, const float* W, const float* bia
   p.ntm = (M + kTiles[ti].bm - 1) / kTiles[ti].bm;
   p.ntn = (N + kTiles[ti].bn - 1) / kTiles[ti].bn;
   p.grid_cap = 256 * kTiles[ti].bpc;
-  static const int grid_knob = pmce_env_int("PMCE_GEMM_GRID", 0);  // tuning knob, read once: persistent workgroups per CU
+  const int grid_knob = g_force_grid.load(std::memory_order_relaxed);  // tuning knob: persistent workgroups per CU
   if (grid_knob >= 1 && grid_knob <= 8) p.grid_cap = 256 * grid_knob;
   switch (ti) {
     case 0: launch_gemm<128, 128, 2>(p, batch, cmap, stream); break;

@@ -9,7 +9,8 @@ sys.path.insert(0, os.environ["REPO"])
 import torch
 from pmce_amd import ops
 dev = torch.device("cuda:0")
-for (M, N, K, act, res) in [(69632, 768, 256, 0, False), (69632, 256, 256, 0, True), (69632, 512, 256, 1, False), (4096, 6144, 2048, 0, False)]:
+for (M, N, K, act, res) in [(69632, 768, 256, 0, False), (69632, 256, 256, 0, True), (69632, 512, 256, 1, False), (4096, 6144, 2048, 0, False),
+                            (69632, 1536, 512, 0, False), (69632, 512, 512, 0, True), (69632, 1024, 512, 1, False), (69632, 512, 1024, 0, True)]:
     A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) * K ** -0.5; b = torch.randn(N, device=dev)
     R = torch.randn(M, N, device=dev) if res else None
     out = torch.empty(M, N, device=dev)
@@ -29,7 +30,7 @@ for f in glob.glob("gpurun_out/gpmc/**/*counter_collection.csv", recursive=True)
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
         if "gemm_nt" not in name: continue
-        key = name.split("(")[0].replace("void gemm_nt_kernel", "gemm") + f" grid={row.get('Grid_Size','?')}"
+        key = name.split("(")[0].replace("void gemm_nt_kernel", "gemm") + f" grid={row.get('Grid_Size','?')} lds={row.get('LDS_Block_Size','?')}"
         a = agg[key][row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
 for k in sorted(agg):
     print(k)

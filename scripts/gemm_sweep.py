@@ -3,14 +3,17 @@ Configs are interleaved round-robin and the best of 4 rounds is reported, so clo
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from pmce_amd import ops
+from pmce_amd import _lib, ops
+
+lib = _lib.load()
 
 dev = torch.device("cuda:0")
 shapes = [  # name, M, N, K, act, res
     ("qkv", 69632, 768, 256, 0, False), ("proj", 69632, 256, 256, 0, True), ("fc1", 69632, 512, 256, 1, False),
     ("fc2", 69632, 256, 512, 0, True), ("gi0", 4096, 6144, 2048, 0, False), ("gi1", 2304, 3072, 2048, 0, False),
     ("final", 256, 20670, 3360, 0, False), ("ada", 256, 3072, 2048, 0, False), ("imgfeat", 4096, 256, 2048, 0, False),
-    ("qkv512", 69632, 1536, 512, 0, False), ("qkvJ19", 77824, 768, 256, 0, False),
+    ("qkv512", 69632, 1536, 512, 0, False), ("proj512", 69632, 512, 512, 0, True), ("fc1_512", 69632, 1024, 512, 1, False),
+    ("fc2_512", 69632, 512, 1024, 0, True), ("qkvJ19", 77824, 768, 256, 0, False),
 ]
 names = ["128x128", "96x128", "64x128", "64x64", "auto", "64x128/g3", "96x128/g3?", "64x64/g5"]
 cfgs = [(0, None), (1, None), (2, None), (3, None), (None, None), (2, 3), (1, 3), (3, 5)]
@@ -23,9 +26,7 @@ for name, M, N, K, act, res in shapes:
     best = [1e9] * len(cfgs)
     for rnd in range(4):
         for t, (tile, grid) in enumerate(cfgs):
-            os.environ.pop("PMCE_GEMM_TILE", None); os.environ.pop("PMCE_GEMM_GRID", None)
-            if tile is not None: os.environ["PMCE_GEMM_TILE"] = str(tile)
-            if grid is not None: os.environ["PMCE_GEMM_GRID"] = str(grid)
+            lib.pmce_gemm_set_tuning(-1 if tile is None else tile, 0 if grid is None else grid)
             ops.gemm_nt(A, W, b, R, act, out=out)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -34,5 +35,5 @@ for name, M, N, K, act, res in shapes:
             for _ in range(n): ops.gemm_nt(A, W, b, R, act, out=out)
             e1.record(); torch.cuda.synchronize()
             best[t] = min(best[t], e0.elapsed_time(e1) / n)
-    os.environ.pop("PMCE_GEMM_TILE", None); os.environ.pop("PMCE_GEMM_GRID", None)
+    lib.pmce_gemm_set_tuning(-1, 0)
     print(f"{name:8s} M={M} N={N} K={K}: " + " | ".join(f"{names[t]} {best[t]*1e3:7.1f}us {2.0*M*N*K/best[t]/1e9:6.1f}TF" for t in range(len(cfgs))), flush=True)
