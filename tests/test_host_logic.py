@@ -228,3 +228,26 @@ def test_checkpoint_loading_does_not_unpickle_code(tmp_path):
     torch.save({"model_state_dict": sd, "extra": Evil()}, g)
     with pytest.raises(ValueError):
         checkpoint.load_reference_checkpoint(str(g))
+
+
+def test_bench_roofline_arithmetic():
+    """bench.py's analytical side (no GPU): work per kernel class and the two floors of the north-star kernel."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", osp.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    B, J = 256, 17
+    # the four lifter products of one block at C = 512: 2*M*K*(3C + C + 2C + 2C) with M = B*16*J
+    M = B * 16 * J
+    per_block = 2.0 * M * 512 * (1536 + 512 + 1024 + 1024)
+    assert bench.gemm_lifter_flops(B, J, 512) == 2.0 * B * 16 * 2048 * 512 + 6 * per_block
+    w, kind = bench.class_work("vertex_ca", B, J, 512)
+    assert kind == "byte" and w == 3 * 229376.0 * B
+    rec = bench.north_star_record({"vertex_ca_mlp": 0.345, "adaln_mlp": 0.27}, {"vertex_ca_mlp": 3, "adaln_mlp": 3}, B, J)
+    # 14 wave tiles per clip, (64 + 16*ceil(17/8) + 512) MFMAs of 64 cycles each, 1024 SIMDs at 2.4 GHz
+    assert abs(rec["mfma_floor_ms"] - B * 14 * 624 * 64 / 1024 / 2.4e9 * 1e3) < 1e-5
+    assert abs(rec["hbm_floor_ms"] - 229376.0 * B / 8e12 * 1e3) < 1e-5
+    assert rec["kernel"] == "vertex_ca_mlp" and rec["bound"] == "mfma" and abs(rec["frac_of_floor"] - rec["mfma_floor_ms"] / 0.115) < 1e-3
+    old = bench.north_star_record({"vertex_ca": 0.09}, {"vertex_ca": 3}, B, J)
+    assert old["kernel"] == "vertex_ca" and abs(old["mfma_floor_ms"] - B * 14 * 112 * 64 / 1024 / 2.4e9 * 1e3) < 1e-5
+    assert bench.north_star_record({"gemm_lifter": 1.0}, {"gemm_lifter": 25}, B, J) is None
