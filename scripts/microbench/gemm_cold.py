@@ -8,11 +8,14 @@ from pmce_amd import ops
 dev = torch.device("cuda:0")
 tiles = [int(t) for t in os.environ.get("TILES", "-1").split(",")]
 shapes = (("qkv", 69632, 768, 256, 0, False), ("proj", 69632, 256, 256, 0, True), ("fc1", 69632, 512, 256, 1, False),
-          ("fc2", 69632, 256, 512, 0, True))
+          ("fc2", 69632, 256, 512, 0, True), ("qkv512", 69632, 1536, 512, 0, False), ("proj512", 69632, 512, 512, 0, True),
+          ("fc1_512", 69632, 1024, 512, 1, False), ("fc2_512", 69632, 512, 1024, 0, True))
+only = [a for a in sys.argv[1:]]
+shapes = [sh for sh in shapes if not only or sh[0] in only]
 for name, M, N, K, act, res in shapes:
     for tile in tiles:
-        if tile >= 0:
-            os.environ["PMCE_GEMM_TILE"] = str(tile)
+        from pmce_amd import _lib
+        _lib.load().pmce_gemm_set_tuning(tile, 0)
         row = []
         for nset in (1, 6):
             A = [torch.randn(M, K, device=dev) for _ in range(nset)]
