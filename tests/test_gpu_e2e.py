@@ -416,3 +416,21 @@ def test_graphed_forward_matches_eager(B):
     model.load_state_dict(cached_state_dict(J, 256))          # re-pack
     with pytest.raises(_lib.PmceError):
         gf(p, f)
+
+
+@pytest.mark.parametrize("J,C", [(24, 256), (32, 512)])
+def test_other_joint_counts_vs_oracle(J, C):
+    """Joint counts beyond the two the reference ships (17, 19): J = 24 / 32 take the generic paths - the one-query
+    sequence-attention kernel (N not in {16,17,19}), and the two-launch CrossAttentionBlock (one clip's folded operands no
+    longer fit beside the FFN weights for J > 23) - and must still match the oracle.  vj_relation keeps indexing the first 17."""
+    from oracle import pmce_oracle as O
+    from pmce_amd import synth
+    model = get_model(J, C)
+    sd = cached_state_dict(J, C)
+    pose2d, img_feat = synth.make_inputs(3, J, 314)
+    mesh, pose, pose3d = model(T(pose2d).to(dev()), T(img_feat).to(dev()))
+    with torch.no_grad():
+        rm, rp, rl = O.pmce_forward(sd, T(pose2d), T(img_feat), model.vj_relation)
+    e = (maxabs(mesh, rm), maxabs(pose, rp), maxabs(pose3d, rl))
+    print(f"J={J} C={C} vs oracle: mesh %.2e m, pose %.2e m, pose3d %.2e mm" % e)
+    assert e[0] < TIGHT_M and e[1] < TIGHT_M and e[2] < TOL_MM
