@@ -726,7 +726,7 @@ long long pmce_model_workspace_offset(const pmce_model* m, int batch, const char
   else if (n == "F2") p = dw.F2;
   else if (n == "JM") p = dw.JM;
   else return -1;
-  return (long long)(reinterpret_cast<const char*>(p) - static_cast<const char*>(nullptr));
+  return (long long)reinterpret_cast<uintptr_t>(p);  // the carver ran on a null base: the pointer value IS the offset
 }
 
 static int check_ws(pmce_model* m, int batch, void* ws, size_t ws_bytes) {
