@@ -437,6 +437,35 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
+    # The second complete record (the other pose-encoder width) is measured by a CHILD process running this same script,
+    # BEFORE this process touches the GPU: a second model in one process shares HIP's few hardware queues with the first
+    # one's (pooled, never destroyed) streams and loses the two-batches overlap (29.2 k instead of 32.1 k clips/s at
+    # C = 256), and a child that runs while its parent holds a HIP context sees ~6 % slower kernels in its profiling pass.
+    variant = None
+    C, B, J = args.embed_dim, args.batch, args.joints
+    if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_variant and not args.single_stream
+            and not args.dist_check and C in (256, 512)):
+        C2 = 256 if C == 512 else 512
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--windows", str(args.windows), "--batch", str(B), "--joints", str(J), "--embed-dim", str(C2),
+               "--pipeline-depth", str(args.pipeline_depth), "--no-variant", "--no-host-fed", "--no-latency",
+               "--cpu-seconds", str(min(args.cpu_seconds, 8.0))]
+        cmd += ["--no-stagger"] if args.no_stagger else []
+        cmd += ["--no-cpu-baseline"] if args.no_cpu_baseline else []
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and lines:
+            d = json.loads(lines[-1])
+            variant = {k: d.get(k) for k in ("value", "unit", "ms_per_step", "windows", "config", "roofline", "roofline_cross_attention",
+                                            "cpu_baseline", "kernel_ms_per_step", "launches_per_step",
+                                            "kernel_ms_total_single_stream", "ref_equiv_tflops", "outputs_finite")}
+            variant["why"] = ("the width every reference config ships (lib/core/config.py:59)" if C2 == 256
+                              else "BASELINE.json north_star's width")
+            variant["measured_by"] = "child process running this same script, before this process touched the GPU"
+        else:
+            variant = {"error": (r.stderr or r.stdout)[-400:]}
+
     import torch
     from pmce_amd import sharding
 
@@ -468,7 +497,6 @@ def main():
                          f"(set PMCE_BENCH_SHARE_GPU=1 PMCE_DIST_BACKEND=gloo to let ranks share a device)")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    B, J, C = args.batch, args.joints, args.embed_dim
 
     head, model, pipe, inputs, sd = measure_config(args, dev, rank, world, J, C, B, args.steps, args.warmup, args.windows)
 
@@ -481,32 +509,6 @@ def main():
     vj = model.vj_relation
     del model, pipe, inputs
     torch.cuda.empty_cache()
-
-    # The second complete record (the other pose-encoder width) is measured by a CHILD process running this same script:
-    # a second model in this process would share HIP's few hardware queues with the first one's (pooled, never destroyed)
-    # streams, and two of its lanes can land on one queue - measured 29.2 k instead of 32.1 k clips/s at C = 256 that way.
-    variant = None
-    if solo and not args.no_variant and not args.single_stream and C in (256, 512):
-        C2 = 256 if C == 512 else 512
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
-               "--windows", str(args.windows), "--batch", str(B), "--joints", str(J), "--embed-dim", str(C2),
-               "--pipeline-depth", str(args.pipeline_depth), "--no-variant", "--no-host-fed", "--no-latency",
-               "--cpu-seconds", str(min(args.cpu_seconds, 8.0))]
-        cmd += ["--no-stagger"] if args.no_stagger else []
-        cmd += ["--no-cpu-baseline"] if args.no_cpu_baseline else []
-        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True)
-        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        if r.returncode == 0 and lines:
-            d = json.loads(lines[-1])
-            variant = {k: d.get(k) for k in ("value", "unit", "ms_per_step", "windows", "config", "roofline", "roofline_cross_attention",
-                                            "cpu_baseline", "kernel_ms_per_step", "launches_per_step",
-                                            "kernel_ms_total_single_stream", "ref_equiv_tflops", "outputs_finite")}
-            variant["why"] = ("the width every reference config ships (lib/core/config.py:59)" if C2 == 256
-                              else "BASELINE.json north_star's width")
-            variant["measured_by"] = "child process running this same script (fresh HIP context)"
-        else:
-            variant = {"error": (r.stderr or r.stdout)[-400:]}
 
     if solo and not args.no_cpu_baseline:      # host-only work last
         cpu = cpu_baseline_record(sd, vj, J, C, args.cpu_seconds)
