@@ -33,7 +33,10 @@ def init_from_env(backend: str | None = None):
             backend = os.environ.get("PMCE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            # bind the communicator to this rank's device up front: barrier() then needs no device guess
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
 

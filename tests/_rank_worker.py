@@ -33,9 +33,10 @@ def main():
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     if mode == "nccl1":
-        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1")
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1")
+        # the same call pmce_amd.sharding.init_from_env makes for world > 1 (backend nccl = RCCL, communicator bound to the device)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
         tot = sharding.reduce_metric_sums(torch.tensor([1.5, 2.0], dtype=torch.float64, device=dev))
         rows = sharding.gather_rows(torch.arange(12, dtype=torch.float32, device=dev).reshape(4, 3))
         tmax = sharding.reduce_max(0.25, dev)
