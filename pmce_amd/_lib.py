@@ -84,6 +84,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # The library takes device pointers and hipStream_t handles that PyTorch created, so both must live in ONE HIP runtime.
+    # torch bundles its own libamdhip64; imported first, its copy also satisfies this library's libamdhip64.so.7 dependency.
+    # Loaded the other way round the process would hold two runtimes and the library's would see no device.
+    import torch  # noqa: F401
     if not osp.exists(LIB_PATH):
         raise PmceError(f"{LIB_PATH} not found: build it first (python -m pmce_amd.build, or __graft_entry__.build()). "
                         "There is no fallback path.")

@@ -434,3 +434,17 @@ def test_other_joint_counts_vs_oracle(J, C):
     e = (maxabs(mesh, rm), maxabs(pose, rp), maxabs(pose3d, rl))
     print(f"J={J} C={C} vs oracle: mesh %.2e m, pose %.2e m, pose3d %.2e mm" % e)
     assert e[0] < TIGHT_M and e[1] < TIGHT_M and e[2] < TOL_MM
+
+
+def test_entry_points_in_one_process():
+    """__graft_entry__.build() (which dlopens libpmce_hip.so) followed by smoke() in ONE fresh process: the library must end up
+    in the same HIP runtime as PyTorch whatever the import order (loaded before torch it used to bring in the system
+    libamdhip64 as a second runtime that saw no device)."""
+    import os.path as osp
+    import subprocess
+    import sys
+    repo = osp.dirname(osp.dirname(osp.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=repo,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert "smoke: max-abs vs oracle" in r.stdout
