@@ -7,7 +7,7 @@ mkdir -p gpurun_out/kpmc
 i=0
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM"; do
   i=$((i+1))
-  (cd /tmp && timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OLDPWD/gpurun_out/kpmc/g$i -o pmc -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --single-stream > $OLDPWD/gpurun_out/kpmc/g$i.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OLDPWD/gpurun_out/kpmc/g$i -o pmc -- python $OLDPWD/bench.py --embed-dim ${PMCE_PMC_C:-512} --steps 1 --warmup 1 --windows 1 --no-cpu-baseline --no-latency --no-host-fed --no-variant --single-stream > $OLDPWD/gpurun_out/kpmc/g$i.log 2>&1)
 done
 PAT="$pat" python - <<'PY'
 import csv, glob, collections, os, re
