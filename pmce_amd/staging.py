@@ -67,6 +67,13 @@ def mesh_window_table(img_names, seqlen: int = 16, stride: int = 1, mid_valid=No
     return np.concatenate(rows).astype(np.int64) if rows else np.zeros((0, 2), dtype=np.int64)
 
 
+def pose_window_table(img_names, seqlen: int = 16, stride: int = 1, match_vibe: bool = True) -> np.ndarray:
+    """The window list of the pose-only path, as ``split_into_chunks_pose`` builds it (lib/_img_utils.py:27-55): the same
+    per-video stride-``stride`` windows and VIBE-tail rule as :func:`mesh_window_table`, without the middle-frame validity
+    filter.  For a single video it equals :func:`pmce_amd.streaming.window_indices`."""
+    return mesh_window_table(img_names, seqlen, stride, None, match_vibe)
+
+
 class PinnedFeeder:
     """Double-buffered host -> device feed: ``slots`` pinned host buffers per tensor and a dedicated copy stream.
 

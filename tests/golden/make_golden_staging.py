@@ -51,6 +51,9 @@ def video_layout():
     return names, np.array(valid)
 
 
+SINGLE_VIDEO_LENGTHS = (15, 16, 17, 31, 32, 33, 47, 48, 100, 1000)
+
+
 def main():
     shims()
     from PW3D.dataset import PW3D
@@ -67,6 +70,13 @@ def main():
     out = {"ext": ext, "ext_pelvis": ext_p, "norm": norm}
     for tag, (seqlen, stride, mv) in {"s1": (16, 1, True), "s16": (16, 16, True), "s4": (16, 4, True), "s1_nov": (16, 1, False)}.items():
         out["win_" + tag] = np.asarray(_img_utils.split_into_chunks_mesh(img_names, seqlen, stride, poses, is_train=False, match_vibe=mv)).reshape(-1, 2)
+    # split_into_chunks_pose (lib/_img_utils.py:27-55: the lifter-only / streaming window list, no validity filter): the same
+    # three-video layout, and single videos of several lengths (what pmce_amd.streaming.window_indices serves)
+    for tag, (seqlen, stride, mv) in {"s1": (16, 1, True), "s16": (16, 16, True), "s4": (16, 4, True), "s1_nov": (16, 1, False)}.items():
+        out["pose_win_" + tag] = np.asarray(_img_utils.split_into_chunks_pose(img_names, seqlen, stride, is_train=False, match_vibe=mv)).reshape(-1, 2)
+    for L in SINGLE_VIDEO_LENGTHS:
+        one = [f"0/only/image_{i:05d}.jpg" for i in range(L)]
+        out[f"pose_win_single_{L}"] = np.asarray(_img_utils.split_into_chunks_pose(one, 16, 1, is_train=False, match_vibe=True)).reshape(-1, 2)
     np.savez_compressed(osp.join(HERE, "staging.npz"), **out)
     print({k: v.shape for k, v in out.items()})
 

@@ -44,3 +44,24 @@ def test_window_table_edge_cases():
     exact = [f"0/s/image_{i:05d}.jpg" for i in range(16)]
     np.testing.assert_array_equal(staging.mesh_window_table(exact, 16, 1), [[0, 15]])
     np.testing.assert_array_equal(staging.mesh_window_table(exact, 16, 1, mid_valid=np.arange(16) != 8), np.zeros((0, 2)))
+
+
+@pytest.mark.parametrize("tag,seqlen,stride,mv", [("s1", 16, 1, True), ("s16", 16, 16, True), ("s4", 16, 4, True), ("s1_nov", 16, 1, False)])
+def test_pose_window_tables_match_reference(tag, seqlen, stride, mv):
+    """split_into_chunks_pose of the REAL reference (fixture) vs the oracle restatement and the product's host function."""
+    names, _ = mg.video_layout()
+    want = G["pose_win_" + tag]
+    np.testing.assert_array_equal(so.split_into_chunks_pose(names, seqlen, stride, match_vibe=mv), want)
+    np.testing.assert_array_equal(staging.pose_window_table(names, seqlen, stride, match_vibe=mv), want)
+
+
+def test_single_video_windows_match_reference():
+    """pmce_amd.streaming.window_indices (one video, stride 1) vs the reference's split_into_chunks_pose on single videos of
+    several lengths, including the ones around the 16-frame VIBE chunk boundaries."""
+    from pmce_amd import streaming
+    for L in mg.SINGLE_VIDEO_LENGTHS:
+        want = G[f"pose_win_single_{L}"]
+        np.testing.assert_array_equal(streaming.window_indices(L), want)
+        one = [f"0/only/image_{i:05d}.jpg" for i in range(L)]
+        np.testing.assert_array_equal(staging.pose_window_table(one), want)
+        np.testing.assert_array_equal(so.split_into_chunks_pose(one, 16, 1), want)
