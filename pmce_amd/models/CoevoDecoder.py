@@ -42,6 +42,8 @@ class Pose2Mesh(HipModuleBase):
         B = joints.shape[0]
         pose = torch.empty(B, self.num_joint, 3, device=joints.device, dtype=torch.float32)
         mesh = torch.empty(B, NUM_VERTS_FULL, 3, device=joints.device, dtype=torch.float32)
+        if B == 0:
+            return pose, mesh
         ws = eng.workspace(B)
         _lib.check(eng.lib.pmce_decoder_forward(eng.handle, _lib.ptr(joints), _lib.ptr(img_feats), _lib.ptr(pose),
                                                 _lib.ptr(mesh), B, C.c_void_p(ws.data_ptr()), ws.numel(),

@@ -56,6 +56,8 @@ class PMCE(HipModuleBase):
             if not eng.regressor_rows:
                 raise _lib.PmceError("forward_with_joints needs set_j_regressor(...) first")
             pred = torch.empty(B, eng.regressor_rows, 3, device=dev, dtype=torch.float32)
+        if B == 0:               # an empty batch is an empty result (the reference's modules return empty tensors too)
+            return mesh, pose, pose3d, pred
         ws = eng.workspace(B)
         _lib.check(eng.lib.pmce_forward(eng.handle, _lib.ptr(pose2d), _lib.ptr(img_feat), _lib.ptr(mesh), _lib.ptr(pose),
                                         _lib.ptr(pose3d), _lib.ptr(pred), B, C.c_void_p(ws.data_ptr()), ws.numel(),

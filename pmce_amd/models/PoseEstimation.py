@@ -38,6 +38,8 @@ class GraphormerNet(HipModuleBase):
         img_feat = _check_input(img_feat, (SEQLEN, FEAT_DIM), "img_feat")
         B = x.shape[0]
         out = torch.empty(B, self.num_joints, 3, device=x.device, dtype=torch.float32)
+        if B == 0:
+            return out
         ws = eng.workspace(B)
         _lib.check(eng.lib.pmce_lifter_forward(eng.handle, _lib.ptr(x), _lib.ptr(img_feat), _lib.ptr(out), B,
                                                C.c_void_p(ws.data_ptr()), ws.numel(), _lib.current_stream()),

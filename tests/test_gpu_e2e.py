@@ -185,6 +185,23 @@ def test_streaming_windows_and_packed_weights(tmp_path):
         assert torch.equal(v, model._engine.packed[k]), k
 
 
+def test_empty_batch():
+    """B = 0: empty outputs of the right shapes from all three modules (no launch), like the reference's modules."""
+    from pmce_amd import models
+    J = 19
+    model = get_model(J, 256)
+    mesh, pose, pose3d, pred = model.forward_with_joints(torch.zeros(0, 16, J, 2, device=dev()), torch.zeros(0, 16, 2048, device=dev()))
+    assert mesh.shape == (0, 6890, 3) and pose.shape == (0, J, 3) and pose3d.shape == (0, J, 3) and pred.shape == (0, 17, 3)
+    sd = cached_state_dict(J, 256)
+    lifter = models.PoseEstimation.get_model(J, 256, 3)
+    lifter.load_state_dict({k[len("pose_lifter."):]: v for k, v in sd.items() if k.startswith("pose_lifter.")})
+    assert lifter.to(dev())(torch.zeros(0, 16, J, 2, device=dev()), torch.zeros(0, 16, 2048, device=dev())).shape == (0, J, 3)
+    dec = models.CoevoDecoder.get_model(J, 256)
+    dec.load_state_dict({k[len("pose_mesh_coevo."):]: v for k, v in sd.items() if k.startswith("pose_mesh_coevo.")})
+    p0, m0 = dec.to(dev())(torch.zeros(0, J, 3, device=dev()), torch.zeros(0, 16, 2048, device=dev()))
+    assert p0.shape == (0, J, 3) and m0.shape == (0, 6890, 3)
+
+
 @pytest.mark.parametrize("B", [1, 77])
 def test_odd_batch_sizes(B):
     """ragged batch sizes (no tile of any kernel is full): clip i of the batch == the same clip in a batch of 3."""
