@@ -126,17 +126,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
   unsigned aoff[LA], boff[LB];  // byte offsets from A / W (the launcher checks that both operands span < 4 GiB)
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, 0xffffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 0xffffffff, 0x00020000);
+  // Both operands span < 4 GiB (checked by the launcher), so the byte offsets fit 32 bits: one 32-bit multiply-add per
+  // row (the tile switch sits on the matrix pipe's critical path: every vector instruction there is matrix time lost).
+  // The row-mapped form of A (a_div) keeps the general arithmetic; no product of the path uses it.
+  const bool a_plain = p.a_div == 0x7fffffff;  // wave-uniform
+  const unsigned lda_u = (unsigned)p.a_lo, ldw_u = (unsigned)p.ldw;
   auto set_ptrs = [&](int mb, int nb) {
+    if (a_plain) {
 #pragma unroll
-    for (int i = 0; i < LA; ++i) {
-      const int r = min(mb + r0 + 32 * i, p.M - 1);
-      aoff[i] = (unsigned)(((long long)(r % p.a_div) * p.a_lo + (long long)(r / p.a_div) * p.a_hi + kc) * 4);
+      for (int i = 0; i < LA; ++i) aoff[i] = ((unsigned)min(mb + r0 + 32 * i, p.M - 1) * lda_u + (unsigned)kc) * 4u;
+    } else {
+#pragma unroll
+      for (int i = 0; i < LA; ++i) {
+        const int r = min(mb + r0 + 32 * i, p.M - 1);
+        aoff[i] = (unsigned)(((long long)(r % p.a_div) * p.a_lo + (long long)(r / p.a_div) * p.a_hi + kc) * 4);
+      }
     }
 #pragma unroll
-    for (int i = 0; i < LB; ++i) {
-      const int r = min(nb + r0 + 32 * i, p.N - 1);
-      boff[i] = (unsigned)(((long long)r * p.ldw + kc) * 4);
-    }
+    for (int i = 0; i < LB; ++i) boff[i] = ((unsigned)min(nb + r0 + 32 * i, p.N - 1) * ldw_u + (unsigned)kc) * 4u;
   };
 
   const unsigned lds_a = __builtin_amdgcn_readfirstlane(lds_addr(&As[0][0]) + wave * (8 * LD * 4));
