@@ -584,41 +584,53 @@ __global__ __launch_bounds__(256) void adaln_qkv_kernel(const float* __restrict_
   const int lane = tid & 63, wave = tid >> 6;
   const int n0 = lane & 31, hb = lane >> 5;
   const int ntiles = B * NTILE;
-  for (int wt = blockIdx.x * 4 + wave; wt < ntiles; wt += gridDim.x * 4) {
+  // The kernel is latency-bound (PMC: 44 % of its wave cycles parked in s_waitcnt, matrix pipe 30 % busy): a wave's next
+  // tile is fetched while the current one is in the matrix pipe.
+  auto tok_of = [&](int wt) {
+    const int v = (wt % NTILE) * 32 + n0;
+    return (long long)(wt / NTILE) * NV + (v < NV ? v : NV - 1);
+  };
+  float x[32];
+  int wt = blockIdx.x * 4 + wave;
+  if (wt < ntiles) load_slots(xin + tok_of(wt) * 64, x, hb);
+  for (; wt < ntiles; wt += gridDim.x * 4) {
     const int b = wt / NTILE, tile = wt % NTILE;
-    const int v = tile * 32 + n0;
-    const bool valid = v < NV;
-    const long long tok = (long long)b * NV + (valid ? v : NV - 1);
-    float x[32], a[32];
-    load_slots(xin + tok * 64, x, hb);
+    float a[32];
     adaln_slots(x, a, GB + (long long)b * gb_stride + inst * 128, hb);
-    f32x16 acc[6];
-#pragma unroll
-    for (int nt = 0; nt < 6; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nt][r] = sB[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb];
-    tl_gemm<8, 6, LDW64>(sW, a, acc, n0, hb);
+    const int wn = wt + gridDim.x * 4;
+    if (wn < ntiles) load_slots(xin + tok_of(wn) * 64, x, hb);  // x is dead after the AdaLN: its registers take the next tile
     // Output through a wave-private LDS tile so that every store instruction writes full 128-byte lines (8 lanes per token
     // and 32-channel group) instead of 32 bytes in each of 32 rows: the accumulator layout's direct stores cost 24 of this
-    // kernel's 59 us.
+    // kernel's 59 us.  The 192 output channels are produced in two halves of three 32-channel tiles (48 instead of 96
+    // accumulator registers: room for the prefetched tile without spilling).
     float* tb = sT + wave * (32 * 36);
     const long long tok0 = (long long)b * NV + tile * 32;
 #pragma unroll
-    for (int nt = 0; nt < 6; ++nt) {
+    for (int half = 0; half < 2; ++half) {
+      f32x16 acc[3];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 t;
-        t.x = acc[nt][4 * g + 0];
-        t.y = acc[nt][4 * g + 1];
-        t.z = acc[nt][4 * g + 2];
-        t.w = acc[nt][4 * g + 3];
-        *reinterpret_cast<f32x4*>(tb + n0 * 36 + 8 * g + 4 * hb) = t;
-      }
+      for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int tk = 8 * i + (lane >> 3);
-        const f32x4 t = *reinterpret_cast<const f32x4*>(tb + tk * 36 + 4 * (lane & 7));
-        if (tile * 32 + tk < NV) *reinterpret_cast<f32x4*>(qkv + (tok0 + tk) * 192 + nt * 32 + 4 * (lane & 7)) = t;
+        for (int r = 0; r < 16; ++r) acc[nt][r] = sB[(3 * half + nt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb];
+      tl_gemm<8, 3, LDW64>(sW + 3 * half * 32 * LDW64, a, acc, n0, hb);
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 t;
+          t.x = acc[nt][4 * g + 0];
+          t.y = acc[nt][4 * g + 1];
+          t.z = acc[nt][4 * g + 2];
+          t.w = acc[nt][4 * g + 3];
+          *reinterpret_cast<f32x4*>(tb + n0 * 36 + 8 * g + 4 * hb) = t;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int tk = 8 * i + (lane >> 3);
+          const f32x4 t = *reinterpret_cast<const f32x4*>(tb + tk * 36 + 4 * (lane & 7));
+          if (tile * 32 + tk < NV)
+            *reinterpret_cast<f32x4*>(qkv + (tok0 + tk) * 192 + (3 * half + nt) * 32 + 4 * (lane & 7)) = t;
+        }
       }
     }
   }
