@@ -58,6 +58,12 @@ const char* pmce_model_tensor_name(const pmce_model* m, int i);
 int pmce_model_set_regressor_rows(pmce_model* m, int rows);
 /* Check that every tensor is registered. */
 int pmce_model_finalize(pmce_model* m);
+/* Arithmetic of the pose lifter's Linear layers (25 of the path's 30 large products): split_f16 != 0 (the default; env
+ * PMCE_LIFTER_SPLIT_F16=0 at create for the other) = the three-product f16 form of pmce_gemm_nt_split_f16 on weights the
+ * model packs for itself at finalize, 0 = the fp32 matrix pipe.  Both meet fp32 accuracy (tests/test_gpu_ops.py measures
+ * each against an fp64 product); may be called at any time between forwards. */
+int pmce_model_set_gemm_mode(pmce_model* m, int split_f16);
+int pmce_model_gemm_mode(const pmce_model* m);
 /* Bytes of caller-provided workspace needed for a batch of B clips. */
 size_t pmce_model_workspace_bytes(const pmce_model* m, int batch);
 
@@ -131,6 +137,17 @@ int pmce_gemm_nt_f32(const float* A, const float* W, const float* bias, const fl
 /* Tuning aid only: force the tile configuration (0..3, -1 = automatic) and the persistent workgroups per CU (1..8, 0 =
  * automatic) of pmce_gemm_nt_f32 for the whole process (initial values: PMCE_GEMM_TILE / PMCE_GEMM_GRID, read once). */
 int pmce_gemm_set_tuning(int tile, int grid_per_cu);
+/* The same nn.Linear product on the f16 matrix pipe with fp32 operands, result and accuracy: W is split ONCE into f16
+ * (hi, lo) planes of W * 2^s by pmce_gemm_pack_split_f16 (Wp: N*K floats of storage, wscale: 4 floats {2^s, 2^-s, ..}), A is
+ * split into (hi, lo * 2^11) on the fly, C = 2^-s (Ahi Whi + Ahi Wlo + Alo Whi) accumulated in fp32 - error at or below the
+ * fp32 product's own rounding.  A, bias, R, C stay fp32 and row-major (lda, ldc); |A| must be below 65504 (an element
+ * outside the f16 range yields inf/nan, never a silently wrong finite value). */
+int pmce_gemm_pack_split_f16(const float* W, int N, int K, int ldw, float* Wp, float* wscale, pmce_stream_t stream);
+int pmce_gemm_nt_split_f16(const float* A, const float* Wp, const float* wscale, const float* bias, const float* R, float* C,
+                           int M, int N, int K, long long lda, long long ldc, int act, int a_packed, pmce_stream_t stream);
+/* a_packed != 0: A is not fp32 but already split, [M][K/32][hi 32 f16 | lo*2^11 32 f16] (the layout the lifter's own
+ * producers write; pmce_split_rows_f16 makes it from fp32 rows). */
+int pmce_split_rows_f16(const float* A, long long M, int K, long long lda, float* Ap, pmce_stream_t stream);
 
 /* PoseEstimation.py:78-81 — x[tok] = joint_embed(pose2d) + imgfeat_embed(img_feat)[b,t] + spatial_pos[j]. */
 int pmce_embed_tokens_f32(const float* pose2d, const float* E, const float* Wje, const float* bje, const float* spos,

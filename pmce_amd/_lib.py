@@ -38,9 +38,14 @@ PROTOTYPES = {
     "pmce_model_set_concurrency": [C.c_void_p, _i],
     "pmce_model_wait_lifter": [C.c_void_p, _s],
     "pmce_model_profile": [C.c_void_p, _i],
+    "pmce_model_set_gemm_mode": [C.c_void_p, _i],
+    "pmce_model_gemm_mode": [C.c_void_p],
     "pmce_model_profile_read": [C.c_void_p, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_longlong)],
     "pmce_gemm_nt_f32": [_f, _f, _f, _f, _f, _i, _i, _i, _l, _i, _l, _i, _i, _l, _l, _i, _l, _l, _i, _l, _l, _l, _l, _s],
     "pmce_gemm_set_tuning": [_i, _i],
+    "pmce_gemm_pack_split_f16": [_f, _i, _i, _i, _f, _f, _s],
+    "pmce_gemm_nt_split_f16": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _l, _l, _i, _i, _s],
+    "pmce_split_rows_f16": [_f, _l, _i, _l, _f, _s],
     "pmce_embed_tokens_f32": [_f, _f, _f, _f, _f, _f, _l, _i, _i, _s],
     "pmce_ln_chain_f32": [_f, _l, _i, _f, _f, _fl, _f, _i, _i, _f, _f, _f, _fl, _f, _s],
     "pmce_seq_attention_f32": [_f, _f, _i, _i, _i, _i, _l, _l, _l, _s],

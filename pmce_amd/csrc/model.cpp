@@ -43,6 +43,15 @@ struct Ev {
 struct LifterBlockW {
   const float *norm1_w, *norm1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2_w, *norm2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
 };
+// the lifter's Linear weights as f16 (hi, lo) planes + scale (pmce_gemm_pack_split_f16): made by pmce_model_finalize in
+// memory the model owns when the lifter's products run in the three-product f16 form
+struct SplitW {
+  const float* wp = nullptr;
+  const float* scale = nullptr;
+};
+struct LifterBlockSplit {
+  SplitW qkv, proj, fc1, fc2;
+};
 struct VertexBlockW {  // vertex side of CoevoBlock k (+ the joint-side preparation every block needs)
   const float *joint_proj_w, *joint_proj_b, *joint_pos, *j2v_w, *j2v_b, *j2v_K, *vertx_proj_w, *Eq;
   const float *vca_wq_w, *vca_wq_b, *vca_wk_w, *vca_wk_b, *vca_wv_w, *vca_wv_b, *vca_proj_w, *vca_proj_b;
@@ -85,6 +94,11 @@ struct pmce_model {
   hipEvent_t ev_lifter = nullptr;  // recorded by pmce_forward when its pose lifter is enqueued (pmce_model_wait_lifter)
   bool concurrent = true;  // pmce_model_set_concurrency
   bool fused_ca = true;    // CrossAttentionBlock of the vertex stream as one launch (PMCE_VERTEX_FUSED=0 at create: two)
+  // lifter Linear layers on the f16 matrix pipe (three-product split, fp32 accuracy) instead of the fp32 one
+  bool split_gemm = true;  // pmce_model_set_gemm_mode / PMCE_LIFTER_GEMM=f32 at create
+  float* split_arena = nullptr;  // owned (hipMalloc): every packed lifter weight + its scale
+  LifterBlockSplit sblk[2][8];
+  SplitW s_ie;
   // regressor (optional)
   const int* jr_indptr = nullptr;
   const int* jr_indices = nullptr;
@@ -313,6 +327,12 @@ int gemm(const float* A, const float* W, const float* bias, const float* R, floa
          long long ldc, int act, hipStream_t s) {
   return pmce_gemm_nt_f32(A, W, bias, R, Cc, M, N, K, lda, K, ldc, act, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, s);
 }
+// a lifter Linear: the f16 three-product form when the model carries the packed weight, the fp32 pipe otherwise
+int lgemm(const float* A, const float* W, const SplitW& sw, const float* bias, const float* R, float* Cc, int M, int N, int K,
+          long long lda, long long ldc, int act, hipStream_t s) {
+  if (sw.wp) return pmce_gemm_nt_split_f16(A, sw.wp, sw.scale, bias, R, Cc, M, N, K, lda, ldc, act, 0, s);
+  return gemm(A, W, bias, R, Cc, M, N, K, lda, ldc, act, s);
+}
 
 // ---- GraphormerNet.forward --------------------------------------------------------------------------------
 // Everything up to and including SpatialBlocks[0] is PER FRAME (its attention runs over the J joints of one frame,
@@ -322,20 +342,21 @@ int gemm(const float* A, const float* W, const float* bias, const float* R, floa
 int lifter_block_body(pmce_model* m, int kind, int i, long long M, int nframes, int B, LifterWs& w, hipStream_t stream) {
   const int J = m->J, C = m->C;
   const LifterBlockW& bw = m->w.blk[kind][i];
-  RUN(P_GEMM_LIFTER, gemm(w.XN, bw.qkv_w, bw.qkv_b, nullptr, w.QKV,
+  const LifterBlockSplit& sw = m->sblk[kind][i];
+  RUN(P_GEMM_LIFTER, lgemm(w.XN, bw.qkv_w, sw.qkv, bw.qkv_b, nullptr, w.QKV,
                           (int)M, 3 * C, C, C, 3 * C, 0, stream));
   if (kind == 0)  // sequences = frames, tokens j contiguous                        (PoseEstimation.py:78,101)
     RUN(P_SEQ_ATTN, pmce_seq_attention_f32(w.QKV, w.AO, nframes, J, C, 0, J, 0, 1, stream));
   else  // sequences = (b,j), tokens t at stride J                                  (PoseEstimation.py:87,104)
     RUN(P_SEQ_ATTN, pmce_seq_attention_f32(w.QKV, w.AO, B * J, T, C, J, 1, (long long)T * J, J, stream));
-  RUN(P_GEMM_LIFTER, gemm(w.AO, bw.proj_w, bw.proj_b, w.X, w.X, (int)M, C,
+  RUN(P_GEMM_LIFTER, lgemm(w.AO, bw.proj_w, sw.proj, bw.proj_b, w.X, w.X, (int)M, C,
                           C, C, C, 0, stream));
   RUN(P_LN, pmce_ln_chain_f32(w.X, M, C, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, bw.norm2_w,
                               bw.norm2_b, 1e-6f, w.XN, stream));
   float* Hid = w.QKV;
-  RUN(P_GEMM_LIFTER, gemm(w.XN, bw.fc1_w, bw.fc1_b, nullptr, Hid, (int)M,
+  RUN(P_GEMM_LIFTER, lgemm(w.XN, bw.fc1_w, sw.fc1, bw.fc1_b, nullptr, Hid, (int)M,
                           2 * C, C, C, 2 * C, 1, stream));
-  RUN(P_GEMM_LIFTER, gemm(Hid, bw.fc2_w, bw.fc2_b, w.X, w.X, (int)M, C,
+  RUN(P_GEMM_LIFTER, lgemm(Hid, bw.fc2_w, sw.fc2, bw.fc2_b, w.X, w.X, (int)M, C,
                           2 * C, 2 * C, C, 0, stream));
   return PMCE_OK;
 }
@@ -345,7 +366,7 @@ int lifter_frames(pmce_model* m, const float* pose2d, const float* img_feat, int
   const int J = m->J, C = m->C;
   const long long M = (long long)nframes * J;
   PMCE_REQUIRE(M < (1ll << 31), "lifter: too many tokens");
-  RUN(P_GEMM_LIFTER, gemm(img_feat, m->w.ie_w, m->w.ie_b, nullptr, w.E,
+  RUN(P_GEMM_LIFTER, lgemm(img_feat, m->w.ie_w, m->s_ie, m->w.ie_b, nullptr, w.E,
                           nframes, C, F, F, C, 0, stream));
   RUN(P_EMBED, pmce_embed_tokens_f32(pose2d, w.E, m->w.je_w, m->w.je_b,
                                      m->w.spos, w.X, M, J, C, stream));
@@ -603,6 +624,58 @@ int ensure_side(pmce_model* m) {
 }  // namespace
 
 // ============================================================================================================
+namespace {
+// (Re)build the packed f16 planes of every lifter Linear weight in model-owned memory, or drop them (fp32 mode / no
+// lifter).  Runs on the null stream and waits: a load-time step, like the packing the host side does.
+int build_split_weights(pmce_model* m) {
+  if (m->split_arena) {
+    (void)hipDeviceSynchronize();  // forwards in flight may still read the old planes
+    (void)hipFree(m->split_arena);
+    m->split_arena = nullptr;
+  }
+  for (auto& kind : m->sblk)
+    for (auto& b : kind) b = LifterBlockSplit{};
+  m->s_ie = SplitW{};
+  if (!m->split_gemm || !m->has_lifter) return PMCE_OK;
+  const int C = m->C;
+  struct Item { const float* w; int n, k; SplitW* dst; };
+  std::vector<Item> items;
+  items.push_back({m->w.ie_w, C, F, &m->s_ie});
+  for (int kind = 0; kind < 2; ++kind)
+    for (int i = 0; i < m->depth; ++i) {
+      const LifterBlockW& bw = m->w.blk[kind][i];
+      LifterBlockSplit& sw = m->sblk[kind][i];
+      items.push_back({bw.qkv_w, 3 * C, C, &sw.qkv});
+      items.push_back({bw.proj_w, C, C, &sw.proj});
+      items.push_back({bw.fc1_w, 2 * C, C, &sw.fc1});
+      items.push_back({bw.fc2_w, C, 2 * C, &sw.fc2});
+    }
+  size_t floats = 0;
+  for (auto& it : items) floats += (((size_t)it.n * it.k + 63) & ~(size_t)63) + 64;
+  const hipError_t rc = hipMalloc(reinterpret_cast<void**>(&m->split_arena), floats * sizeof(float));
+  if (rc != hipSuccess) {
+    m->split_arena = nullptr;
+    pmce_set_error("model_finalize: hipMalloc(%zu bytes) for the split lifter weights failed: %s", floats * sizeof(float),
+                   hipGetErrorString(rc));
+    return PMCE_ERR_LAUNCH;
+  }
+  float* p = m->split_arena;
+  for (auto& it : items) {
+    float* wp = p;
+    float* sc = p + (((size_t)it.n * it.k + 63) & ~(size_t)63);
+    p = sc + 64;
+    PMCE_TRY(pmce_gemm_pack_split_f16(it.w, it.n, it.k, it.k, wp, sc, nullptr));
+    it.dst->wp = wp;
+    it.dst->scale = sc;
+  }
+  if (hipStreamSynchronize(nullptr) != hipSuccess) {
+    pmce_set_error("model_finalize: packing the split lifter weights failed");
+    return PMCE_ERR_LAUNCH;
+  }
+  return PMCE_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int pmce_model_create(int num_joint, int embed_dim, int depth, pmce_model** out) {
@@ -616,6 +689,7 @@ int pmce_model_create(int num_joint, int embed_dim, int depth, pmce_model** out)
   m->depth = depth;
   m->concurrent = getenv("PMCE_SINGLE_STREAM") == nullptr;
   m->fused_ca = pmce_env_int("PMCE_VERTEX_FUSED", 1) != 0;
+  m->split_gemm = pmce_env_int("PMCE_LIFTER_SPLIT_F16", 1) != 0;
   build_names(m);
   *out = m;
   return PMCE_OK;
@@ -634,6 +708,7 @@ void pmce_model_destroy(pmce_model* m) {
   for (hipEvent_t e : {m->ev_fork, m->ev_join, m->ev_a, m->ev_b, m->ev_c, m->ev_d, m->ev_lifter})
     if (e) (void)hipEventDestroy(e);
   if (m->side) (void)hipStreamDestroy(m->side);
+  if (m->split_arena) (void)hipFree(m->split_arena);
   delete m;
 }
 
@@ -691,9 +766,20 @@ int pmce_model_finalize(pmce_model* m) {
     auto it = m->ptr.find(sl.name);
     *sl.dst = it == m->ptr.end() ? nullptr : it->second;
   }
+  PMCE_TRY(build_split_weights(m));
   m->finalized = true;
   return PMCE_OK;
 }
+
+int pmce_model_set_gemm_mode(pmce_model* m, int split_f16) {
+  PMCE_REQUIRE(m, "model_set_gemm_mode: null model");
+  if (m->split_gemm != (split_f16 != 0)) {
+    m->split_gemm = split_f16 != 0;
+    if (m->finalized) PMCE_TRY(build_split_weights(m));
+  }
+  return PMCE_OK;
+}
+int pmce_model_gemm_mode(const pmce_model* m) { return m && m->split_gemm ? 1 : 0; }
 
 size_t pmce_model_workspace_bytes(const pmce_model* m, int batch) {
   if (!m || batch <= 0) return 0;

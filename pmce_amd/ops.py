@@ -35,6 +35,40 @@ def gemm_nt(A, W, bias=None, residual=None, act=0, out=None):
     return out
 
 
+def pack_split_f16(W):
+    """W[N,K] fp32 -> (Wp[N,K] storage of the f16 hi/lo planes, wscale[4]) for :func:`gemm_nt_split`."""
+    lib = _lib.load()
+    W = _c(W)
+    N, K = W.shape
+    Wp = torch.empty(N, K, device=W.device, dtype=torch.float32)
+    wscale = torch.empty(4, device=W.device, dtype=torch.float32)
+    _lib.check(lib.pmce_gemm_pack_split_f16(P(W), N, K, K, P(Wp), P(wscale), _st()), "gemm_pack_split_f16")
+    return Wp, wscale
+
+
+def split_rows_f16(A):
+    """A[M,K] fp32 -> the packed (hi | lo*2^11) f16 planes, as an [M,K] float32-typed buffer."""
+    lib = _lib.load()
+    A = _c(A)
+    M, K = A.shape
+    Ap = torch.empty(M, K, device=A.device, dtype=torch.float32)
+    _lib.check(lib.pmce_split_rows_f16(P(A), M, K, K, P(Ap), _st()), "split_rows_f16")
+    return Ap
+
+
+def gemm_nt_split(A, Wp, wscale, bias=None, residual=None, act=0, out=None, a_packed=False):
+    """gemm_nt on the f16 matrix pipe (three-product split, fp32 accumulate): fp32 in, fp32 out, fp32 accuracy."""
+    lib = _lib.load()
+    A = _c(A)
+    M, K = A.shape
+    N = Wp.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    _lib.check(lib.pmce_gemm_nt_split_f16(P(A), P(Wp), P(wscale), P(bias), P(residual), P(out), M, N, K, K, N, act,
+                                          1 if a_packed else 0, _st()), "gemm_nt_split")
+    return out
+
+
 def ln_chain(x, w1=None, b1=None, eps1=1e-6, add=None, add_div=1, add_mod=1, want_out1=True, w2=None, b2=None, eps2=1e-6):
     lib = _lib.load()
     x = _c(x)

@@ -86,6 +86,7 @@ class HipEngine:
         """A second handle on the SAME packed weights (no copy): its own workspace, side stream and events, so that two
         forwards can be in flight at once (models.PMCE.Pipeline)."""
         other = HipEngine(self.J, self.C, self.depth)
+        other.set_gemm_mode(self.gemm_mode())
         other.register(self.packed)
         if self.regressor_rows:
             _lib.check(other.lib.pmce_model_set_regressor_rows(other.handle, self.regressor_rows), "set_regressor_rows")
@@ -111,6 +112,16 @@ class HipEngine:
             raise KeyError(name)
         n = int(np.prod(shape))
         return self.ws[off:off + 4 * n].view(torch.float32).reshape(shape)
+
+    def set_gemm_mode(self, mode: str):
+        """'split_f16' (default): the lifter's Linear layers on the f16 matrix pipe in the three-product form (fp32 operands,
+        fp32 accumulate, fp32 accuracy); 'f32': on the fp32 matrix pipe."""
+        if mode not in ("split_f16", "f32"):
+            raise ValueError("gemm mode must be 'split_f16' or 'f32'")
+        _lib.check(self.lib.pmce_model_set_gemm_mode(self.handle, 1 if mode == "split_f16" else 0), "model_set_gemm_mode")
+
+    def gemm_mode(self) -> str:
+        return "split_f16" if self.lib.pmce_model_gemm_mode(self.handle) else "f32"
 
     def set_concurrency(self, enable: bool):
         _lib.check(self.lib.pmce_model_set_concurrency(self.handle, 1 if enable else 0), "model_set_concurrency")
@@ -144,6 +155,19 @@ class HipModuleBase(nn.Module):
         super().__init__()
         self._engine = None
         self._dirty = True
+        self._gemm_mode = None   # None = the library's default (split_f16 unless PMCE_LIFTER_SPLIT_F16=0)
+
+    def set_gemm_mode(self, mode):
+        """Arithmetic of the pose lifter's Linear layers: 'split_f16' (three f16 products per fp32 product on the f16 matrix
+        pipe, fp32 accumulate; fp32-grade accuracy, the default) or 'f32' (fp32 matrix pipe).  Takes effect at the next
+        forward; pipelines and captured graphs made before must be rebuilt."""
+        if mode not in (None, "split_f16", "f32"):
+            raise ValueError("gemm mode must be 'split_f16', 'f32' or None")
+        self._gemm_mode = mode
+        self._dirty = True
+
+    def gemm_mode(self):
+        return self._ensure_packed().gemm_mode()
 
     # any change of the parameters' storage invalidates the packed copy
     def _apply(self, fn, *a, **k):
@@ -170,6 +194,8 @@ class HipModuleBase(nn.Module):
             raise _lib.PmceError("model parameters are on CPU: move the model to the GPU (.cuda()); no CPU fallback exists")
         if self._engine is None or self._dirty or self._engine.device != dev:
             self._engine = self._build_engine(dev)
+            if self._gemm_mode is not None:
+                self._engine.set_gemm_mode(self._gemm_mode)
             self._dirty = False
         return self._engine
 
