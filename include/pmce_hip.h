@@ -58,8 +58,8 @@ const char* pmce_model_tensor_name(const pmce_model* m, int i);
 int pmce_model_set_regressor_rows(pmce_model* m, int rows);
 /* Check that every tensor is registered. */
 int pmce_model_finalize(pmce_model* m);
-/* Arithmetic of the pose lifter's Linear layers (25 of the path's 30 large products): split_f16 != 0 (the default; env
- * PMCE_LIFTER_SPLIT_F16=0 at create for the other) = the three-product f16 form of pmce_gemm_nt_split_f16 on weights the
+/* Arithmetic of the path's 30 large products per forward (the pose lifter's Linear layers, the GRU input projections, the
+ * packed AdaLN and final products): split_f16 != 0 (the default; env PMCE_SPLIT_F16=0 at create for the other) = the three-product f16 form of pmce_gemm_nt_split_f16 on weights the
  * model packs for itself at finalize, 0 = the fp32 matrix pipe.  Both meet fp32 accuracy (tests/test_gpu_ops.py measures
  * each against an fp64 product); may be called at any time between forwards. */
 int pmce_model_set_gemm_mode(pmce_model* m, int split_f16);
@@ -145,9 +145,22 @@ int pmce_gemm_set_tuning(int tile, int grid_per_cu);
 int pmce_gemm_pack_split_f16(const float* W, int N, int K, int ldw, float* Wp, float* wscale, pmce_stream_t stream);
 int pmce_gemm_nt_split_f16(const float* A, const float* Wp, const float* wscale, const float* bias, const float* R, float* C,
                            int M, int N, int K, long long lda, long long ldc, int act, int a_packed, pmce_stream_t stream);
-/* a_packed != 0: A is not fp32 but already split, [M][K/32][hi 32 f16 | lo*2^11 32 f16] (the layout the lifter's own
+/* The same with mapped output rows: row r of C at C + (r % c_div)*c_lo + (r / c_div)*c_hi (the GRU layer-0 input projection
+ * writes (b,t) rows time-major). */
+int pmce_gemm_nt_split_f16_rowmap(const float* A, const float* Wp, const float* wscale, const float* bias, float* C, int M, int N,
+                                  int K, long long lda, int c_div, long long c_lo, long long c_hi, pmce_stream_t stream);
+/* a_packed != 0: A is not fp32 but already split, [M][K/16][hi 16 f16 | lo*2^11 16 f16] (the layout the lifter's own
  * producers write; pmce_split_rows_f16 makes it from fp32 rows). */
 int pmce_split_rows_f16(const float* A, long long M, int K, long long lda, float* Ap, pmce_stream_t stream);
+/* Tuning aid only: force the tile configuration of pmce_gemm_nt_split_f16 (0: 128x256, 1: 128x128, 2: 64x128; -1 automatic). */
+int pmce_gemm_split_set_tuning(int tile);
+/* Tuning aid only: start delay of every CU's second workgroup in units of 4096 cycles (-1: half a tile of matrix time). */
+int pmce_gemm_split_set_skew(int units);
+/* Diagnostics (scripts/microbench/victims.py; not on the product path): self-checking bystander kernels and matrix-pipe
+ * spinners used to show that waves executing f16 matrix instructions disturb packed-fp32 arithmetic of other kernels' waves on
+ * MI355X - the reason the split-f16 mode runs every kernel of a forward on one stream.  bad4: 4 unsigned counters. */
+int pmce_dbg_victim(int kind, unsigned* bad4, int blocks, int iters, const float* table, pmce_stream_t stream);
+int pmce_dbg_mfma_spin(int kind, float* sink, int blocks, int iters, pmce_stream_t stream);
 
 /* PoseEstimation.py:78-81 — x[tok] = joint_embed(pose2d) + imgfeat_embed(img_feat)[b,t] + spatial_pos[j]. */
 int pmce_embed_tokens_f32(const float* pose2d, const float* E, const float* Wje, const float* bje, const float* spos,

@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = osp.dirname(osp.abspath(__file__))
 CSRC = osp.join(HERE, "csrc")
 LIB = osp.join(HERE, "libpmce_hip.so")
-SOURCES = ["common.cpp", "gemm_f32.hip", "lifter.hip", "gru.hip", "coevo.hip", "metrics.hip", "model.cpp"]
+SOURCES = ["common.cpp", "gemm_f32.hip", "gemm_split_f16.hip", "lifter.hip", "gru.hip", "coevo.hip", "metrics.hip", "dbg_victims.hip", "model.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -39,7 +39,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(src):
         obj = osp.join(objdir, osp.splitext(src)[0] + ".o")
-        cmd = [hipcc, *FLAGS, "-x", "hip", "-c", osp.join(CSRC, src), "-o", obj]
+        extra = os.environ.get("PMCE_EXTRA_HIPCC_FLAGS", "").split()
+        cmd = [hipcc, *FLAGS, *extra, "-x", "hip", "-c", osp.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")

@@ -48,8 +48,6 @@ struct GemmParams {
   long long bsA, bsW, bsBias, bsC;  // per-blockIdx.z offsets (elements)
   int ntm, ntn;                     // tile counts
   int grid_cap;                     // persistent workgroups per batch entry
-  const float* wscale;              // split-f16 form only: {2^s, 2^-s} of the packed W (device memory)
-  int a_packed;                     // split-f16 form only: A is already in (hi | lo * 2^11) f16 planes
 };
 
 struct PendingEpi {  // the finished-but-not-yet-stored tile (all fields wave-uniform: they live in SGPRs)
@@ -75,24 +73,7 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
 }
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-// fp32 -> (hi, lo) f16 pair per element: hi = rne16(x), lo = rne16((x - hi) * 2^11).  x = hi + lo * 2^-11 to 22 bits;
-// the 2^11 keeps lo a NORMAL f16 wherever hi is one (no reliance on sub-normal operands in the matrix pipe).
-__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, f16x8& hi, f16x8& lo) {
-  const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-#pragma unroll
-  for (int e = 0; e < 8; ++e) hi[e] = (_Float16)v[e];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) lo[e] = (_Float16)((v[e] - (float)hi[e]) * 2048.0f);
-}
-
-// SPLIT = the three-product f16 form: W is the PACKED operand of pmce_gemm_pack_split_f16 - per row and
-// 32-wide k-tile, 32 f16 "hi" then 32 f16 "lo" of W * 2^s (128 bytes: the same rows, strides and LDS-DMA as the fp32 form)
-// - A stays fp32 in memory and is split into (hi, lo * 2^11) in registers on its way from LDS to the matrix pipe;
-//     acc += Ahi * Whi + Ahi * Wlo + Alo_s * (Whi * 2^-11)        (v_mfma_f32_32x32x16_f16, fp32 accumulate)
-// and the epilogue multiplies by 2^-s.  Dropped: the lo*lo term (2^-22 relative) - below the fp32 product's own rounding.
-template <int BM, int BN, int WGM, int ACT, bool RES, bool CMAP, bool SPLIT = false, bool APACK = false>
+template <int BM, int BN, int WGM, int ACT, bool RES, bool CMAP>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
   constexpr int LD = 32;  // unpadded rows (the DMA writes lane-linearly); 16-byte chunks XOR-swizzled instead
   constexpr int WGN = 4 / WGM;  // 4 waves arranged WGM x WGN
@@ -215,13 +196,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
 
   // The bias is the accumulators' initial value (no add in the epilogue); the next tile's is fetched a tile ahead.
   float bv_next[TN];
-  const float w_up = SPLIT ? p.wscale[0] : 1.f, w_down = SPLIT ? p.wscale[1] : 1.f;  // 2^s, 2^-s (wave-uniform)
   auto load_bias = [&](int nb) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = nb + wn * WN + j * 32 + n0;
       bv_next[j] = (bias && n < p.N) ? bias[n] : 0.f;
-      if (SPLIT) bv_next[j] *= w_up;  // exact: a power of two
     }
   };
 
@@ -243,7 +222,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
       for (int u = 0; u < EPS; u += 2) {  // EPS is even; pairs share the packed GELU
         const int e = SS * EPS + u;
         f32x2 v = {prv[(e / 16) % TM][(e / 16) / TM][e % 16], prv[((e + 1) / 16) % TM][((e + 1) / 16) / TM][(e + 1) % 16]};
-        if (SPLIT) v *= w_down;
         if (ACT == 1) v = gelu_erf2(v);
         if (RES) v += f32x2{rv[SS & 1][u], rv[SS & 1][u + 1]};
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), rc, lane_off, EPI_BYTES(e, ldcb), PMCE_ST_AUX);
@@ -265,57 +243,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
     }
     const float* as = &As[buf][(wm * WM + n0) * LD];
     const float* bs = &Bs[buf][(wn * WN + n0) * LD];
-    if constexpr (SPLIT) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {  // two k-steps of 16: lane (row, hb) holds k = 16 s + 8 hb + [0, 8) of its row
-        f16x8 ahi[TM], alo[TM], whi[TN], wlo[TN], wh2[TN];
+    for (int g = 0; g < 4; ++g) {
+      const int co = 4 * ((2 * g + hb) ^ swz);  // physical position of logical chunk 2g+hb in this lane's rows
+      f32x4 a[TM], b[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          if constexpr (APACK) {  // A already holds (hi | lo * 2^11) f16 planes per 32-wide k-tile, like W
-            ahi[i] = *reinterpret_cast<const f16x8*>(as + i * 32 * LD + 4 * ((2 * s + hb) ^ swz));
-            alo[i] = *reinterpret_cast<const f16x8*>(as + i * 32 * LD + 4 * ((4 + 2 * s + hb) ^ swz));
-          } else {
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(as + i * 32 * LD + 4 * ((4 * s + 2 * hb) ^ swz));
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(as + i * 32 * LD + 4 * ((4 * s + 2 * hb + 1) ^ swz));
-            split8(x0, x1, ahi[i], alo[i]);
-          }
-        }
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LD + co);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          whi[j] = *reinterpret_cast<const f16x8*>(bs + j * 32 * LD + 4 * ((2 * s + hb) ^ swz));
-          wlo[j] = *reinterpret_cast<const f16x8*>(bs + j * 32 * LD + 4 * ((4 + 2 * s + hb) ^ swz));
-          wh2[j] = whi[j] * (_Float16)0.00048828125f;  // 2^-11: undoes the scale of alo
-        }
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LD + co);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) cur[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[i], whi[j], cur[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) cur[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[i], wlo[j], cur[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) cur[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[i], wh2[j], cur[i][j], 0, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = 4 * ((2 * g + hb) ^ swz);  // physical position of logical chunk 2g+hb in this lane's rows
-        f32x4 a[TM], b[TN];
-  #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LD + co);
-  #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LD + co);
-  #pragma unroll
-        for (int s = 0; s < 4; ++s)
-  #pragma unroll
-          for (int i = 0; i < TM; ++i)
-  #pragma unroll
-            for (int j = 0; j < TN; ++j)
-              cur[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], cur[i][j], 0, 0, 0);
-      }
+          for (int j = 0; j < TN; ++j)
+            cur[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], cur[i][j], 0, 0, 0);
     }
     dma_wait_and_sync();
     buf ^= 1;
@@ -361,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
           for (int r = 0; r < 16; ++r) {
             const int m = mrow + (r & 3) + 8 * (r >> 2);
             if (nok && m < p.M)
-              C[(long long)(m % p.c_div) * p.c_lo + (long long)(m / p.c_div) * p.c_hi + n] = SPLIT ? acc[i][j][r] * w_down : acc[i][j][r];
+              C[(long long)(m % p.c_div) * p.c_lo + (long long)(m / p.c_div) * p.c_hi + n] = acc[i][j][r];
           }
         } else {
           float* __restrict__ Cp = C + (long long)mrow * ldc + n;  // 32-bit offsets from here on
@@ -374,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              float v = SPLIT ? acc[i][j][r] * w_down : acc[i][j][r];
+              float v = acc[i][j][r];
               if (ACT == 1) v = gelu_erf(v);
               if (RES) v += rv[r];
               Cp[((r & 3) + 8 * (r >> 2)) * ldc] = v;
@@ -384,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
             for (int r = 0; r < 16; ++r) {
               const int rr = (r & 3) + 8 * (r >> 2);
               if (nok && mrow + rr < p.M) {
-                float v = SPLIT ? acc[i][j][r] * w_down : acc[i][j][r];
+                float v = acc[i][j][r];
                 if (ACT == 1) v = gelu_erf(v);
                 if (RES) v += Rp[rr * ldc];
                 Cp[rr * ldc] = v;
@@ -456,23 +398,7 @@ static void launch_gemm(const GemmParams& p, int batch, bool cmap, hipStream_t s
   g = (g + 7) & ~7;  // the XCD chunking wants a multiple of 8 workgroups
   const dim3 grid(g, 1, batch), block(256);
   const bool res = p.R != nullptr;
-  if (p.wscale && p.a_packed) {
-    if (p.act == 1) {
-      if (res) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, 1, true, false, true, true>), grid, block, 0, stream, p);
-      else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, 1, false, false, true, true>), grid, block, 0, stream, p);
-    } else {
-      if (res) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, 0, true, false, true, true>), grid, block, 0, stream, p);
-      else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, 0, false, false, true, true>), grid, block, 0, stream, p);
-    }
-  } else if (p.wscale) {  // split-f16 form (never with a C row map: checked by the caller)
-    if (p.act == 1) {
-      if (res) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, 1, true, false, true>), grid, block, 0, stream, p);
-      else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, 1, false, false, true>), grid, block, 0, stream, p);
-    } else {
-      if (res) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, 0, true, false, true>), grid, block, 0, stream, p);
-      else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, 0, false, false, true>), grid, block, 0, stream, p);
-    }
-  } else if (cmap) {
+  if (cmap) {
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, 0, false, true>), grid, block, 0, stream, p);
   } else if (p.act == 1) {
     if (res) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, 1, true, false>), grid, block, 0, stream, p);
@@ -515,10 +441,10 @@ static int pick_tile(int M, int N, int batch) {
   return best;
 }
 
-static int gemm_nt_any(const float* A, const float* W, const float* wscale, int a_packed, const float* bias, const float* R, float* C, int M,
-                       int N, int K, long long lda, int ldw, long long ldc, int act, int a_div, long long a_lo, long long a_hi,
-                       int c_div, long long c_lo, long long c_hi, int batch, long long bsA, long long bsW, long long bsBias,
-                       long long bsC, hipStream_t stream) {
+extern "C" int pmce_gemm_nt_f32(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N,
+                                int K, long long lda, int ldw, long long ldc, int act, int a_div, long long a_lo,
+                                long long a_hi, int c_div, long long c_lo, long long c_hi, int batch, long long bsA,
+                                long long bsW, long long bsBias, long long bsC, hipStream_t stream) {
   PMCE_REQUIRE(A && W && C, "gemm: null pointer");
   PMCE_REQUIRE(M > 0 && N > 0 && K > 0 && K % 32 == 0, "gemm: need M,N>0 and K%%32==0 (got M=%d N=%d K=%d)", M, N, K);
   PMCE_REQUIRE(ldw >= K && ldw % 4 == 0, "gemm: ldw=%d must be >=K and a multiple of 4", ldw);
@@ -540,8 +466,6 @@ static int gemm_nt_any(const float* A, const float* W, const float* wscale, int 
                  "gemm: an operand spans 4 GiB or more per batch entry (split the batch)");
   }
   p.act = act;
-  p.wscale = wscale;
-  p.a_packed = a_packed;
   p.bsA = bsA; p.bsW = bsW; p.bsBias = bsBias; p.bsC = bsC;
   const int ti = pick_tile(M, N, batch);
   p.ntm = (M + kTiles[ti].bm - 1) / kTiles[ti].bm;
@@ -555,97 +479,5 @@ static int gemm_nt_any(const float* A, const float* W, const float* wscale, int 
     case 2: launch_gemm<64, 128, 2>(p, batch, cmap, stream); break;
     default: launch_gemm<64, 64, 2>(p, batch, cmap, stream); break;
   }
-  return pmce_check_launch(wscale ? "gemm_nt_split_f16" : "gemm_nt_f32");
-}
-
-extern "C" int pmce_gemm_nt_f32(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N,
-                                int K, long long lda, int ldw, long long ldc, int act, int a_div, long long a_lo,
-                                long long a_hi, int c_div, long long c_lo, long long c_hi, int batch, long long bsA,
-                                long long bsW, long long bsBias, long long bsC, hipStream_t stream) {
-  return gemm_nt_any(A, W, nullptr, 0, bias, R, C, M, N, K, lda, ldw, ldc, act, a_div, a_lo, a_hi, c_div, c_lo, c_hi, batch, bsA,
-                     bsW, bsBias, bsC, stream);
-}
-
-// ---- the three-product f16 form ---------------------------------------------------------------------------------------------
-// C = epi(A Wt + bias) (+R) with fp32 A, C, bias, R in memory and the same result to fp32 rounding (tests/test_gpu_ops.py
-// measures both forms against an fp64 product), on the f16 matrix pipe (16x the fp32 pipe's rate).  `Wp` / `wscale` come from
-// pmce_gemm_pack_split_f16 (once per weight).  |A| must stay below the f16 range (65504): an overflowing element gives
-// inf/nan outputs, never a silently wrong finite one.
-extern "C" int pmce_gemm_nt_split_f16(const float* A, const float* Wp, const float* wscale, const float* bias, const float* R,
-                                      float* C, int M, int N, int K, long long lda, long long ldc, int act, int a_packed,
-                                      hipStream_t stream) {
-  PMCE_REQUIRE(wscale, "gemm_split: null wscale");
-  PMCE_REQUIRE(!a_packed || lda == K, "gemm_split: a packed A has lda == K");
-  return gemm_nt_any(A, Wp, wscale, a_packed, bias, R, C, M, N, K, lda, K, ldc, act, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, stream);
-}
-
-// W[N][ldw] fp32 -> Wp[N][K/32][2][32] f16 (viewed as N*K floats) and wscale = {2^s, 2^-s, max|W| bits}, s chosen so that
-// max|W| * 2^s lies in [2^14, 2^15): hi = rne16(W 2^s), lo = rne16(W 2^s - hi) - both normal f16 for every weight within
-// 2^-17 of the largest (smaller ones lose bits that are 2^-28 of the largest product).
-__global__ void split_absmax_kernel(const float* __restrict__ W, int N, int K, int ldw, unsigned* __restrict__ out) {
-  float m = 0.f;
-  const long long total = (long long)N * K;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
-    m = fmaxf(m, fabsf(W[(i / K) * ldw + (i % K)]));
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order like their bit patterns
-}
-__global__ void split_pack_kernel(const float* __restrict__ W, int N, int K, int ldw, _Float16* __restrict__ Wp,
-                                  float* __restrict__ wscale) {
-  const float mx = __uint_as_float(reinterpret_cast<const unsigned*>(wscale)[2]);
-  int e = 0;
-  if (mx > 0.f) frexpf(mx, &e);  // mx = f * 2^e, f in [0.5, 1)
-  const float up = mx > 0.f ? ldexpf(1.f, 15 - e) : 1.f, down = mx > 0.f ? ldexpf(1.f, e - 15) : 1.f;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    wscale[0] = up;
-    wscale[1] = down;
-  }
-  const long long total = (long long)N * K;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long n = i / K;
-    const int k = (int)(i % K);
-    const float ws = W[n * ldw + k] * up;
-    const _Float16 hi = (_Float16)ws;
-    const _Float16 lo = (_Float16)(ws - (float)hi);
-    _Float16* row = Wp + (n * K + (k / 32) * 32) * 2;  // 64 f16 per (row, k-tile)
-    row[k % 32] = hi;
-    row[32 + k % 32] = lo;
-  }
-}
-// A[M][lda] fp32 -> Ap[M][K/32][2][32] f16: hi = rne16(a), lo = rne16((a - hi) * 2^11)  (what the producers of the lifter's
-// GEMM operands write directly; this stand-alone form serves tests and operands that arrive as fp32)
-__global__ void split_rows_kernel(const float* __restrict__ A, long long M, int K, long long lda, _Float16* __restrict__ Ap) {
-  const long long total = M * K;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long m = i / K;
-    const int k = (int)(i % K);
-    const float a = A[m * lda + k];
-    const _Float16 hi = (_Float16)a;
-    const _Float16 lo = (_Float16)((a - (float)hi) * 2048.0f);
-    _Float16* row = Ap + (m * K + (k / 32) * 32) * 2;
-    row[k % 32] = hi;
-    row[32 + k % 32] = lo;
-  }
-}
-extern "C" int pmce_split_rows_f16(const float* A, long long M, int K, long long lda, float* Ap, hipStream_t stream) {
-  PMCE_REQUIRE(A && Ap && M > 0 && K > 0 && K % 32 == 0 && lda >= K, "split_rows: bad arguments");
-  const long long total = M * K;
-  const long long want = (total + 256 * 4 - 1) / (256 * 4);
-  hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, stream, A, M, K, lda,
-                     reinterpret_cast<_Float16*>(Ap));
-  return pmce_check_launch("split_rows_f16");
-}
-
-extern "C" int pmce_gemm_pack_split_f16(const float* W, int N, int K, int ldw, float* Wp, float* wscale, hipStream_t stream) {
-  PMCE_REQUIRE(W && Wp && wscale, "gemm_pack_split: null pointer");
-  PMCE_REQUIRE(N > 0 && K > 0 && K % 32 == 0 && ldw >= K, "gemm_pack_split: need N>0, K%%32==0, ldw>=K (N=%d K=%d ldw=%d)", N, K, ldw);
-  if (const hipError_t rc = hipMemsetAsync(wscale, 0, 4 * sizeof(float), stream); rc != hipSuccess) {
-    pmce_set_error("gemm_pack_split: hipMemsetAsync failed: %s", hipGetErrorString(rc));
-    return PMCE_ERR_LAUNCH;
-  }
-  const long long total = (long long)N * K;
-  const int blocks = (int)((total + 256 * 8 - 1) / (256 * 8) < 2048 ? (total + 256 * 8 - 1) / (256 * 8) : 2048);
-  hipLaunchKernelGGL(split_absmax_kernel, dim3(blocks), dim3(256), 0, stream, W, N, K, ldw, reinterpret_cast<unsigned*>(wscale) + 2);
-  hipLaunchKernelGGL(split_pack_kernel, dim3(blocks), dim3(256), 0, stream, W, N, K, ldw, reinterpret_cast<_Float16*>(Wp), wscale);
-  return pmce_check_launch("gemm_pack_split_f16");
+  return pmce_check_launch("gemm_nt_f32");
 }

@@ -1,0 +1,480 @@
+// Three-product f16 "NT" GEMM for gfx950:  C[m,n] = epi( sum_k A[m,k] * W[n,k] + bias[n] )  (+ R[m,n]),  fp32 in memory.
+//
+// The pose lifter's Linear layers (reference PoseEstimation.py:13-29 via timm Attention/Mlp, and imgfeat_embed,
+// PoseEstimation.py:80) are 25 of the path's 30 large products and 70 % of its time on the fp32 matrix pipe
+// (v_mfma_f32_32x32x2_f32: 157 TFLOP/s).  The f16 pipe is 16x faster (v_mfma_f32_32x32x16_f16: 2.5 PFLOP/s) and
+// accumulates in fp32, so an fp32 product costs three f16 products at fp32 accuracy:
+//     a = ahi + alo * 2^-11,  w * 2^s = whi + wlo            (hi = rne16(x), lo = rne16(x - hi); 22 mantissa bits each)
+//     a * w * 2^s  =  ahi whi + ahi wlo + alo (whi 2^-11)  +  O(2^-22)
+// (the dropped lo*lo term and the planes' own rounding sit below the fp32 product's accumulation error: measured against an
+// fp64 product the result is CLOSER than the fp32 pipe's, tests/test_gpu_ops.py).  2^s (a power of two per weight, chosen
+// by pmce_gemm_pack_split_f16) lifts max|w| to [2^14, 2^15) so that wlo and whi 2^-11 are normal f16 numbers for every weight
+// that matters; alo carries 2^11 so that it is normal wherever ahi is.  No operand relies on f16 sub-normals.
+//
+// Kernel: 256 threads = 2x2 waves, wave tile (32 TM) x (32 TN), block tile (64 TM) x (64 TN), k-tile 16.
+//  * W is PACKED once: per row and 16-wide k-tile, 16 f16 hi then 16 f16 lo (64 bytes - the size of a 16-wide fp32 k-tile of
+//    A, so both operands move as 64-byte rows).  A stays fp32 in memory (or arrives packed the same way, APACK) and is split in
+//    registers between its ds_read and the matrix pipe.
+//  * Tiles go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), 16 rows x 64 B per wave instruction, into a ring of
+//    NS = 3 or 4 stages; the 16-byte chunks of a row are XOR-swizzled with (row >> 2) & 3 on the DMA's source address and on
+//    the ds_read address (conflict-free ds_read_b128).  A k-iteration is 24 (TN = 4) or 12 matrix instructions per wave -
+//    0.3 us - far less than a loaded L2 / HBM round trip, hence NS - 1 k-tiles in flight and ONE barrier per iteration:
+//        wait(k-tile it landed) ; barrier ; issue DMA of k-tile it+NS-1 into the stage read in iteration it-1 ; compute.
+//    The stream of k-tiles runs across tile boundaries (the next tile's first k-tiles fly under this tile's last ones).
+//    The tile's bias slice rides in with its first k-tile (one more DMA instruction of wave 0) and becomes the accumulators'
+//    initial value: the k-loop has no compiler-counted vector-memory operation whose wait would drain the ring.
+//  * PERSISTENT workgroups, two per CU, walk an XCD-local chunk of the tile order (as gemm_f32.hip); the epilogue (scale by
+//    2^-s, GELU, residual, stores) runs straight from the accumulators while the CU's other workgroup keeps the pipe busy.
+#include <atomic>
+
+#include "common.hpp"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct SplitParams {
+  const float* A;       // fp32 [M][lda], or packed planes [M][K/16][16 hi | 16 lo*2^11] f16 (APACK)
+  const float* W;       // packed planes [N][K/16][16 hi | 16 lo] f16 of W * 2^s
+  const float* wscale;  // {2^s, 2^-s}
+  const float* bias;    // [N] or null
+  const float* R;       // residual [M][ldc] or null
+  float* C;
+  int M, N, K;
+  unsigned lda, ldc;
+  int ntm, ntn;
+  int c_div;             // > 0: C row r lives at (r % c_div) * c_lo + (r / c_div) * c_hi (elements); never with R
+  long long c_lo, c_hi;
+  int skew;  // start delay of the second workgroup per CU, in units of 4096 cycles
+};
+
+// LDS-DMA: 64 lanes x 16 B from per-lane buffer offsets into LDS at M0 + lane*16 (see gemm_f32.hip)
+__device__ __forceinline__ void sdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff, unsigned lds_wave_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(lds_wave_base), "s"(soff)
+      : "memory");
+}
+
+// fp32 -> (hi, lo * 2^11) f16
+__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, f16x8& hi, f16x8& lo) {
+  const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) hi[e] = (_Float16)v[e];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) lo[e] = (_Float16)((v[e] - (float)hi[e]) * 2048.0f);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int TM, int TN>
+struct SplitCfg {
+  static constexpr int BM = 64 * TM, BN = 64 * TN;
+  static constexpr int STAGE_FLOATS = (BM + BN) * 16;
+  static constexpr int NS = STAGE_FLOATS * 4 * 4 <= 64 * 1024 ? 4 : 3;
+  static constexpr int LDS_BYTES = NS * STAGE_FLOATS * 4 + 2 * 1024;  // + two bias slices (this tile's, the next one's)
+  static constexpr int DPW = (BM + BN) / 64;  // DMA instructions per wave per k-tile (16 rows each)
+};
+
+template <int TM, int TN, int ACT, bool RES, bool APACK>
+__global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
+  using Cfg = SplitCfg<TM, TN>;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, WM = 32 * TM, WN = 32 * TN;
+  constexpr int NS = Cfg::NS, SF = Cfg::STAGE_FLOATS, DPW = Cfg::DPW;
+  constexpr int GA = BM / 16;  // 16-row groups of the A part of a stage (a multiple of 4: every wave's first GA/4 DMAs are A's)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = lane & 31, hb = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;
+
+  // ---- persistent workgroups on an XCD-local chunk of the grouped tile order (gemm_f32.hip) ----
+  const int nblk = p.ntm * p.ntn;
+  const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, gx = gridDim.x >> 3;
+  const int cq = nblk >> 3, cr = nblk & 7;
+  const int chunk_start = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+  const int chunk_len = cq + (xcd < cr ? 1 : 0);
+  if (bx >= chunk_len) return;
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * p.ntn;
+  auto tile_coords = [&](int bid, int& mb, int& nb) {
+    const int group = bid / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(p.ntm - first_m, GROUP_M);
+    mb = (first_m + (bid % per_group) % gsz) * BM;
+    nb = ((bid % per_group) / gsz) * BN;
+  };
+  const int my_tiles = (chunk_len - bx + gx - 1) / gx;
+  const int nk = p.K / 16;
+  const int total = my_tiles * nk;
+  // The two workgroups of a CU start together and their tiles take the same time: left alone they reach their epilogues
+  // (a burst of stores with the matrix pipe idle) at the same moment, tile after tile.  The second workgroup of each CU (the
+  // dispatcher fills every CU of an XCD once before it doubles up) starts about half a tile late, so that one stores while
+  // the other computes.
+  if (p.skew > 0 && gridDim.x >= 512 && bx >= (gx >> 1)) {
+    for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(64);
+  }
+
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, 0xffffffff, 0x00020000);
+  // bounded: lanes past bias[N-1] read zeros
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.N * 4 : 0, 0x00020000);
+
+  // ---- DMA side.  Instruction q of a wave moves row group g = wave + 4 q of a stage: lane L -> row 16 g + (L >> 2), PHYSICAL
+  // chunk L & 3, which holds logical chunk (L & 3) ^ ((row >> 2) & 3) = (L & 3) ^ ((L >> 4) & 3). ----
+  const int drow = lane >> 2;
+  const unsigned dchunk = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) * 4);  // floats
+  unsigned doff[DPW];
+  auto set_ptrs = [&](int mb, int nb) {
+#pragma unroll
+    for (int q = 0; q < DPW; ++q) {
+      const int g = wave + 4 * q;
+      if (g < GA)
+        doff[q] = ((unsigned)min(mb + 16 * g + drow, p.M - 1) * p.lda + dchunk) * 4u;
+      else
+        doff[q] = ((unsigned)min(nb + 16 * (g - GA) + drow, p.N - 1) * (unsigned)p.K + dchunk) * 4u;
+    }
+  };
+  const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)lds;
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+  auto issue = [&](int kt, int stage) {
+    const int ko = kt * 64;  // bytes
+#pragma unroll
+    for (int q = 0; q < DPW; ++q)
+      sdma16((wave + 4 * q) < GA ? rsrc_a : rsrc_w, doff[q], ko, lds_wave + stage * (SF * 4) + q * 4096);
+  };
+
+  // issue-side cursor (runs NS-1 k-tiles ahead of the compute side, across tile boundaries)
+  int i_li = bx, i_kt = 0, i_stage = 0, issued = 0, i_nb = 0, i_par = 0;
+  {
+    int mb;
+    tile_coords(chunk_start + i_li, mb, i_nb);
+    set_ptrs(mb, i_nb);
+  }
+  auto issue_next = [&]() {
+    if (i_kt == 0) {  // the tile's bias slice: 64 lanes x 4 floats
+      if (p.bias && wave == 0) sdma16(rsrc_b, (unsigned)lane * 16u, i_nb * 4, lds0 + NS * SF * 4 + i_par * 1024);
+      i_par ^= 1;
+    }
+    issue(i_kt, i_stage);
+    ++issued;
+    i_stage = i_stage + 1 == NS ? 0 : i_stage + 1;
+    if (++i_kt == nk) {
+      i_kt = 0;
+      i_li += gx;
+      if (i_li < chunk_len) {
+        int mb;
+        tile_coords(chunk_start + i_li, mb, i_nb);
+        set_ptrs(mb, i_nb);
+      }
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < NS - 1; ++q)
+    if (issued < total) issue_next();
+
+  const float w_up = p.wscale[0], w_down = p.wscale[1];
+  const int swz = (n0 >> 2) & 3;
+  const int a_row = (wm * WM + n0) * 16, w_row = BM * 16 + (wn * WN + n0) * 16;  // floats inside a stage
+  // chunk offsets (floats) of this lane's operand fragments
+  const int ca0 = 4 * ((2 * hb) ^ swz), ca1 = 4 * ((2 * hb + 1) ^ swz);  // fp32 A: k = 8 hb + [0,4), + [4,8)
+  const int ch = 4 * (hb ^ swz), cl = 4 * ((2 + hb) ^ swz);              // packed: hi / lo plane, k = 8 hb + [0,8)
+
+  f32x16 acc[TM][TN];
+  int li = bx, kt = 0, stage = 0, c_par = 0;
+  int m_base, n_base;
+  tile_coords(chunk_start + li, m_base, n_base);
+
+  for (int it = 0; it < total; ++it) {
+    // k-tile `it` has landed when at most (younger batches) x DPW of this wave's DMAs are still in flight (in-order
+    // completion; anything else outstanding only makes the wait stricter)
+    const int younger = issued - it - 1;
+    if (NS == 4 && younger >= 2) wait_vm<2 * DPW>();
+    else if (younger >= 1) wait_vm<DPW>();
+    else wait_vm<0>();
+    __syncthreads();  // every wave's part of k-tile `it` is in LDS; every wave is done reading the stage of k-tile it-1
+    if (issued < total) issue_next();
+
+    if (kt == 0) {  // the bias slice (scaled like W) is the accumulators' initial value
+      const float* sB = lds + NS * SF + c_par * 256 + wn * WN + n0;
+      c_par ^= 1;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float bv = p.bias ? sB[j * 32] * w_up : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+      }
+    }
+    const float* sA = lds + stage * SF;
+    {
+    f16x8 ahi[TM], alo[TM], whi[TN], wlo[TN], wh2[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if constexpr (APACK) {
+        ahi[i] = *reinterpret_cast<const f16x8*>(sA + a_row + i * 512 + ch);
+        alo[i] = *reinterpret_cast<const f16x8*>(sA + a_row + i * 512 + cl);
+      } else {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(sA + a_row + i * 512 + ca0);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(sA + a_row + i * 512 + ca1);
+        split8(x0, x1, ahi[i], alo[i]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      whi[j] = *reinterpret_cast<const f16x8*>(sA + w_row + j * 512 + ch);
+      wlo[j] = *reinterpret_cast<const f16x8*>(sA + w_row + j * 512 + cl);
+      wh2[j] = whi[j] * (_Float16)0.00048828125f;  // 2^-11: undoes the scale of alo
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[i], whi[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[i], wlo[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[i], wh2[j], acc[i][j], 0, 0, 0);
+    }
+
+    stage = stage + 1 == NS ? 0 : stage + 1;
+    if (++kt == nk) {
+      // ---- epilogue of the finished tile, straight from the accumulators ----
+      kt = 0;
+      const bool full = (m_base + BM <= p.M) && (n_base + BN <= p.N) && p.c_div == 0;
+      if (p.c_div > 0) {  // mapped rows (GRU layer-0 input projection: (b,t) rows -> time-major)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n_base + wn * WN + j * 32 + n0;
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int mm = m_base + wm * WM + i * 32 + 4 * hb + (r & 3) + 8 * (r >> 2);
+              if (n < p.N && mm < p.M) {
+                float v = acc[i][j][r] * w_down;
+                if (ACT == 1) v = gelu_erf(v);
+                p.C[(long long)(mm % p.c_div) * p.c_lo + (long long)(mm / p.c_div) * p.c_hi + n] = v;
+              }
+            }
+        }
+      } else
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n_base + wn * WN + j * 32 + n0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int mrow = m_base + wm * WM + i * 32 + 4 * hb;
+          float* __restrict__ Cp = p.C + (size_t)mrow * p.ldc + n;
+          const float* __restrict__ Rp = RES ? p.R + (size_t)mrow * p.ldc + n : nullptr;
+          if (full) {
+            float rv[16];
+            if (RES) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) rv[r] = Rp[((r & 3) + 8 * (r >> 2)) * p.ldc];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              f32x2 v = {acc[i][j][r] * w_down, acc[i][j][r + 1] * w_down};
+              if (ACT == 1) v = gelu_erf2(v);
+              if (RES) v += f32x2{rv[r], rv[r + 1]};
+              __builtin_nontemporal_store(v.x, Cp + ((r & 3) + 8 * (r >> 2)) * p.ldc);
+              __builtin_nontemporal_store(v.y, Cp + (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * p.ldc);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int rr = (r & 3) + 8 * (r >> 2);
+              if (n < p.N && mrow + rr < p.M) {
+                float v = acc[i][j][r] * w_down;
+                if (ACT == 1) v = gelu_erf(v);
+                if (RES) v += Rp[rr * p.ldc];
+                Cp[rr * p.ldc] = v;
+              }
+            }
+          }
+        }
+      }
+      li += gx;
+      if (li < chunk_len) tile_coords(chunk_start + li, m_base, n_base);
+    }
+  }
+}
+
+// ---- launch ---------------------------------------------------------------------------------------------------------------
+static std::atomic<int> g_split_tile{pmce_env_int("PMCE_SPLIT_TILE", -1)};
+static std::atomic<int> g_split_skew{pmce_env_int("PMCE_SPLIT_SKEW", -1)};
+extern "C" int pmce_gemm_split_set_skew(int units) {
+  g_split_skew.store(units, std::memory_order_relaxed);
+  return PMCE_OK;
+}
+extern "C" int pmce_gemm_split_set_tuning(int tile) {
+  g_split_tile.store(tile, std::memory_order_relaxed);
+  return PMCE_OK;
+}
+
+template <int TM, int TN, int ACT, bool RES, bool APACK>
+static int launch_one(const SplitParams& p, int grid, hipStream_t stream) {
+  using Cfg = SplitCfg<TM, TN>;
+  static std::atomic<unsigned long long> done{0};
+  PMCE_TRY(pmce_opt_in_lds(reinterpret_cast<const void*>(&gemm_split_kernel<TM, TN, ACT, RES, APACK>), Cfg::LDS_BYTES, done,
+                           "gemm_split_f16"));
+  hipLaunchKernelGGL((gemm_split_kernel<TM, TN, ACT, RES, APACK>), dim3(grid), dim3(256), Cfg::LDS_BYTES, stream, p);
+  return PMCE_OK;
+}
+template <int TM, int TN>
+static int launch_cfg(SplitParams& p, int act, bool apack, hipStream_t stream) {
+  using Cfg = SplitCfg<TM, TN>;
+  p.ntm = (p.M + Cfg::BM - 1) / Cfg::BM;
+  p.ntn = (p.N + Cfg::BN - 1) / Cfg::BN;
+  const int per_cu = (160 * 1024) / Cfg::LDS_BYTES >= 3 ? 3 : 2;
+  int g = p.ntm * p.ntn;
+  if (g > 256 * per_cu) g = 256 * per_cu;
+  g = (g + 7) & ~7;
+  const bool res = p.R != nullptr;
+  if (apack) {
+    if (act == 1) return res ? launch_one<TM, TN, 1, true, true>(p, g, stream) : launch_one<TM, TN, 1, false, true>(p, g, stream);
+    return res ? launch_one<TM, TN, 0, true, true>(p, g, stream) : launch_one<TM, TN, 0, false, true>(p, g, stream);
+  }
+  if (act == 1) return res ? launch_one<TM, TN, 1, true, false>(p, g, stream) : launch_one<TM, TN, 1, false, false>(p, g, stream);
+  return res ? launch_one<TM, TN, 0, true, false>(p, g, stream) : launch_one<TM, TN, 0, false, false>(p, g, stream);
+}
+
+// Tile choice: a launch takes as long as its busiest CU (tiles are spread evenly over an XCD's 32 CUs, two or three
+// workgroups per CU sharing one matrix pipe); `ovh` is the per-area handicap of the smaller wave tiles (operand traffic and
+// split work per matrix instruction).
+struct SplitTile { int bm, bn; double ovh; };
+static const SplitTile kSplitTiles[] = {{128, 256, 1.0}, {128, 128, 1.12}, {64, 128, 1.3}};
+static int pick_split_tile(int M, int N) {
+  const int forced = g_split_tile.load(std::memory_order_relaxed);
+  if (forced >= 0 && forced < 3) return forced;
+  int best = 0;
+  double best_cost = 1e300;
+  for (int i = 0; i < 3; ++i) {
+    const SplitTile& t = kSplitTiles[i];
+    const long long tiles = (long long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
+    const long long per_cu = ((tiles + 7) / 8 + 31) / 32;
+    const double cost = (double)per_cu * t.bm * t.bn * t.ovh;
+    if (cost < best_cost) { best_cost = cost; best = i; }
+  }
+  return best;
+}
+
+static int gemm_split_any(const float* A, const float* Wp, const float* wscale, const float* bias, const float* R, float* C, int M,
+                          int N, int K, long long lda, long long ldc, int act, int a_packed, int c_div, long long c_lo,
+                          long long c_hi, hipStream_t stream) {
+  PMCE_REQUIRE(A && Wp && wscale && C, "gemm_split: null pointer");
+  PMCE_REQUIRE(M > 0 && N > 0 && K >= 32 && K % 16 == 0, "gemm_split: need M,N>0, K>=32 and K%%16==0 (got M=%d N=%d K=%d)", M, N, K);
+  PMCE_REQUIRE(act == 0 || act == 1, "gemm_split: act must be 0 or 1");
+  PMCE_REQUIRE(lda >= K && lda % 4 == 0 && ldc >= N, "gemm_split: lda=%lld (>=K, multiple of 4) / ldc=%lld (>=N)", lda, ldc);
+  PMCE_REQUIRE(!a_packed || lda == K, "gemm_split: a packed A has lda == K");
+  PMCE_REQUIRE((long long)M * lda * 4 < (1ll << 32) && (long long)N * K * 4 < (1ll << 32) && (long long)M * ldc < (1ll << 32),
+               "gemm_split: an operand spans 4 GiB or more (split the batch)");
+  PMCE_REQUIRE(c_div == 0 || R == nullptr, "gemm_split: a C row map cannot be combined with a residual");
+  SplitParams p;
+  p.A = A; p.W = Wp; p.wscale = wscale; p.bias = bias; p.R = R; p.C = C;
+  p.M = M; p.N = N; p.K = K; p.lda = (unsigned)lda; p.ldc = (unsigned)ldc;
+  p.c_div = c_div; p.c_lo = c_lo; p.c_hi = c_hi;
+  {  // half a tile of matrix time: nk iterations x 3*TM*TN instructions x 32 cycles (TM*TN = 8 or 4), / 2, in 4096-cycle units
+    const int knob = g_split_skew.load(std::memory_order_relaxed);
+    p.skew = knob >= 0 ? knob : (K / 16) * 12 * 32 / 4096 + 1;
+  }
+  switch (pick_split_tile(M, N)) {
+    case 0: PMCE_TRY((launch_cfg<2, 4>(p, act, a_packed != 0, stream))); break;
+    case 1: PMCE_TRY((launch_cfg<2, 2>(p, act, a_packed != 0, stream))); break;
+    default: PMCE_TRY((launch_cfg<1, 2>(p, act, a_packed != 0, stream))); break;
+  }
+  return pmce_check_launch("gemm_nt_split_f16");
+}
+
+extern "C" int pmce_gemm_nt_split_f16(const float* A, const float* Wp, const float* wscale, const float* bias, const float* R,
+                                      float* C, int M, int N, int K, long long lda, long long ldc, int act, int a_packed,
+                                      hipStream_t stream) {
+  return gemm_split_any(A, Wp, wscale, bias, R, C, M, N, K, lda, ldc, act, a_packed, 0, 0, 0, stream);
+}
+extern "C" int pmce_gemm_nt_split_f16_rowmap(const float* A, const float* Wp, const float* wscale, const float* bias, float* C,
+                                             int M, int N, int K, long long lda, int c_div, long long c_lo, long long c_hi,
+                                             hipStream_t stream) {
+  PMCE_REQUIRE(c_div > 0, "gemm_split_rowmap: c_div must be positive");
+  return gemm_split_any(A, Wp, wscale, bias, nullptr, C, M, N, K, lda, N, 0, 0, c_div, c_lo, c_hi, stream);
+}
+
+// ---- operand packing ------------------------------------------------------------------------------------------------------
+// W[N][ldw] fp32 -> Wp[N][K/16][2][16] f16 (N*K floats of storage) and wscale = {2^s, 2^-s, max|W| bits, 0}, s chosen so
+// that max|W| * 2^s lies in [2^14, 2^15): hi = rne16(W 2^s), lo = rne16(W 2^s - hi) - both normal f16 for every weight within
+// 2^-17 of the largest (smaller ones lose bits that are 2^-28 of the largest product).
+__global__ void split_absmax_kernel(const float* __restrict__ W, int N, int K, int ldw, unsigned* __restrict__ out) {
+  float m = 0.f;
+  const long long total = (long long)N * K;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(W[(i / K) * ldw + (i % K)]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order like their bit patterns
+}
+__global__ void split_pack_kernel(const float* __restrict__ W, int N, int K, int ldw, _Float16* __restrict__ Wp,
+                                  float* __restrict__ wscale) {
+  const float mx = __uint_as_float(reinterpret_cast<const unsigned*>(wscale)[2]);
+  int e = 0;
+  if (mx > 0.f) frexpf(mx, &e);  // mx = f * 2^e, f in [0.5, 1)
+  const float up = mx > 0.f ? ldexpf(1.f, 15 - e) : 1.f, down = mx > 0.f ? ldexpf(1.f, e - 15) : 1.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    wscale[0] = up;
+    wscale[1] = down;
+  }
+  const long long total = (long long)N * K;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / K;
+    const int k = (int)(i % K);
+    const float ws = W[n * ldw + k] * up;
+    const _Float16 hi = (_Float16)ws;
+    const _Float16 lo = (_Float16)(ws - (float)hi);
+    _Float16* row = Wp + (n * K + (k / 16) * 16) * 2;  // 32 f16 per (row, k-tile)
+    row[k % 16] = hi;
+    row[16 + k % 16] = lo;
+  }
+}
+extern "C" int pmce_gemm_pack_split_f16(const float* W, int N, int K, int ldw, float* Wp, float* wscale, hipStream_t stream) {
+  PMCE_REQUIRE(W && Wp && wscale, "gemm_pack_split: null pointer");
+  PMCE_REQUIRE(N > 0 && K > 0 && K % 16 == 0 && ldw >= K, "gemm_pack_split: need N>0, K%%16==0, ldw>=K (N=%d K=%d ldw=%d)", N, K, ldw);
+  if (const hipError_t rc = hipMemsetAsync(wscale, 0, 4 * sizeof(float), stream); rc != hipSuccess) {
+    pmce_set_error("gemm_pack_split: hipMemsetAsync failed: %s", hipGetErrorString(rc));
+    return PMCE_ERR_LAUNCH;
+  }
+  const long long total = (long long)N * K;
+  const long long want = (total + 256 * 8 - 1) / (256 * 8);
+  const int blocks = (int)(want < 2048 ? want : 2048);
+  hipLaunchKernelGGL(split_absmax_kernel, dim3(blocks), dim3(256), 0, stream, W, N, K, ldw, reinterpret_cast<unsigned*>(wscale) + 2);
+  hipLaunchKernelGGL(split_pack_kernel, dim3(blocks), dim3(256), 0, stream, W, N, K, ldw, reinterpret_cast<_Float16*>(Wp), wscale);
+  return pmce_check_launch("gemm_pack_split_f16");
+}
+
+// A[M][lda] fp32 -> Ap[M][K/16][2][16] f16: hi = rne16(a), lo = rne16((a - hi) * 2^11)
+__global__ void split_rows_kernel(const float* __restrict__ A, long long M, int K, long long lda, _Float16* __restrict__ Ap) {
+  const long long total = M * K;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long m = i / K;
+    const int k = (int)(i % K);
+    const float a = A[m * lda + k];
+    const _Float16 hi = (_Float16)a;
+    const _Float16 lo = (_Float16)((a - (float)hi) * 2048.0f);
+    _Float16* row = Ap + (m * K + (k / 16) * 16) * 2;
+    row[k % 16] = hi;
+    row[16 + k % 16] = lo;
+  }
+}
+extern "C" int pmce_split_rows_f16(const float* A, long long M, int K, long long lda, float* Ap, hipStream_t stream) {
+  PMCE_REQUIRE(A && Ap && M > 0 && K > 0 && K % 16 == 0 && lda >= K, "split_rows: bad arguments");
+  const long long total = M * K;
+  const long long want = (total + 256 * 4 - 1) / (256 * 4);
+  hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, stream, A, M, K, lda,
+                     reinterpret_cast<_Float16*>(Ap));
+  return pmce_check_launch("split_rows_f16");
+}

@@ -94,11 +94,11 @@ struct pmce_model {
   hipEvent_t ev_lifter = nullptr;  // recorded by pmce_forward when its pose lifter is enqueued (pmce_model_wait_lifter)
   bool concurrent = true;  // pmce_model_set_concurrency
   bool fused_ca = true;    // CrossAttentionBlock of the vertex stream as one launch (PMCE_VERTEX_FUSED=0 at create: two)
-  // lifter Linear layers on the f16 matrix pipe (three-product split, fp32 accuracy) instead of the fp32 one
-  bool split_gemm = true;  // pmce_model_set_gemm_mode / PMCE_LIFTER_GEMM=f32 at create
-  float* split_arena = nullptr;  // owned (hipMalloc): every packed lifter weight + its scale
+  // the large products on the f16 matrix pipe (three-product split, fp32 accuracy) instead of the fp32 one
+  bool split_gemm = true;  // pmce_model_set_gemm_mode / PMCE_SPLIT_F16=0 at create
+  float* split_arena = nullptr;  // owned (hipMalloc): every packed weight + its scale
   LifterBlockSplit sblk[2][8];
-  SplitW s_ie;
+  SplitW s_ie, s_wih0, s_wih1, s_ada, s_final;
   // regressor (optional)
   const int* jr_indptr = nullptr;
   const int* jr_indices = nullptr;
@@ -327,7 +327,7 @@ int gemm(const float* A, const float* W, const float* bias, const float* R, floa
          long long ldc, int act, hipStream_t s) {
   return pmce_gemm_nt_f32(A, W, bias, R, Cc, M, N, K, lda, K, ldc, act, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, s);
 }
-// a lifter Linear: the f16 three-product form when the model carries the packed weight, the fp32 pipe otherwise
+// a large product: the f16 three-product form when the model carries the packed weight, the fp32 pipe otherwise
 int lgemm(const float* A, const float* W, const SplitW& sw, const float* bias, const float* R, float* Cc, int M, int N, int K,
           long long lda, long long ldc, int act, hipStream_t s) {
   if (sw.wp) return pmce_gemm_nt_split_f16(A, sw.wp, sw.scale, bias, R, Cc, M, N, K, lda, ldc, act, 0, s);
@@ -458,9 +458,13 @@ int gru_rest(pmce_model* m, int B, DecoderWs& w, hipStream_t stream);
 int gru_part(pmce_model* m, const float* img_feat, int B, DecoderWs& w, hipStream_t stream) {
   // ---- bi-GRU over the 16 frames (CoevoDecoder.py:228); buffers are time-major [t][b][.] ----
   // layer 0 input projections for both directions in one product: rows (b,t) of img_feat -> rows (t,b) of GI0
-  RUN(P_GEMM_GRU_IN, pmce_gemm_nt_f32(img_feat, m->w.wih0, m->w.bih0, nullptr, w.GI0, B * T,
-                                      6 * GH, F, F, F, 6 * GH, 0, 0, 0, 0, T, (long long)B * 6 * GH, 6 * GH, 1, 0, 0, 0, 0,
-                                      stream));
+  if (m->s_wih0.wp)
+    RUN(P_GEMM_GRU_IN, pmce_gemm_nt_split_f16_rowmap(img_feat, m->s_wih0.wp, m->s_wih0.scale, m->w.bih0, w.GI0, B * T, 6 * GH, F,
+                                                     F, T, (long long)B * 6 * GH, 6 * GH, stream));
+  else
+    RUN(P_GEMM_GRU_IN, pmce_gemm_nt_f32(img_feat, m->w.wih0, m->w.bih0, nullptr, w.GI0, B * T,
+                                        6 * GH, F, F, F, 6 * GH, 0, 0, 0, 0, T, (long long)B * 6 * GH, 6 * GH, 1, 0, 0, 0, 0,
+                                        stream));
   return gru_rest(m, B, w, stream);
 }
 
@@ -470,16 +474,18 @@ int gru_rest(pmce_model* m, int B, DecoderWs& w, hipStream_t stream) {
   // layer 1: only y[8] is consumed (CoevoDecoder.py:229,241-243) -> fwd needs t = 0..8, bwd t = 15..8.
   float* GI1f = w.GI1;
   float* GI1b = w.GI1 + (long long)9 * B * 3 * GH;
-  RUN(P_GEMM_GRU_IN, gemm(w.Y0, m->w.wih1, m->w.bih1, nullptr, GI1f, 9 * B, 3 * GH, 2 * GH, 2 * GH,
-                          3 * GH, 0, stream));
-  RUN(P_GEMM_GRU_IN, gemm(w.Y0 + (long long)8 * B * 2 * GH, m->w.wih1 + (long long)3 * GH * 2 * GH,
-                          m->w.bih1 + 3 * GH, nullptr, GI1b, 8 * B, 3 * GH, 2 * GH, 2 * GH, 3 * GH, 0, stream));
+  SplitW wih1_b = m->s_wih1;  // rows 3072.. of the packed weight (same row stride as the fp32 one), same scale
+  if (wih1_b.wp) wih1_b.wp += (long long)3 * GH * 2 * GH;
+  RUN(P_GEMM_GRU_IN, lgemm(w.Y0, m->w.wih1, m->s_wih1, m->w.bih1, nullptr, GI1f, 9 * B, 3 * GH, 2 * GH, 2 * GH,
+                           3 * GH, 0, stream));
+  RUN(P_GEMM_GRU_IN, lgemm(w.Y0 + (long long)8 * B * 2 * GH, m->w.wih1 + (long long)3 * GH * 2 * GH, wih1_b,
+                           m->w.bih1 + 3 * GH, nullptr, GI1b, 8 * B, 3 * GH, 2 * GH, 2 * GH, 3 * GH, 0, stream));
   PMCE_TRY(gru_layer(m, 1, GI1f, GI1b, 3 * GH, 0, T - 1, 9, 8, w.Y1, B, stream));
   const float* g = w.Y1 + (long long)8 * B * 2 * GH;  // img_feat = y[seqlen // 2], [B, 2048]
 
   // ---- all live AdaLN gamma/beta in one product (CoevoDecoder.py:19-20,27-28) ----
-  RUN(P_GEMM_ADA, gemm(g, m->w.ada_w, m->w.ada_b, nullptr, w.GB, B, N_ADA * 128, 2 * GH, 2 * GH,
-                       N_ADA * 128, 0, stream));
+  RUN(P_GEMM_ADA, lgemm(g, m->w.ada_w, m->s_ada, m->w.ada_b, nullptr, w.GB, B, N_ADA * 128, 2 * GH, 2 * GH,
+                        N_ADA * 128, 0, stream));
   return PMCE_OK;
 }
 
@@ -581,8 +587,8 @@ int coevo_part(pmce_model* m, const float* joints, float* cam_pose, float* cam_m
   }
   // ---- 431 -> 6890 upsample conv + 3 residual Linear(2048->6890) as ONE product (CoevoDecoder.py:238-244) ----
   RUN(P_FINAL_OP, pmce_build_final_operand_f32(g, vt_cur, w.FA, B, FINAL_K, stream));
-  RUN(P_GEMM_FINAL, gemm(w.FA, m->w.final_w, m->w.final_b, nullptr, cam_mesh, B, NVF * 3, FINAL_K,
-                         FINAL_K, NVF * 3, 0, stream));
+  RUN(P_GEMM_FINAL, lgemm(w.FA, m->w.final_w, m->s_final, m->w.final_b, nullptr, cam_mesh, B, NVF * 3, FINAL_K,
+                          FINAL_K, NVF * 3, 0, stream));
   if (side) PMCE_TRY(ev_wait(stream, m->ev_d, "coevo join d"));  // cam_pose is written by the side stream
   return PMCE_OK;
 }
@@ -606,6 +612,11 @@ int fail_after_fork(pmce_model* m, hipStream_t stream, int rc) {
   (void)hipStreamSynchronize(stream);
   return rc;
 }
+
+// Two streams inside one forward only on the fp32 matrix pipe.  A wave executing the f16 matrix instructions disturbs packed-fp32
+// arithmetic of OTHER kernels' waves on the same CU (measured: scripts/microbench/victims.py), so kernels of the
+// split-f16 form must never share the GPU with another kernel of this path: everything goes down one stream, in order.
+bool two_streams(const pmce_model* m) { return m->concurrent && !m->split_gemm; }
 
 int ensure_side(pmce_model* m) {
   if (m->side) return PMCE_OK;
@@ -635,27 +646,36 @@ int build_split_weights(pmce_model* m) {
   }
   for (auto& kind : m->sblk)
     for (auto& b : kind) b = LifterBlockSplit{};
-  m->s_ie = SplitW{};
-  if (!m->split_gemm || !m->has_lifter) return PMCE_OK;
+  m->s_ie = m->s_wih0 = m->s_wih1 = m->s_ada = m->s_final = SplitW{};
+  if (!m->split_gemm) return PMCE_OK;
   const int C = m->C;
   struct Item { const float* w; int n, k; SplitW* dst; };
   std::vector<Item> items;
-  items.push_back({m->w.ie_w, C, F, &m->s_ie});
-  for (int kind = 0; kind < 2; ++kind)
-    for (int i = 0; i < m->depth; ++i) {
-      const LifterBlockW& bw = m->w.blk[kind][i];
-      LifterBlockSplit& sw = m->sblk[kind][i];
-      items.push_back({bw.qkv_w, 3 * C, C, &sw.qkv});
-      items.push_back({bw.proj_w, C, C, &sw.proj});
-      items.push_back({bw.fc1_w, 2 * C, C, &sw.fc1});
-      items.push_back({bw.fc2_w, C, 2 * C, &sw.fc2});
-    }
+  if (m->has_lifter) {
+    items.push_back({m->w.ie_w, C, F, &m->s_ie});
+    for (int kind = 0; kind < 2; ++kind)
+      for (int i = 0; i < m->depth; ++i) {
+        const LifterBlockW& bw = m->w.blk[kind][i];
+        LifterBlockSplit& sw = m->sblk[kind][i];
+        items.push_back({bw.qkv_w, 3 * C, C, &sw.qkv});
+        items.push_back({bw.proj_w, C, C, &sw.proj});
+        items.push_back({bw.fc1_w, 2 * C, C, &sw.fc1});
+        items.push_back({bw.fc2_w, C, 2 * C, &sw.fc2});
+      }
+  }
+  if (m->has_decoder) {
+    items.push_back({m->w.wih0, 6 * GH, F, &m->s_wih0});
+    items.push_back({m->w.wih1, 6 * GH, 2 * GH, &m->s_wih1});
+    items.push_back({m->w.ada_w, N_ADA * 128, 2 * GH, &m->s_ada});
+    items.push_back({m->w.final_w, NVF * 3, FINAL_K, &m->s_final});
+  }
+  if (items.empty()) return PMCE_OK;
   size_t floats = 0;
   for (auto& it : items) floats += (((size_t)it.n * it.k + 63) & ~(size_t)63) + 64;
   const hipError_t rc = hipMalloc(reinterpret_cast<void**>(&m->split_arena), floats * sizeof(float));
   if (rc != hipSuccess) {
     m->split_arena = nullptr;
-    pmce_set_error("model_finalize: hipMalloc(%zu bytes) for the split lifter weights failed: %s", floats * sizeof(float),
+    pmce_set_error("model_finalize: hipMalloc(%zu bytes) for the split weights failed: %s", floats * sizeof(float),
                    hipGetErrorString(rc));
     return PMCE_ERR_LAUNCH;
   }
@@ -669,7 +689,7 @@ int build_split_weights(pmce_model* m) {
     it.dst->scale = sc;
   }
   if (hipStreamSynchronize(nullptr) != hipSuccess) {
-    pmce_set_error("model_finalize: packing the split lifter weights failed");
+    pmce_set_error("model_finalize: packing the split weights failed");
     return PMCE_ERR_LAUNCH;
   }
   return PMCE_OK;
@@ -689,7 +709,7 @@ int pmce_model_create(int num_joint, int embed_dim, int depth, pmce_model** out)
   m->depth = depth;
   m->concurrent = getenv("PMCE_SINGLE_STREAM") == nullptr;
   m->fused_ca = pmce_env_int("PMCE_VERTEX_FUSED", 1) != 0;
-  m->split_gemm = pmce_env_int("PMCE_LIFTER_SPLIT_F16", 1) != 0;
+  m->split_gemm = pmce_env_int("PMCE_SPLIT_F16", 1) != 0;
   build_names(m);
   *out = m;
   return PMCE_OK;
@@ -848,8 +868,8 @@ int pmce_decoder_forward(pmce_model* m, const float* joints, const float* img_fe
   carve_lifter(c, m, batch, lw);
   carve_decoder(c, m, batch, dw);
   PMCE_TRY(gru_part(m, img_feat, batch, dw, stream));
-  if (m->concurrent) PMCE_TRY(ensure_side(m));
-  const int rc = coevo_part(m, joints, cam_pose, cam_mesh, batch, dw, stream, m->concurrent ? m->side : nullptr);
+  if (two_streams(m)) PMCE_TRY(ensure_side(m));
+  const int rc = coevo_part(m, joints, cam_pose, cam_mesh, batch, dw, stream, two_streams(m) ? m->side : nullptr);
   return rc == PMCE_OK ? rc : fail_after_fork(m, stream, rc);
 }
 
@@ -868,7 +888,7 @@ int pmce_coevo_block_forward(pmce_model* m, int k, const float* joints, const fl
   DecoderWs dw;
   carve_lifter(c, m, batch, lw);
   carve_decoder(c, m, batch, dw);
-  RUN(P_GEMM_ADA, gemm(g, m->w.ada_w, m->w.ada_b, nullptr, dw.GB, batch, N_ADA * 128, 2 * GH, 2 * GH, N_ADA * 128, 0, stream));
+  RUN(P_GEMM_ADA, lgemm(g, m->w.ada_w, m->s_ada, m->w.ada_b, nullptr, dw.GB, batch, N_ADA * 128, 2 * GH, 2 * GH, N_ADA * 128, 0, stream));
   PMCE_TRY(joint_prep(m, k, joints, batch, dw, stream));
   if (joint_out) PMCE_TRY(joint_branch(m, joints, vt_in, joint_out, batch, dw, stream));
   return vertex_block(m, k, vt_in, vt_out, batch, dw, stream);
@@ -879,7 +899,7 @@ static int forward_impl(pmce_model* m, const float* pose2d, const float* img_fea
   // Fork: the GRU / AdaLN-parameter branch depends only on img_feat; it runs on a second (high-priority) stream
   // under the pose lifter, whose long matrix-core kernels leave the gaps its 25 short dependent steps need.
   // pmce_model_set_concurrency(m, 0) (or PMCE_SINGLE_STREAM=1 at create time) keeps everything on one stream.
-  const bool single = !m->concurrent;
+  const bool single = !two_streams(m);
   if (!single) {
     PMCE_TRY(ev_record(m->ev_fork, stream, "forward fork"));
     PMCE_TRY(ev_wait(m->side, m->ev_fork, "forward fork"));
@@ -912,7 +932,7 @@ int pmce_forward(pmce_model* m, const float* pose2d, const float* img_feat, floa
   DecoderWs dw;
   carve_lifter(c, m, batch, lw);
   carve_decoder(c, m, batch, dw);
-  if (m->concurrent) PMCE_TRY(ensure_side(m));
+  if (two_streams(m)) PMCE_TRY(ensure_side(m));
   const int rc = forward_impl(m, pose2d, img_feat, cam_mesh, cam_pose, pose3d, pred_pose, batch, lw, dw, stream);
   return rc == PMCE_OK ? rc : fail_after_fork(m, stream, rc);
 }
@@ -937,15 +957,15 @@ int pmce_stream_precompute(pmce_model* m, const float* pose2d_frames, const floa
   RUN(P_LN, pmce_ln_chain_f32(lw.X, (long long)L * m->J, m->C, m->w.ns_w, m->w.ns_b, 1e-6f,
                               nullptr, 1, 1, x0, nullptr, nullptr, 0.f, nullptr, stream));
   // window-independent GRU work: layer-0 input projections of both directions, once per frame (CoevoDecoder.py:216-221)
-  RUN(P_GEMM_GRU_IN, gemm(feat_frames, m->w.wih0, m->w.bih0, nullptr, gi0, L, 6 * GH, F, F, 6 * GH,
-                          0, stream));
+  RUN(P_GEMM_GRU_IN, lgemm(feat_frames, m->w.wih0, m->s_wih0, m->w.bih0, nullptr, gi0, L, 6 * GH, F, F, 6 * GH,
+                           0, stream));
   return PMCE_OK;
 }
 
 static int stream_forward_impl(pmce_model* m, const float* x0, const float* gi0, const int* win, int W, int L,
                                float* cam_mesh, float* cam_pose, float* pose3d, float* pred_pose, LifterWs& lw, DecoderWs& dw,
                                hipStream_t stream) {
-  const bool single = !m->concurrent;
+  const bool single = !two_streams(m);
   hipStream_t gs = single ? stream : m->side;
   if (!single) {
     PMCE_TRY(ev_record(m->ev_fork, stream, "stream_forward fork"));
@@ -984,7 +1004,7 @@ int pmce_stream_forward(pmce_model* m, const float* x0, const float* gi0, const 
   DecoderWs dw;
   carve_lifter(c, m, W, lw);
   carve_decoder(c, m, W, dw);
-  if (m->concurrent) PMCE_TRY(ensure_side(m));
+  if (two_streams(m)) PMCE_TRY(ensure_side(m));
   const int rc = stream_forward_impl(m, x0, gi0, win, W, L, cam_mesh, cam_pose, pose3d, pred_pose, lw, dw, stream);
   return rc == PMCE_OK ? rc : fail_after_fork(m, stream, rc);
 }

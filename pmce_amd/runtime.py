@@ -155,12 +155,18 @@ class HipModuleBase(nn.Module):
         super().__init__()
         self._engine = None
         self._dirty = True
-        self._gemm_mode = None   # None = the library's default (split_f16 unless PMCE_LIFTER_SPLIT_F16=0)
+        self._gemm_mode = None   # None = the library's default (split_f16 unless PMCE_SPLIT_F16=0)
 
     def set_gemm_mode(self, mode):
         """Arithmetic of the pose lifter's Linear layers: 'split_f16' (three f16 products per fp32 product on the f16 matrix
         pipe, fp32 accumulate; fp32-grade accuracy, the default) or 'f32' (fp32 matrix pipe).  Takes effect at the next
-        forward; pipelines and captured graphs made before must be rebuilt."""
+        forward; pipelines and captured graphs made before must be rebuilt.
+
+        In 'split_f16' mode every kernel of a forward runs on ONE stream and a Pipeline's lanes share one stream: on MI355X a
+        wave executing the f16 matrix instructions corrupts packed-fp32 arithmetic of other kernels' waves on the same CU
+        (scripts/microbench/victims.py), so these kernels are never overlapped with anything.  Do not run other GPU work
+        (another model, another stream of this process) concurrently with a forward in this mode; 'f32' mode has no such
+        restriction and keeps the two-stream / two-batches-in-flight execution."""
         if mode not in (None, "split_f16", "f32"):
             raise ValueError("gemm mode must be 'split_f16', 'f32' or None")
         self._gemm_mode = mode

@@ -18,10 +18,11 @@ for (N, K, act, res) in [(512, 512, 0, True), (1536, 512, 0, False), (1024, 512,
     R = torch.randn(M, N, device=dev) if res else None
     Wp, ws = ops.pack_split_f16(W)
     out = []
-    for tile in (0, 1, 2, 3):
-        for grid in (0, 1, 2, 3, 4):
-            lib.pmce_gemm_set_tuning(tile, grid)
-            t = timeit(lambda: ops.gemm_nt_split(A, Wp, ws, b, R, act))
-            out.append(f"t{tile}g{grid}:{t*1e3:.0f}")
-    lib.pmce_gemm_set_tuning(-1, 0)
+    Ap = ops.split_rows_f16(A)
+    for tile in (0, 1, 2):
+        lib.pmce_gemm_split_set_tuning(tile)
+        t = timeit(lambda: ops.gemm_nt_split(A, Wp, ws, b, R, act))
+        tp = timeit(lambda: ops.gemm_nt_split(Ap, Wp, ws, b, R, act, a_packed=True))
+        out.append(f"t{tile}:{t*1e3:.0f}/{tp*1e3:.0f}")
+    lib.pmce_gemm_split_set_tuning(-1)
     print(f"N={N} K={K} act={act} res={int(res)} us: " + " ".join(out), flush=True)

@@ -72,6 +72,72 @@ def test_gemm_nt(M, N, K, act, res):
     assert e < 2e-5       # fp32 accumulation over K <= 2048 of O(1) terms
 
 
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2])
+@pytest.mark.parametrize("M,N,K,act,res", [
+    (2, 3072, 2048, 0, False),       # AdaLN product of a 2-clip batch
+    (32, 6144, 2048, 0, False),      # GRU input projection, 2 clips
+    (300, 200, 64, 0, False),        # ragged edges everywhere
+    (544, 256, 256, 0, True),        # lifter proj, 2 clips (ragged last row tile)
+    (1000, 768, 256, 0, False),
+    (4352, 512, 256, 1, False),      # fc1 + GELU
+    (4352, 256, 512, 0, True),       # fc2 + residual
+    (130, 20670, 96, 0, False),      # ragged N (final-product shape)
+    (64, 20670, 3360, 0, False),     # the final product of a 64-clip batch
+    (17408, 768, 256, 0, False),     # qkv at B=64
+    (69632, 512, 512, 0, True),      # proj + residual at B=256, C=512: persistent workgroups walk several tiles
+    (69650, 1024, 512, 1, False),    # fc1 + GELU, ragged last row tile
+])
+def test_gemm_nt_split(M, N, K, act, res, tile):
+    """The three-product f16 form against an fp64 product, next to the fp32 pipe's own error on the same operands: every
+    tile configuration, fp32 and pre-split A."""
+    from pmce_amd import _lib, ops
+    if tile >= 0 and M > 20000 and tile != 0:
+        pytest.skip("forced small tiles at the largest sizes add nothing")
+    lib = _lib.load()
+    A = rnd("gemm.A", (M, K)).to(dev())
+    A[::5] *= 1e-3                                  # rows of small magnitude next to O(1) ones
+    W = rnd("gemm.W", (N, K), scale=K ** -0.5).to(dev())
+    b = rnd("gemm.b", (N,)).to(dev())
+    R = rnd("gemm.R", (M, N)).to(dev()) if res else None
+    Wp, ws = ops.pack_split_f16(W)
+    lib.pmce_gemm_split_set_tuning(tile)
+    try:
+        out = ops.gemm_nt_split(A, Wp, ws, b, R, act)
+        outp = ops.gemm_nt_split(ops.split_rows_f16(A), Wp, ws, b, R, act, a_packed=True)
+    finally:
+        lib.pmce_gemm_split_set_tuning(-1)
+    out32 = ops.gemm_nt(A, W, b, R, act)
+    e = e32 = 0.0
+    for r0 in range(0, M, 16384):
+        sl = slice(r0, min(M, r0 + 16384))
+        ref = A[sl].double() @ W.double().t() + b.double()
+        if act:
+            ref = torch.nn.functional.gelu(ref)
+        if res:
+            ref = ref + R[sl].double()
+        e = max(e, float((out[sl].double() - ref).abs().max()))
+        e32 = max(e32, float((out32[sl].double() - ref).abs().max()))
+    print(f"split gemm {M}x{N}x{K} act={act} res={res} tile={tile}: max-abs {e:.2e} (fp32 pipe {e32:.2e})")
+    assert torch.equal(out, outp)     # splitting A ahead of time is the same arithmetic
+    assert e < 2e-5 and e <= 1.5 * e32 + 1e-7
+
+
+def test_gemm_split_row_map():
+    """GI0 form on the f16 pipe: A rows (b,t) -> C rows (t,b)."""
+    from pmce_amd import _lib, ops
+    lib = _lib.load()
+    B, Tn, K, N = 5, 16, 64, 96
+    A = rnd("gemm.rm.A", (B * Tn, K)).to(dev())
+    W = rnd("gemm.rm.W", (N, K)).to(dev())
+    b = rnd("gemm.rm.b", (N,)).to(dev())
+    Wp, ws = ops.pack_split_f16(W)
+    out = torch.zeros(Tn * B, N, device=dev())
+    _lib.check(lib.pmce_gemm_nt_split_f16_rowmap(_lib.ptr(A), _lib.ptr(Wp), _lib.ptr(ws), _lib.ptr(b), _lib.ptr(out), B * Tn, N, K, K,
+                                                 Tn, B * N, N, _lib.current_stream()))
+    ref = (A.double() @ W.double().t() + b.double()).reshape(B, Tn, N).permute(1, 0, 2).reshape(Tn * B, N)
+    assert maxabs(out, ref) < 1e-5
+
+
 def test_gemm_row_maps_and_batch():
     """GI0 form: A rows (b,t) -> C rows (t,b); and a 2-batch launch with independent operands."""
     from pmce_amd import _lib, ops
