@@ -31,6 +31,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 MFMA == fp32 vector peak
+PEAK_F16_TFLOPS = 2500.0    # same guide: dense f16/bf16 MFMA peak (v_mfma_f32_32x32x16_f16)
 PEAK_HBM_GBS = 8000.0       # HBM3E peak (same guide; ~6.3 TB/s is what a streaming copy reaches)
 CLOCK_GHZ = 2.4
 N_SIMD = 1024               # 256 CUs x 4 SIMDs; one v_mfma_f32_32x32x2_f32 occupies a SIMD's matrix pipe for 64 cycles
@@ -94,9 +95,31 @@ def gemm_lifter_flops(B, J, C, depth=3, T=16, F=2048):
     return 2.0 * B * T * F * C + depth * 2 * (2.0 * M * C * 3 * C + 2.0 * M * C * C + 2 * 2.0 * M * C * 2 * C)
 
 
-# kernel function behind each timing class of model.cpp
-KERNEL_OF = {"gemm_lifter": "gemm_nt_kernel", "gemm_gru_in": "gemm_nt_kernel", "gemm_ada": "gemm_nt_kernel",
-             "gemm_final": "gemm_nt_kernel"}
+# kernel function behind each timing class of model.cpp: the four GEMM classes are one kernel - gemm_split_kernel in the
+# split-f16 mode (three f16 matrix products per fp32 product), gemm_nt_kernel on the fp32 matrix pipe
+GEMM_CLASSES = ("gemm_lifter", "gemm_gru_in", "gemm_ada", "gemm_final")
+
+
+def kernel_of(cls, gemm_mode):
+    if cls in GEMM_CLASSES:
+        return "gemm_split_kernel" if gemm_mode == "split_f16" else "gemm_nt_kernel"
+    return cls
+
+
+def gemm_class_bytes(name, B, J, C, depth=3, T=16, F=2048):
+    """ALGORITHMIC HBM bytes of a GEMM class: every operand and result once (fp32: A, W, C, + residual where there is one)."""
+    GH = 1024
+    M = B * T * J
+    if name == "gemm_lifter":
+        per_block = (M * C + 3 * M * C + 3 * C * C) + (M * C + 2 * M * C + C * C) + (M * C + 2 * M * C + 2 * C * C) + (2 * M * C + 2 * M * C + 2 * C * C)
+        return 4.0 * (B * T * F + B * T * C + F * C + 2 * depth * per_block)
+    if name == "gemm_gru_in":
+        return 4.0 * (16 * B * F + 16 * B * 6 * GH + 6 * GH * F + 17 * B * 2 * GH + 17 * B * 3 * GH + 6 * GH * 2 * GH)
+    if name == "gemm_ada":
+        return 4.0 * (B * 2048 + B * 3072 + 3072 * 2048)
+    if name == "gemm_final":
+        return 4.0 * (B * 3360 + B * 20670 + 20670 * 3360)
+    return None
 
 
 def class_work(name, B, J, C):
@@ -183,6 +206,8 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
     model.load_state_dict(sd)
     model.set_j_regressor(assets.load_j_regressor("h36m"))
     model = model.to(dev)
+    model.set_gemm_mode(args.gemm_mode)
+    gemm_mode = model.gemm_mode()
 
     # synthetic clips resident in HBM; NB distinct batches are rotated so that the timed loop's inputs (NB x 33.6 MB at
     # B = 256) do not sit in the 256 MB Infinity Cache from one step to the next
@@ -244,8 +269,10 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
            "config": {"workload": f"full two-stream PMCE forward (temporal pose encoder + CoEvoDecoder + 6890-vertex upsample + "
                                   f"J_regressor), batch={B}/GPU, T=16, J={J}, C={C}, random-init weights",
                       "global_batch": B * world, "seq_len": 16, "joints": J, "embed_dim": C,
-                      "parallelism": f"clip-sharded dp{world}, weights replicated", "streams": 1 if args.single_stream else 2 * depth,
-                      "batches_in_flight": depth, "distinct_input_batches": NB},
+                      "parallelism": f"clip-sharded dp{world}, weights replicated",
+                      "gemm_mode": gemm_mode,
+                      "streams": 1 if (args.single_stream or gemm_mode == "split_f16") else 2 * depth,
+                      "batches_enqueued_ahead": depth, "distinct_input_batches": NB},
            "ref_equiv_tflops": round(fpc * clips_per_s / 1e12, 2), "outputs_finite": finite}
     if not full:
         return rec, model, pipe, inputs, sd
@@ -266,7 +293,7 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
     launches = {k_: int(v[1] // nprof) for k_, v in prof.items() if v[1] > 0}
     by_kernel = {}
     for k_ in kernel_ms:
-        by_kernel.setdefault(KERNEL_OF.get(k_, k_), []).append(k_)
+        by_kernel.setdefault(kernel_of(k_, gemm_mode), []).append(k_)
     dominant = max(by_kernel, key=lambda kn: sum(kernel_ms[c] for c in by_kernel[kn]))
     dom_classes = by_kernel[dominant]
     dom_ms = sum(kernel_ms[c] for c in dom_classes)
@@ -281,7 +308,20 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
         common = {"kernel": dominant, "classes": dom_classes, "launches_per_step": dom_launches,
                   "avg_launch_ms": round(dom_ms / dom_launches, 5), "traffic": traffic, "traffic_source": traffic_src,
                   "algorithmic_per_launch": work / dom_launches}
-        if kind == "flop":
+        if kind == "flop" and dominant == "gemm_split_kernel":
+            # the kernel issues THREE f16 matrix products per algorithmic fp32 product: achieved = issued f16 FLOP/s against the
+            # dense f16 peak; the fp32-equivalent rate and the same launches against the HBM roofline (every operand and
+            # result once) are printed beside it - at these shapes the two floors are within 15 % of each other
+            ach = 3.0 * work / secs / 1e12
+            byt = sum(gemm_class_bytes(c, B, J, C) for c in dom_classes)
+            common["algorithmic_per_launch"] = 3.0 * work / dom_launches
+            roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_F16_TFLOPS, 4), **common,
+                        "arithmetic": "3 x v_mfma_f32_32x32x16_f16 per fp32 product (hi*hi + hi*lo + lo*hi), fp32 accumulate",
+                        "fp32_equiv_tflops": round(work / secs / 1e12, 1),
+                        "hbm": {"algorithmic_bytes_per_launch": round(byt / dom_launches), "achieved_gbs": round(byt / secs / 1e9, 1),
+                                "peak_gbs": PEAK_HBM_GBS, "frac": round(byt / secs / 1e9 / PEAK_HBM_GBS, 4)}}
+        elif kind == "flop":
             ach = work / secs / 1e12
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_F32_TFLOPS, 4), **common}
@@ -291,7 +331,7 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
                         "frac": round(ach / PEAK_HBM_GBS, 4), **common}
     rec.update({"roofline": roofline, "roofline_cross_attention": north_star_record(kernel_ms, launches, B, J),
                 "kernel_ms_per_step": kernel_ms, "launches_per_step": launches,
-                "kernel_ms_total_single_stream": round(sum(kernel_ms.values()), 4)})
+                "kernel_ms_total_single_stream": round(sum(kernel_ms.values()), 4), "gemm_mode": gemm_mode})
     return rec, model, pipe, inputs, sd
 
 
@@ -430,6 +470,9 @@ def main():
     ap.add_argument("--no-host-fed", action="store_true", help="skip the extra (untimed-for-value) host-fed measurement")
     ap.add_argument("--no-latency", action="store_true", help="skip the B=1 / B=8 latency record")
     ap.add_argument("--no-variant", action="store_true", help="skip the second complete record (the other pose-encoder width)")
+    ap.add_argument("--gemm-mode", choices=("split_f16", "f32"), default="split_f16",
+                    help="the large products as three f16 matrix products each (fp32 accumulate, fp32 accuracy; every kernel on one "
+                         "stream) or on the fp32 matrix pipe (two streams, two batches in flight)")
     ap.add_argument("--dist-check", action="store_true",
                     help="rendezvous + the path's collectives only (no GPU work): what the non-GPU test of the N>1 entry point runs")
     args = ap.parse_args()
@@ -441,30 +484,38 @@ def main():
     # BEFORE this process touches the GPU: a second model in one process shares HIP's few hardware queues with the first
     # one's (pooled, never destroyed) streams and loses the two-batches overlap (29.2 k instead of 32.1 k clips/s at
     # C = 256), and a child that runs while its parent holds a HIP context sees ~6 % slower kernels in its profiling pass.
-    variant = None
+    variant = variant_f32 = None
     C, B, J = args.embed_dim, args.batch, args.joints
-    if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_variant and not args.single_stream
-            and not args.dist_check and C in (256, 512)):
-        C2 = 256 if C == 512 else 512
+    keep = ("value", "unit", "ms_per_step", "windows", "config", "roofline", "roofline_cross_attention", "cpu_baseline",
+            "kernel_ms_per_step", "launches_per_step", "kernel_ms_total_single_stream", "ref_equiv_tflops", "outputs_finite")
+
+    def child_record(extra, cpu_ok):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
-               "--windows", str(args.windows), "--batch", str(B), "--joints", str(J), "--embed-dim", str(C2),
+               "--windows", str(args.windows), "--batch", str(B), "--joints", str(J),
                "--pipeline-depth", str(args.pipeline_depth), "--no-variant", "--no-host-fed", "--no-latency",
-               "--cpu-seconds", str(min(args.cpu_seconds, 8.0))]
+               "--cpu-seconds", str(min(args.cpu_seconds, 8.0)), *extra]
         cmd += ["--no-stagger"] if args.no_stagger else []
-        cmd += ["--no-cpu-baseline"] if args.no_cpu_baseline else []
+        cmd += ["--no-cpu-baseline"] if (args.no_cpu_baseline or not cpu_ok) else []
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
         r = subprocess.run(cmd, env=env, capture_output=True, text=True)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode == 0 and lines:
             d = json.loads(lines[-1])
-            variant = {k: d.get(k) for k in ("value", "unit", "ms_per_step", "windows", "config", "roofline", "roofline_cross_attention",
-                                            "cpu_baseline", "kernel_ms_per_step", "launches_per_step",
-                                            "kernel_ms_total_single_stream", "ref_equiv_tflops", "outputs_finite")}
-            variant["why"] = ("the width every reference config ships (lib/core/config.py:59)" if C2 == 256
-                              else "BASELINE.json north_star's width")
-            variant["measured_by"] = "child process running this same script, before this process touched the GPU"
-        else:
-            variant = {"error": (r.stderr or r.stdout)[-400:]}
+            rec = {k: d.get(k) for k in keep}
+            rec["measured_by"] = "child process running this same script, before this process touched the GPU"
+            return rec
+        return {"error": (r.stderr or r.stdout)[-400:]}
+
+    if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_variant and not args.single_stream
+            and not args.dist_check and C in (256, 512)):
+        C2 = 256 if C == 512 else 512
+        variant = child_record(["--embed-dim", str(C2), "--gemm-mode", args.gemm_mode], True)
+        variant["why"] = ("the width every reference config ships (lib/core/config.py:59)" if C2 == 256
+                          else "BASELINE.json north_star's width")
+        if args.gemm_mode == "split_f16":     # the same workload with every product on the fp32 matrix pipe
+            variant_f32 = child_record(["--embed-dim", str(C), "--gemm-mode", "f32"], False)
+            variant_f32["why"] = ("every product on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak), two streams and two batches in "
+                                  "flight: the round-1 arithmetic, for comparison")
 
     import torch
     from pmce_amd import sharding
@@ -517,10 +568,13 @@ def main():
         line = {
             "metric": "16-frame clips/s", "value": head["value"], "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32 (large products as three f16 MFMA products each, fp32 accumulate; error vs fp64 below the fp32 pipe's)"
+                      if head.get("gemm_mode") == "split_f16" else "f32"),
+            "data": "synthetic",
             "config": head["config"], "roofline": head["roofline"], "roofline_cross_attention": head["roofline_cross_attention"],
             "cpu_baseline": cpu, "windows": head["windows"], "host_fed": host_fed, "latency": latency,
-            f"variant_c{256 if C == 512 else 512}": variant,
+            f"variant_c{256 if C == 512 else 512}": variant, "variant_f32_pipe": variant_f32,
             "kernel_ms_per_step": head["kernel_ms_per_step"], "launches_per_step": head["launches_per_step"],
             "kernel_ms_total_single_stream": head["kernel_ms_total_single_stream"],
             "ref_equiv_tflops": head["ref_equiv_tflops"], "outputs_finite": head["outputs_finite"],

@@ -64,6 +64,9 @@ int pmce_model_finalize(pmce_model* m);
  * each against an fp64 product); may be called at any time between forwards. */
 int pmce_model_set_gemm_mode(pmce_model* m, int split_f16);
 int pmce_model_gemm_mode(const pmce_model* m);
+/* Calls with fewer clips (windows) than this stay on the fp32 pipe and keep its two-stream schedule even in split_f16 mode
+ * (default 48, env PMCE_SPLIT_MIN_BATCH at create): a small batch is bound by the GRU's dependent launches, not by the products. */
+int pmce_model_set_split_min_batch(pmce_model* m, int clips);
 /* Bytes of caller-provided workspace needed for a batch of B clips. */
 size_t pmce_model_workspace_bytes(const pmce_model* m, int batch);
 

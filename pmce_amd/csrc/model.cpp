@@ -99,6 +99,11 @@ struct pmce_model {
   float* split_arena = nullptr;  // owned (hipMalloc): every packed weight + its scale
   LifterBlockSplit sblk[2][8];
   SplitW s_ie, s_wih0, s_wih1, s_ada, s_final;
+  // Below this many clips per call the products stay on the fp32 pipe: a small batch is bound by its 25 dependent GRU launches,
+  // which the two-stream schedule (fp32 mode only, see two_streams) hides under the pose lifter - worth more than the GEMM time
+  // the f16 form saves there (B = 1: 1.8 ms against 2.7 ms).  PMCE_SPLIT_MIN_BATCH at create.
+  int split_min_batch = 48;
+  bool split_now = false;  // decision for the call in progress (set by check_ws, the first thing every entry point does)
   // regressor (optional)
   const int* jr_indptr = nullptr;
   const int* jr_indices = nullptr;
@@ -328,9 +333,9 @@ int gemm(const float* A, const float* W, const float* bias, const float* R, floa
   return pmce_gemm_nt_f32(A, W, bias, R, Cc, M, N, K, lda, K, ldc, act, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, s);
 }
 // a large product: the f16 three-product form when the model carries the packed weight, the fp32 pipe otherwise
-int lgemm(const float* A, const float* W, const SplitW& sw, const float* bias, const float* R, float* Cc, int M, int N, int K,
-          long long lda, long long ldc, int act, hipStream_t s) {
-  if (sw.wp) return pmce_gemm_nt_split_f16(A, sw.wp, sw.scale, bias, R, Cc, M, N, K, lda, ldc, act, 0, s);
+int lgemm(const pmce_model* m, const float* A, const float* W, const SplitW& sw, const float* bias, const float* R, float* Cc,
+          int M, int N, int K, long long lda, long long ldc, int act, hipStream_t s) {
+  if (m->split_now && sw.wp) return pmce_gemm_nt_split_f16(A, sw.wp, sw.scale, bias, R, Cc, M, N, K, lda, ldc, act, 0, s);
   return gemm(A, W, bias, R, Cc, M, N, K, lda, ldc, act, s);
 }
 
@@ -343,20 +348,20 @@ int lifter_block_body(pmce_model* m, int kind, int i, long long M, int nframes, 
   const int J = m->J, C = m->C;
   const LifterBlockW& bw = m->w.blk[kind][i];
   const LifterBlockSplit& sw = m->sblk[kind][i];
-  RUN(P_GEMM_LIFTER, lgemm(w.XN, bw.qkv_w, sw.qkv, bw.qkv_b, nullptr, w.QKV,
+  RUN(P_GEMM_LIFTER, lgemm(m, w.XN, bw.qkv_w, sw.qkv, bw.qkv_b, nullptr, w.QKV,
                           (int)M, 3 * C, C, C, 3 * C, 0, stream));
   if (kind == 0)  // sequences = frames, tokens j contiguous                        (PoseEstimation.py:78,101)
     RUN(P_SEQ_ATTN, pmce_seq_attention_f32(w.QKV, w.AO, nframes, J, C, 0, J, 0, 1, stream));
   else  // sequences = (b,j), tokens t at stride J                                  (PoseEstimation.py:87,104)
     RUN(P_SEQ_ATTN, pmce_seq_attention_f32(w.QKV, w.AO, B * J, T, C, J, 1, (long long)T * J, J, stream));
-  RUN(P_GEMM_LIFTER, lgemm(w.AO, bw.proj_w, sw.proj, bw.proj_b, w.X, w.X, (int)M, C,
+  RUN(P_GEMM_LIFTER, lgemm(m, w.AO, bw.proj_w, sw.proj, bw.proj_b, w.X, w.X, (int)M, C,
                           C, C, C, 0, stream));
   RUN(P_LN, pmce_ln_chain_f32(w.X, M, C, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, bw.norm2_w,
                               bw.norm2_b, 1e-6f, w.XN, stream));
   float* Hid = w.QKV;
-  RUN(P_GEMM_LIFTER, lgemm(w.XN, bw.fc1_w, sw.fc1, bw.fc1_b, nullptr, Hid, (int)M,
+  RUN(P_GEMM_LIFTER, lgemm(m, w.XN, bw.fc1_w, sw.fc1, bw.fc1_b, nullptr, Hid, (int)M,
                           2 * C, C, C, 2 * C, 1, stream));
-  RUN(P_GEMM_LIFTER, lgemm(Hid, bw.fc2_w, sw.fc2, bw.fc2_b, w.X, w.X, (int)M, C,
+  RUN(P_GEMM_LIFTER, lgemm(m, Hid, bw.fc2_w, sw.fc2, bw.fc2_b, w.X, w.X, (int)M, C,
                           2 * C, 2 * C, C, 0, stream));
   return PMCE_OK;
 }
@@ -366,7 +371,7 @@ int lifter_frames(pmce_model* m, const float* pose2d, const float* img_feat, int
   const int J = m->J, C = m->C;
   const long long M = (long long)nframes * J;
   PMCE_REQUIRE(M < (1ll << 31), "lifter: too many tokens");
-  RUN(P_GEMM_LIFTER, lgemm(img_feat, m->w.ie_w, m->s_ie, m->w.ie_b, nullptr, w.E,
+  RUN(P_GEMM_LIFTER, lgemm(m, img_feat, m->w.ie_w, m->s_ie, m->w.ie_b, nullptr, w.E,
                           nframes, C, F, F, C, 0, stream));
   RUN(P_EMBED, pmce_embed_tokens_f32(pose2d, w.E, m->w.je_w, m->w.je_b,
                                      m->w.spos, w.X, M, J, C, stream));
@@ -458,7 +463,7 @@ int gru_rest(pmce_model* m, int B, DecoderWs& w, hipStream_t stream);
 int gru_part(pmce_model* m, const float* img_feat, int B, DecoderWs& w, hipStream_t stream) {
   // ---- bi-GRU over the 16 frames (CoevoDecoder.py:228); buffers are time-major [t][b][.] ----
   // layer 0 input projections for both directions in one product: rows (b,t) of img_feat -> rows (t,b) of GI0
-  if (m->s_wih0.wp)
+  if (m->split_now && m->s_wih0.wp)
     RUN(P_GEMM_GRU_IN, pmce_gemm_nt_split_f16_rowmap(img_feat, m->s_wih0.wp, m->s_wih0.scale, m->w.bih0, w.GI0, B * T, 6 * GH, F,
                                                      F, T, (long long)B * 6 * GH, 6 * GH, stream));
   else
@@ -476,15 +481,15 @@ int gru_rest(pmce_model* m, int B, DecoderWs& w, hipStream_t stream) {
   float* GI1b = w.GI1 + (long long)9 * B * 3 * GH;
   SplitW wih1_b = m->s_wih1;  // rows 3072.. of the packed weight (same row stride as the fp32 one), same scale
   if (wih1_b.wp) wih1_b.wp += (long long)3 * GH * 2 * GH;
-  RUN(P_GEMM_GRU_IN, lgemm(w.Y0, m->w.wih1, m->s_wih1, m->w.bih1, nullptr, GI1f, 9 * B, 3 * GH, 2 * GH, 2 * GH,
+  RUN(P_GEMM_GRU_IN, lgemm(m, w.Y0, m->w.wih1, m->s_wih1, m->w.bih1, nullptr, GI1f, 9 * B, 3 * GH, 2 * GH, 2 * GH,
                            3 * GH, 0, stream));
-  RUN(P_GEMM_GRU_IN, lgemm(w.Y0 + (long long)8 * B * 2 * GH, m->w.wih1 + (long long)3 * GH * 2 * GH, wih1_b,
+  RUN(P_GEMM_GRU_IN, lgemm(m, w.Y0 + (long long)8 * B * 2 * GH, m->w.wih1 + (long long)3 * GH * 2 * GH, wih1_b,
                            m->w.bih1 + 3 * GH, nullptr, GI1b, 8 * B, 3 * GH, 2 * GH, 2 * GH, 3 * GH, 0, stream));
   PMCE_TRY(gru_layer(m, 1, GI1f, GI1b, 3 * GH, 0, T - 1, 9, 8, w.Y1, B, stream));
   const float* g = w.Y1 + (long long)8 * B * 2 * GH;  // img_feat = y[seqlen // 2], [B, 2048]
 
   // ---- all live AdaLN gamma/beta in one product (CoevoDecoder.py:19-20,27-28) ----
-  RUN(P_GEMM_ADA, lgemm(g, m->w.ada_w, m->s_ada, m->w.ada_b, nullptr, w.GB, B, N_ADA * 128, 2 * GH, 2 * GH,
+  RUN(P_GEMM_ADA, lgemm(m, g, m->w.ada_w, m->s_ada, m->w.ada_b, nullptr, w.GB, B, N_ADA * 128, 2 * GH, 2 * GH,
                         N_ADA * 128, 0, stream));
   return PMCE_OK;
 }
@@ -587,7 +592,7 @@ int coevo_part(pmce_model* m, const float* joints, float* cam_pose, float* cam_m
   }
   // ---- 431 -> 6890 upsample conv + 3 residual Linear(2048->6890) as ONE product (CoevoDecoder.py:238-244) ----
   RUN(P_FINAL_OP, pmce_build_final_operand_f32(g, vt_cur, w.FA, B, FINAL_K, stream));
-  RUN(P_GEMM_FINAL, lgemm(w.FA, m->w.final_w, m->s_final, m->w.final_b, nullptr, cam_mesh, B, NVF * 3, FINAL_K,
+  RUN(P_GEMM_FINAL, lgemm(m, w.FA, m->w.final_w, m->s_final, m->w.final_b, nullptr, cam_mesh, B, NVF * 3, FINAL_K,
                           FINAL_K, NVF * 3, 0, stream));
   if (side) PMCE_TRY(ev_wait(stream, m->ev_d, "coevo join d"));  // cam_pose is written by the side stream
   return PMCE_OK;
@@ -616,7 +621,7 @@ int fail_after_fork(pmce_model* m, hipStream_t stream, int rc) {
 // Two streams inside one forward only on the fp32 matrix pipe.  A wave executing the f16 matrix instructions disturbs packed-fp32
 // arithmetic of OTHER kernels' waves on the same CU (measured: scripts/microbench/victims.py), so kernels of the
 // split-f16 form must never share the GPU with another kernel of this path: everything goes down one stream, in order.
-bool two_streams(const pmce_model* m) { return m->concurrent && !m->split_gemm; }
+bool two_streams(const pmce_model* m) { return m->concurrent && !m->split_now; }
 
 int ensure_side(pmce_model* m) {
   if (m->side) return PMCE_OK;
@@ -710,6 +715,7 @@ int pmce_model_create(int num_joint, int embed_dim, int depth, pmce_model** out)
   m->concurrent = getenv("PMCE_SINGLE_STREAM") == nullptr;
   m->fused_ca = pmce_env_int("PMCE_VERTEX_FUSED", 1) != 0;
   m->split_gemm = pmce_env_int("PMCE_SPLIT_F16", 1) != 0;
+  m->split_min_batch = pmce_env_int("PMCE_SPLIT_MIN_BATCH", 48);
   build_names(m);
   *out = m;
   return PMCE_OK;
@@ -800,6 +806,11 @@ int pmce_model_set_gemm_mode(pmce_model* m, int split_f16) {
   return PMCE_OK;
 }
 int pmce_model_gemm_mode(const pmce_model* m) { return m && m->split_gemm ? 1 : 0; }
+int pmce_model_set_split_min_batch(pmce_model* m, int clips) {
+  PMCE_REQUIRE(m && clips >= 1, "model_set_split_min_batch: need a model and clips >= 1");
+  m->split_min_batch = clips;
+  return PMCE_OK;
+}
 
 size_t pmce_model_workspace_bytes(const pmce_model* m, int batch) {
   if (!m || batch <= 0) return 0;
@@ -843,6 +854,7 @@ static int check_ws(pmce_model* m, int batch, void* ws, size_t ws_bytes) {
     pmce_set_error("workspace too small: %zu < %zu bytes for batch %d", ws_bytes, pmce_model_workspace_bytes(m, batch), batch);
     return PMCE_ERR_WORKSPACE;
   }
+  m->split_now = m->split_gemm && batch >= m->split_min_batch;  // arithmetic (and with it the stream schedule) of this call
   return PMCE_OK;
 }
 
@@ -888,7 +900,7 @@ int pmce_coevo_block_forward(pmce_model* m, int k, const float* joints, const fl
   DecoderWs dw;
   carve_lifter(c, m, batch, lw);
   carve_decoder(c, m, batch, dw);
-  RUN(P_GEMM_ADA, lgemm(g, m->w.ada_w, m->s_ada, m->w.ada_b, nullptr, dw.GB, batch, N_ADA * 128, 2 * GH, 2 * GH, N_ADA * 128, 0, stream));
+  RUN(P_GEMM_ADA, lgemm(m, g, m->w.ada_w, m->s_ada, m->w.ada_b, nullptr, dw.GB, batch, N_ADA * 128, 2 * GH, 2 * GH, N_ADA * 128, 0, stream));
   PMCE_TRY(joint_prep(m, k, joints, batch, dw, stream));
   if (joint_out) PMCE_TRY(joint_branch(m, joints, vt_in, joint_out, batch, dw, stream));
   return vertex_block(m, k, vt_in, vt_out, batch, dw, stream);
@@ -957,7 +969,7 @@ int pmce_stream_precompute(pmce_model* m, const float* pose2d_frames, const floa
   RUN(P_LN, pmce_ln_chain_f32(lw.X, (long long)L * m->J, m->C, m->w.ns_w, m->w.ns_b, 1e-6f,
                               nullptr, 1, 1, x0, nullptr, nullptr, 0.f, nullptr, stream));
   // window-independent GRU work: layer-0 input projections of both directions, once per frame (CoevoDecoder.py:216-221)
-  RUN(P_GEMM_GRU_IN, lgemm(feat_frames, m->w.wih0, m->s_wih0, m->w.bih0, nullptr, gi0, L, 6 * GH, F, F, 6 * GH,
+  RUN(P_GEMM_GRU_IN, lgemm(m, feat_frames, m->w.wih0, m->s_wih0, m->w.bih0, nullptr, gi0, L, 6 * GH, F, F, 6 * GH,
                            0, stream));
   return PMCE_OK;
 }

@@ -52,6 +52,7 @@ class HipEngine:
         self.ws_batch = 0
         self.device = None
         self.regressor_rows = 0
+        self.split_min_batch = None
 
     def __del__(self):
         try:
@@ -87,6 +88,9 @@ class HipEngine:
         forwards can be in flight at once (models.PMCE.Pipeline)."""
         other = HipEngine(self.J, self.C, self.depth)
         other.set_gemm_mode(self.gemm_mode())
+        if self.split_min_batch is not None:
+            other.set_split_min_batch(self.split_min_batch)
+        other.split_min_batch = self.split_min_batch
         other.register(self.packed)
         if self.regressor_rows:
             _lib.check(other.lib.pmce_model_set_regressor_rows(other.handle, self.regressor_rows), "set_regressor_rows")
@@ -123,6 +127,9 @@ class HipEngine:
     def gemm_mode(self) -> str:
         return "split_f16" if self.lib.pmce_model_gemm_mode(self.handle) else "f32"
 
+    def set_split_min_batch(self, clips: int):
+        _lib.check(self.lib.pmce_model_set_split_min_batch(self.handle, int(clips)), "model_set_split_min_batch")
+
     def set_concurrency(self, enable: bool):
         _lib.check(self.lib.pmce_model_set_concurrency(self.handle, 1 if enable else 0), "model_set_concurrency")
 
@@ -156,9 +163,10 @@ class HipModuleBase(nn.Module):
         self._engine = None
         self._dirty = True
         self._gemm_mode = None   # None = the library's default (split_f16 unless PMCE_SPLIT_F16=0)
+        self._split_min_batch = None
 
-    def set_gemm_mode(self, mode):
-        """Arithmetic of the pose lifter's Linear layers: 'split_f16' (three f16 products per fp32 product on the f16 matrix
+    def set_gemm_mode(self, mode, min_batch=None):
+        """Arithmetic of the large products (min_batch: calls with fewer clips stay on the fp32 pipe, default 48): 'split_f16' (three f16 products per fp32 product on the f16 matrix
         pipe, fp32 accumulate; fp32-grade accuracy, the default) or 'f32' (fp32 matrix pipe).  Takes effect at the next
         forward; pipelines and captured graphs made before must be rebuilt.
 
@@ -170,6 +178,7 @@ class HipModuleBase(nn.Module):
         if mode not in (None, "split_f16", "f32"):
             raise ValueError("gemm mode must be 'split_f16', 'f32' or None")
         self._gemm_mode = mode
+        self._split_min_batch = min_batch
         self._dirty = True
 
     def gemm_mode(self):
@@ -202,6 +211,9 @@ class HipModuleBase(nn.Module):
             self._engine = self._build_engine(dev)
             if self._gemm_mode is not None:
                 self._engine.set_gemm_mode(self._gemm_mode)
+            if self._split_min_batch is not None:
+                self._engine.set_split_min_batch(self._split_min_batch)
+                self._engine.split_min_batch = self._split_min_batch
             self._dirty = False
         return self._engine
 

@@ -44,22 +44,35 @@ def get_model(J, C):
     return _MODELS[key]
 
 
+@pytest.mark.parametrize("mode", ["default", "split_f16 at every batch size", "f32"])
 @pytest.mark.parametrize("name", ["e2e_J17_C256_B2.npz", "e2e_J19_C256_B1.npz", "e2e_J17_C512_B1.npz"])
-def test_forward_matches_reference_fixture(golden, name):
+def test_forward_matches_reference_fixture(golden, name, mode):
+    """Outputs of the reference's own forward (fixtures made by importing it, tests/golden/make_golden_e2e.py) - in the default
+    configuration (small batches stay on the fp32 pipe), with the three-product f16 form forced, and on the fp32 pipe."""
     from pmce_amd import synth
     z = golden(name)
     J, C, B = int(z["J"]), int(z["C"]), int(z["B"])
     model = get_model(J, C)
+    if mode == "default":
+        model.set_gemm_mode(None)
+    elif mode == "f32":
+        model.set_gemm_mode("f32")
+    else:
+        model.set_gemm_mode("split_f16", min_batch=1)
     assert np.array_equal(model.vj_relation, z["vj_relation"])
     pose2d, img_feat = synth.make_inputs(B, J, int(z["input_seed"]))
-    mesh, pose, pose3d, pred = model.forward_with_joints(T(pose2d).to(dev()), T(img_feat).to(dev()))
-    torch.cuda.synchronize()
+    try:
+        mesh, pose, pose3d, pred = model.forward_with_joints(T(pose2d).to(dev()), T(img_feat).to(dev()))
+        torch.cuda.synchronize()
+        eng = model._engine
+        inter = {key: buf.clone() for key, buf in (("g_mid", eng.intermediate("g", B, (B, 2048))), ("v1", eng.intermediate("VT1", B, (B, 431, 3))),
+                                                     ("v2", eng.intermediate("VT2", B, (B, 431, 3))), ("v3", eng.intermediate("VT0", B, (B, 431, 3))))}
+    finally:
+        model.set_gemm_mode(None)          # the cached model goes back to the library's defaults
     e = dict(mesh=maxabs(mesh, T(z["cam_mesh"])), pose=maxabs(pose, T(z["cam_pose"])),
              pose3d_mm=maxabs(pose3d, T(z["pose3d"])), pred_mm=maxabs(pred, T(z["pred_pose"])))
     print(name, {k: f"{v:.2e}" for k, v in e.items()})
-    eng = model._engine
-    for key, buf in (("g_mid", eng.intermediate("g", B, (B, 2048))), ("v1", eng.intermediate("VT1", B, (B, 431, 3))),
-                     ("v2", eng.intermediate("VT2", B, (B, 431, 3))), ("v3", eng.intermediate("VT0", B, (B, 431, 3)))):
+    for key, buf in inter.items():
         ei = maxabs(buf, T(z[key]))
         print(f"   intermediate {key}: {ei:.2e}")
         assert ei < TIGHT_M, key
@@ -329,6 +342,38 @@ def test_streaming_frame_reuse_other_configs(J, C):
     out = streaming.stream_forward_cached(model, cache, windows=win, batch=20, with_joints=True, lanes=2)
     e = [maxabs(a, b) for a, b in zip(out, ref)]
     assert e[0] < 1e-5 and e[1] < 1e-5 and e[2] < 1e-2 and e[3] < 1e-2, e
+
+
+@pytest.mark.parametrize("C", [256, 512])
+def test_gemm_modes(C):
+    """The two arithmetic modes of the large products on one batch: (1) they agree to fp32 rounding; (2) the three-product
+    f16 form is batch-invariant BITWISE (its k order does not depend on the tile shape the batch size selects); (3) small
+    batches of a split_f16 model take the fp32 pipe (identical to an f32-mode model) unless min_batch says otherwise."""
+    from pmce_amd import synth
+    J, B = 17, 64
+    model = get_model(J, C)
+    pose2d, img_feat = synth.make_inputs(B, J, 321)
+    p, f = T(pose2d).to(dev()), T(img_feat).to(dev())
+    try:
+        model.set_gemm_mode("f32")
+        assert model.gemm_mode() == "f32"
+        o32 = [t.clone() for t in model.forward_with_joints(p, f)]
+        o32_small = [t.clone() for t in model.forward_with_joints(p[:4], f[:4])]
+        model.set_gemm_mode("split_f16")
+        assert model.gemm_mode() == "split_f16"
+        osp = [t.clone() for t in model.forward_with_joints(p, f)]
+        osp_small = [t.clone() for t in model.forward_with_joints(p[:4], f[:4])]         # below min_batch: fp32 pipe
+        model.set_gemm_mode("split_f16", min_batch=1)
+        osp_forced = [t.clone() for t in model.forward_with_joints(p[:4], f[:4])]
+    finally:
+        model.set_gemm_mode(None)
+    e = [maxabs(a, b) for a, b in zip(o32, osp)]
+    print(f"C={C} f32 vs split_f16 at B=64: mesh {e[0]:.2e} m, pose {e[1]:.2e} m, pose3d {e[2]:.2e} mm, pred {e[3]:.2e} mm")
+    assert e[0] < TIGHT_M and e[1] < TIGHT_M and e[2] < TOL_MM and e[3] < 1000 * TIGHT_M
+    for a, b in zip(o32_small, osp_small):
+        assert torch.equal(a, b)
+    for a, b in zip(osp_forced, osp):
+        assert torch.equal(a, b[:4])
 
 
 @pytest.mark.parametrize("C", [256, 512])
