@@ -105,6 +105,9 @@ int pmce_stream_forward(pmce_model* m, const float* x0, const float* gi0, const 
 /* building blocks of the above */
 int pmce_window_tokens_f32(const float* x0, const int* win, const float* tpos, const float* w2, const float* b2, float eps2,
                            float* X, float* XN, int W, int L, int T, int J, int C, pmce_stream_t stream);
+/* XN written pre-split (see pmce_ln_chain_ex_f32). */
+int pmce_window_tokens_ex_f32(const float* x0, const int* win, const float* tpos, const float* w2, const float* b2, float eps2,
+                           float* X, float* XN, int W, int L, int T, int J, int C, int xn_split, pmce_stream_t stream);
 int pmce_window_rows_f32(const float* src, const int* win, float* dst, int W, int L, int T, int ncols, pmce_stream_t stream);
 
 /* enable != 0 (default): pmce_forward / pmce_decoder_forward run the image-feature branch (GRU, AdaLN parameters) and the
@@ -148,6 +151,11 @@ int pmce_gemm_set_tuning(int tile, int grid_per_cu);
 int pmce_gemm_pack_split_f16(const float* W, int N, int K, int ldw, float* Wp, float* wscale, pmce_stream_t stream);
 int pmce_gemm_nt_split_f16(const float* A, const float* Wp, const float* wscale, const float* bias, const float* R, float* C,
                            int M, int N, int K, long long lda, long long ldc, int act, int a_packed, pmce_stream_t stream);
+/* c_packed != 0 (packed A, GELU, no residual, N % 32 == 0): the result is written pre-split as well - it is the A operand of the
+ * next product (the lifter's fc1 -> fc2). */
+int pmce_gemm_nt_split_f16_ex(const float* A, const float* Wp, const float* wscale, const float* bias, const float* R, float* C,
+                              int M, int N, int K, long long lda, long long ldc, int act, int a_packed, int c_packed,
+                              pmce_stream_t stream);
 /* The same with mapped output rows: row r of C at C + (r % c_div)*c_lo + (r / c_div)*c_hi (the GRU layer-0 input projection
  * writes (b,t) rows time-major). */
 int pmce_gemm_nt_split_f16_rowmap(const float* A, const float* Wp, const float* wscale, const float* bias, float* C, int M, int N,
@@ -170,6 +178,13 @@ int pmce_embed_tokens_f32(const float* pose2d, const float* E, const float* Wje,
                           float* x, long long ntok, int J, int C, pmce_stream_t stream);
 /* nn.LayerNorm chain over rows of C channels: y1 = (w1 ? LN(x;w1,b1,eps1) : x) + add[(row/add_div)%add_mod];
  * out1 = y1 (optional); out2 = LN(y1;w2,b2,eps2) (optional).  norm1/norm2/norm_s/norm_t (PoseEstimation.py:17,23,58-59). */
+/* _ex forms: out2 / out / XN written pre-split ([row][C/16][16 hi | 16 lo*2^11] f16 in the bytes of the fp32 row), i.e. directly as
+ * the A operand of pmce_gemm_nt_split_f16_ex(a_packed = 1). */
+int pmce_ln_chain_ex_f32(const float* x, long long rows, int C, const float* w1, const float* b1, float eps1, const float* add,
+                         int add_div, int add_mod, float* out1, const float* w2, const float* b2, float eps2, float* out2,
+                         int out2_split, pmce_stream_t stream);
+int pmce_seq_attention_ex_f32(const float* qkv, float* out, int nseq, int N, int C, int seq_div, long long seq_lo,
+                              long long seq_hi, long long tok_stride, int out_split, pmce_stream_t stream);
 int pmce_ln_chain_f32(const float* x, long long rows, int C, const float* w1, const float* b1, float eps1,
                       const float* add, int add_div, int add_mod, float* out1, const float* w2, const float* b2,
                       float eps2, float* out2, pmce_stream_t stream);

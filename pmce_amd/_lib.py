@@ -34,6 +34,7 @@ PROTOTYPES = {
     "pmce_stream_precompute": [C.c_void_p, _f, _f, _i, _f, _f, _f, C.c_size_t, _s],
     "pmce_stream_forward": [C.c_void_p, _f, _f, _f, _i, _i, _f, _f, _f, _f, _f, C.c_size_t, _s],
     "pmce_window_tokens_f32": [_f, _f, _f, _f, _f, _fl, _f, _f, _i, _i, _i, _i, _i, _s],
+    "pmce_window_tokens_ex_f32": [_f, _f, _f, _f, _f, _fl, _f, _f, _i, _i, _i, _i, _i, _i, _s],
     "pmce_window_rows_f32": [_f, _f, _f, _i, _i, _i, _i, _s],
     "pmce_model_set_concurrency": [C.c_void_p, _i],
     "pmce_model_wait_lifter": [C.c_void_p, _s],
@@ -47,6 +48,9 @@ PROTOTYPES = {
     "pmce_gemm_pack_split_f16": [_f, _i, _i, _i, _f, _f, _s],
     "pmce_gemm_nt_split_f16": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _l, _l, _i, _i, _s],
     "pmce_split_rows_f16": [_f, _l, _i, _l, _f, _s],
+    "pmce_gemm_nt_split_f16_ex": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _l, _l, _i, _i, _i, _s],
+    "pmce_ln_chain_ex_f32": [_f, _l, _i, _f, _f, _fl, _f, _i, _i, _f, _f, _f, _fl, _f, _i, _s],
+    "pmce_seq_attention_ex_f32": [_f, _f, _i, _i, _i, _i, _l, _l, _l, _i, _s],
     "pmce_gemm_nt_split_f16_rowmap": [_f, _f, _f, _f, _f, _i, _i, _i, _l, _i, _l, _l, _s],
     "pmce_gemm_split_set_tuning": [_i],
     "pmce_dbg_victim": [_i, _f, _i, _i, _f, _s],

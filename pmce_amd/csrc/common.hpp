@@ -144,6 +144,21 @@ __device__ __forceinline__ void stage_weight(float* __restrict__ dst, const floa
   }
 }
 
+// Four consecutive channels c..c+3 (c % 4 == 0) of a row, written in the pre-split operand layout of the three-product f16 GEMM
+// (gemm_split_f16.hip): per 16-wide k-tile 16 f16 "hi" then 16 f16 "lo * 2^11".  `row` is the row's start (the packed row takes
+// the bytes of the fp32 row).
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store4_split_f16(float* __restrict__ row, int c, const f32x4& v) {
+  f16x4 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) hi[e] = (_Float16)v[e];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) lo[e] = (_Float16)((v[e] - (float)hi[e]) * 2048.0f);
+  _Float16* p = reinterpret_cast<_Float16*>(row) + (c >> 4) * 32 + (c & 15);
+  *reinterpret_cast<f16x4*>(p) = hi;
+  *reinterpret_cast<f16x4*>(p + 16) = lo;
+}
+
 // AdaLayerNorm on a slot-layout token (reference CoevoDecoder.py:23-29): unbiased std, eps on the std.
 // gb points at this clip's [gamma(64) | beta(64)] for the instance.
 __device__ __forceinline__ void adaln_slots(const float* x, float* y, const float* __restrict__ gb, int hb) {

@@ -74,12 +74,16 @@ template <int TM, int TN>
 struct SplitCfg {
   static constexpr int BM = 64 * TM, BN = 64 * TN;
   static constexpr int STAGE_FLOATS = (BM + BN) * 16;
+#ifdef PMCE_SPLIT_NS3
+  static constexpr int NS = 3;
+#else
   static constexpr int NS = STAGE_FLOATS * 4 * 4 <= 64 * 1024 ? 4 : 3;
+#endif
   static constexpr int LDS_BYTES = NS * STAGE_FLOATS * 4 + 2 * 1024;  // + two bias slices (this tile's, the next one's)
   static constexpr int DPW = (BM + BN) / 64;  // DMA instructions per wave per k-tile (16 rows each)
 };
 
-template <int TM, int TN, int ACT, bool RES, bool APACK>
+template <int TM, int TN, int ACT, bool RES, bool APACK, bool OPACK = false>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
   using Cfg = SplitCfg<TM, TN>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, WM = 32 * TM, WN = 32 * TN;
@@ -249,6 +253,41 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
     if (++kt == nk) {
       // ---- epilogue of the finished tile, straight from the accumulators ----
       kt = 0;
+      if constexpr (OPACK) {
+        // The result is itself the A operand of the next product (fc1 -> fc2): written pre-split, [row][K/16][16 hi | 16 lo*2^11]
+        // f16 in the bytes of the fp32 row.  A lane holds ONE column of 16 rows; adjacent lanes pair up (DPP quad_perm) so that
+        // every lane still stores one dword per element: even lanes {hi(n), hi(n+1)}, odd lanes {lo(n-1), lo(n)}.
+        const bool odd = lane & 1;
+        const int colf = (n0 >> 4) * 32 + (odd ? 16 + ((n0 - 1) & 15) : (n0 & 15));  // f16 index inside the 32-column group
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int cb = n_base + wn * WN + j * 32;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int mrow = m_base + wm * WM + i * 32 + 4 * hb;
+            _Float16* __restrict__ Cp = reinterpret_cast<_Float16*>(p.C) + (size_t)mrow * (2 * p.ldc) + 2 * cb + colf;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              f32x2 v = {acc[i][j][r] * w_down, acc[i][j][r + 1] * w_down};
+              if (ACT == 1) v = gelu_erf2(v);
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const float x = e ? v.y : v.x;
+                const _Float16 h = (_Float16)x;
+                const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
+                const unsigned w = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+                const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);  // lane ^ 1
+                const unsigned outw = odd ? ((nbr >> 16) | (w & 0xffff0000u)) : ((w & 0xffffu) | (nbr << 16));
+                const int rr = ((r + e) & 3) + 8 * ((r + e) >> 2);
+                if (mrow + rr < p.M) __builtin_nontemporal_store(outw, reinterpret_cast<unsigned*>(Cp + (size_t)rr * (2 * p.ldc)));
+              }
+            }
+          }
+        }
+        li += gx;
+        if (li < chunk_len) tile_coords(chunk_start + li, m_base, n_base);
+        continue;
+      }
       const bool full = (m_base + BM <= p.M) && (n_base + BN <= p.N) && p.c_div == 0;
       if (p.c_div > 0) {  // mapped rows (GRU layer-0 input projection: (b,t) rows -> time-major)
 #pragma unroll
@@ -286,18 +325,27 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
               f32x2 v = {acc[i][j][r] * w_down, acc[i][j][r + 1] * w_down};
               if (ACT == 1) v = gelu_erf2(v);
               if (RES) v += f32x2{rv[r], rv[r + 1]};
+#ifndef PMCE_SPLIT_PLAIN_STORES  // streaming stores measure 5-9 % faster than write-back ones here
               __builtin_nontemporal_store(v.x, Cp + ((r & 3) + 8 * (r >> 2)) * p.ldc);
               __builtin_nontemporal_store(v.y, Cp + (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * p.ldc);
+#else
+              Cp[((r & 3) + 8 * (r >> 2)) * p.ldc] = v.x;
+              Cp[(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * p.ldc] = v.y;
+#endif
             }
           } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int rr = (r & 3) + 8 * (r >> 2);
-              if (n < p.N && mrow + rr < p.M) {
-                float v = acc[i][j][r] * w_down;
-                if (ACT == 1) v = gelu_erf(v);
-                if (RES) v += Rp[rr * p.ldc];
-                Cp[rr * p.ldc] = v;
+            for (int r = 0; r < 16; r += 2) {  // the same arithmetic as the full-tile path (results do not depend on tile shape)
+              f32x2 v = {acc[i][j][r] * w_down, acc[i][j][r + 1] * w_down};
+              if (ACT == 1) v = gelu_erf2(v);
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const int rr = ((r + e) & 3) + 8 * ((r + e) >> 2);
+                if (n < p.N && mrow + rr < p.M) {
+                  float o = e ? v.y : v.x;
+                  if (RES) o += Rp[rr * p.ldc];
+                  Cp[rr * p.ldc] = o;
+                }
               }
             }
           }
@@ -321,17 +369,17 @@ extern "C" int pmce_gemm_split_set_tuning(int tile) {
   return PMCE_OK;
 }
 
-template <int TM, int TN, int ACT, bool RES, bool APACK>
+template <int TM, int TN, int ACT, bool RES, bool APACK, bool OPACK = false>
 static int launch_one(const SplitParams& p, int grid, hipStream_t stream) {
   using Cfg = SplitCfg<TM, TN>;
   static std::atomic<unsigned long long> done{0};
-  PMCE_TRY(pmce_opt_in_lds(reinterpret_cast<const void*>(&gemm_split_kernel<TM, TN, ACT, RES, APACK>), Cfg::LDS_BYTES, done,
+  PMCE_TRY(pmce_opt_in_lds(reinterpret_cast<const void*>(&gemm_split_kernel<TM, TN, ACT, RES, APACK, OPACK>), Cfg::LDS_BYTES, done,
                            "gemm_split_f16"));
-  hipLaunchKernelGGL((gemm_split_kernel<TM, TN, ACT, RES, APACK>), dim3(grid), dim3(256), Cfg::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm_split_kernel<TM, TN, ACT, RES, APACK, OPACK>), dim3(grid), dim3(256), Cfg::LDS_BYTES, stream, p);
   return PMCE_OK;
 }
 template <int TM, int TN>
-static int launch_cfg(SplitParams& p, int act, bool apack, hipStream_t stream) {
+static int launch_cfg(SplitParams& p, int act, bool apack, bool opack, hipStream_t stream) {
   using Cfg = SplitCfg<TM, TN>;
   p.ntm = (p.M + Cfg::BM - 1) / Cfg::BM;
   p.ntn = (p.N + Cfg::BN - 1) / Cfg::BN;
@@ -340,6 +388,7 @@ static int launch_cfg(SplitParams& p, int act, bool apack, hipStream_t stream) {
   if (g > 256 * per_cu) g = 256 * per_cu;
   g = (g + 7) & ~7;
   const bool res = p.R != nullptr;
+  if (opack) return launch_one<TM, TN, 1, false, true, true>(p, g, stream);  // fc1 of the lifter: GELU, packed in, packed out
   if (apack) {
     if (act == 1) return res ? launch_one<TM, TN, 1, true, true>(p, g, stream) : launch_one<TM, TN, 1, false, true>(p, g, stream);
     return res ? launch_one<TM, TN, 0, true, true>(p, g, stream) : launch_one<TM, TN, 0, false, true>(p, g, stream);
@@ -369,8 +418,8 @@ static int pick_split_tile(int M, int N) {
 }
 
 static int gemm_split_any(const float* A, const float* Wp, const float* wscale, const float* bias, const float* R, float* C, int M,
-                          int N, int K, long long lda, long long ldc, int act, int a_packed, int c_div, long long c_lo,
-                          long long c_hi, hipStream_t stream) {
+                          int N, int K, long long lda, long long ldc, int act, int a_packed, int c_packed, int c_div,
+                          long long c_lo, long long c_hi, hipStream_t stream) {
   PMCE_REQUIRE(A && Wp && wscale && C, "gemm_split: null pointer");
   PMCE_REQUIRE(M > 0 && N > 0 && K >= 32 && K % 16 == 0, "gemm_split: need M,N>0, K>=32 and K%%16==0 (got M=%d N=%d K=%d)", M, N, K);
   PMCE_REQUIRE(act == 0 || act == 1, "gemm_split: act must be 0 or 1");
@@ -379,6 +428,8 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
   PMCE_REQUIRE((long long)M * lda * 4 < (1ll << 32) && (long long)N * K * 4 < (1ll << 32) && (long long)M * ldc < (1ll << 32),
                "gemm_split: an operand spans 4 GiB or more (split the batch)");
   PMCE_REQUIRE(c_div == 0 || R == nullptr, "gemm_split: a C row map cannot be combined with a residual");
+  PMCE_REQUIRE(!c_packed || (a_packed && act == 1 && R == nullptr && c_div == 0 && N % 32 == 0 && ldc == N),
+               "gemm_split: a packed result is supported for the packed-A + GELU form with N %% 32 == 0 and ldc == N");
   SplitParams p;
   p.A = A; p.W = Wp; p.wscale = wscale; p.bias = bias; p.R = R; p.C = C;
   p.M = M; p.N = N; p.K = K; p.lda = (unsigned)lda; p.ldc = (unsigned)ldc;
@@ -388,9 +439,9 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
     p.skew = knob >= 0 ? knob : (K / 16) * 12 * 32 / 4096 + 1;
   }
   switch (pick_split_tile(M, N)) {
-    case 0: PMCE_TRY((launch_cfg<2, 4>(p, act, a_packed != 0, stream))); break;
-    case 1: PMCE_TRY((launch_cfg<2, 2>(p, act, a_packed != 0, stream))); break;
-    default: PMCE_TRY((launch_cfg<1, 2>(p, act, a_packed != 0, stream))); break;
+    case 0: PMCE_TRY((launch_cfg<2, 4>(p, act, a_packed != 0, c_packed != 0, stream))); break;
+    case 1: PMCE_TRY((launch_cfg<2, 2>(p, act, a_packed != 0, c_packed != 0, stream))); break;
+    default: PMCE_TRY((launch_cfg<1, 2>(p, act, a_packed != 0, c_packed != 0, stream))); break;
   }
   return pmce_check_launch("gemm_nt_split_f16");
 }
@@ -398,13 +449,18 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
 extern "C" int pmce_gemm_nt_split_f16(const float* A, const float* Wp, const float* wscale, const float* bias, const float* R,
                                       float* C, int M, int N, int K, long long lda, long long ldc, int act, int a_packed,
                                       hipStream_t stream) {
-  return gemm_split_any(A, Wp, wscale, bias, R, C, M, N, K, lda, ldc, act, a_packed, 0, 0, 0, stream);
+  return gemm_split_any(A, Wp, wscale, bias, R, C, M, N, K, lda, ldc, act, a_packed, 0, 0, 0, 0, stream);
+}
+extern "C" int pmce_gemm_nt_split_f16_ex(const float* A, const float* Wp, const float* wscale, const float* bias, const float* R,
+                                         float* C, int M, int N, int K, long long lda, long long ldc, int act, int a_packed,
+                                         int c_packed, hipStream_t stream) {
+  return gemm_split_any(A, Wp, wscale, bias, R, C, M, N, K, lda, ldc, act, a_packed, c_packed, 0, 0, 0, stream);
 }
 extern "C" int pmce_gemm_nt_split_f16_rowmap(const float* A, const float* Wp, const float* wscale, const float* bias, float* C,
                                              int M, int N, int K, long long lda, int c_div, long long c_lo, long long c_hi,
                                              hipStream_t stream) {
   PMCE_REQUIRE(c_div > 0, "gemm_split_rowmap: c_div must be positive");
-  return gemm_split_any(A, Wp, wscale, bias, nullptr, C, M, N, K, lda, N, 0, 0, c_div, c_lo, c_hi, stream);
+  return gemm_split_any(A, Wp, wscale, bias, nullptr, C, M, N, K, lda, N, 0, 0, 0, c_div, c_lo, c_hi, stream);
 }
 
 // ---- operand packing ------------------------------------------------------------------------------------------------------

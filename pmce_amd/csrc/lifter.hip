@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__
                                                        float eps1, const float* __restrict__ add, int add_div, int add_mod,
                                                        float* __restrict__ out1, const float* __restrict__ w2,
                                                        const float* __restrict__ b2, float eps2, float* __restrict__ out2,
-                                                       const int* __restrict__ win, int nframes) {
+                                                       const int* __restrict__ win, int nframes, int out2_split) {
   constexpr int NV = C / 64;
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__
       f32x4 t;
 #pragma unroll
       for (int i = 0; i < 4; ++i) t[i] = v[i4 * 4 + i];
-      *reinterpret_cast<f32x4*>(out2 + row * C + i4 * 256 + lane * 4) = t;
+      if (out2_split) store4_split_f16(out2 + row * C, i4 * 256 + lane * 4, t);  // operand of a three-product f16 GEMM
+      else *reinterpret_cast<f32x4*>(out2 + row * C + i4 * 256 + lane * 4) = t;
     }
   }
 }
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__
 template <int HD>
 __global__ __launch_bounds__(256) void seq_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N,
                                                             int seq_div, long long seq_lo, long long seq_hi,
-                                                            long long tok_stride) {
+                                                            long long tok_stride, int out_split) {
   constexpr int C = HD * 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;
@@ -192,13 +193,14 @@ __global__ __launch_bounds__(256) void seq_attention_kernel(const float* __restr
     m = mn;
   }
   const float inv = 1.0f / l;
-  float* dst = out + (base + i * tok_stride) * C + head * HD;
+  float* dst = out + (base + i * tok_stride) * C;
 #pragma unroll
   for (int d4 = 0; d4 < HD / 4; ++d4) {
     f32x4 t;
 #pragma unroll
     for (int k = 0; k < 4; ++k) t[k] = o[4 * d4 + k] * inv;
-    *reinterpret_cast<f32x4*>(dst + 4 * d4) = t;
+    if (out_split) store4_split_f16(dst, head * HD + 4 * d4, t);  // operand of a three-product f16 GEMM
+    else *reinterpret_cast<f32x4*>(dst + head * HD + 4 * d4) = t;
   }
 }
 
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256) void seq_attention_kernel(const float* __restr
 // when the region changes hands.  Used at C = 512 (HD = 64): 151 / 139 us per spatial / temporal launch against 195 /
 // 179 us (B = 256); at C = 256 the first kernel already runs 16 waves per CU and both sit at ~4 TB/s, so it stays.
 // ------------------------------------------------------------------------------------------------------
-template <int HD, int N>
+template <int HD, int N, bool OUT_SPLIT>
 __global__ __launch_bounds__(128, 2) void seq_attention_pair_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                  int seq_div, long long seq_lo, long long seq_hi,
                                                                  long long tok_stride) {
@@ -375,9 +377,12 @@ __global__ __launch_bounds__(128, 2) void seq_attention_pair_kernel(const float*
 #pragma unroll
   for (int u = 0; u < NIT; ++u) {
     const int idx = tid + 128 * u;
-    if (idx < CNT)
-      *reinterpret_cast<f32x4*>(out + (base + (idx / C4) * tok_stride) * C + 4 * (idx % C4)) =
-          *reinterpret_cast<const f32x4*>(R + lds_off(u));
+    if (idx < CNT) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(R + lds_off(u));
+      float* row = out + (base + (idx / C4) * tok_stride) * C;
+      if constexpr (OUT_SPLIT) store4_split_f16(row, 4 * (idx % C4), t);
+      else *reinterpret_cast<f32x4*>(row + 4 * (idx % C4)) = t;
+    }
   }
 }
 
@@ -449,9 +454,9 @@ extern "C" int pmce_embed_tokens_f32(const float* pose2d, const float* E, const 
   return pmce_check_launch("embed_tokens");
 }
 
-extern "C" int pmce_ln_chain_f32(const float* x, long long rows, int C, const float* w1, const float* b1, float eps1,
-                                 const float* add, int add_div, int add_mod, float* out1, const float* w2, const float* b2,
-                                 float eps2, float* out2, hipStream_t stream) {
+extern "C" int pmce_ln_chain_ex_f32(const float* x, long long rows, int C, const float* w1, const float* b1, float eps1,
+                                    const float* add, int add_div, int add_mod, float* out1, const float* w2, const float* b2,
+                                    float eps2, float* out2, int out2_split, hipStream_t stream) {
   PMCE_REQUIRE(C == 256 || C == 512, "ln_chain: C must be 256 or 512 (got %d)", C);
   PMCE_REQUIRE(rows > 0 && (out1 || out2), "ln_chain: nothing to do");
   PMCE_REQUIRE(!out2 || (w2 && b2), "ln_chain: out2 needs w2/b2");
@@ -460,29 +465,39 @@ extern "C" int pmce_ln_chain_f32(const float* x, long long rows, int C, const fl
   const unsigned grid = (unsigned)((rows + 3) / 4);
   if (C == 256)
     hipLaunchKernelGGL((ln_chain_kernel<256>), dim3(grid), dim3(256), 0, stream, x, rows, w1, b1, eps1, add, add_div, add_mod,
-                       out1, w2, b2, eps2, out2, nullptr, 0);
+                       out1, w2, b2, eps2, out2, nullptr, 0, out2_split);
   else
     hipLaunchKernelGGL((ln_chain_kernel<512>), dim3(grid), dim3(256), 0, stream, x, rows, w1, b1, eps1, add, add_div, add_mod,
-                       out1, w2, b2, eps2, out2, nullptr, 0);
+                       out1, w2, b2, eps2, out2, nullptr, 0, out2_split);
   return pmce_check_launch("ln_chain");
+}
+extern "C" int pmce_ln_chain_f32(const float* x, long long rows, int C, const float* w1, const float* b1, float eps1,
+                                 const float* add, int add_div, int add_mod, float* out1, const float* w2, const float* b2,
+                                 float eps2, float* out2, hipStream_t stream) {
+  return pmce_ln_chain_ex_f32(x, rows, C, w1, b1, eps1, add, add_div, add_mod, out1, w2, b2, eps2, out2, 0, stream);
 }
 
 // Streaming: tokens of W windows from the per-frame table x0[L,J,C] (= norm_s(SpatialBlocks[0](embed)), window-independent):
 //   X[w,t,j,:] = x0[frame(w,t),j,:] + tpos[t,:]  (PoseEstimation.py:87-88) ;  XN = LN(X; w2,b2,eps2)  (TemporalBlocks[0].norm1)
-extern "C" int pmce_window_tokens_f32(const float* x0, const int* win, const float* tpos, const float* w2, const float* b2,
-                                      float eps2, float* X, float* XN, int W, int L, int T, int J, int C,
-                                      hipStream_t stream) {
+extern "C" int pmce_window_tokens_ex_f32(const float* x0, const int* win, const float* tpos, const float* w2, const float* b2,
+                                         float eps2, float* X, float* XN, int W, int L, int T, int J, int C, int xn_split,
+                                         hipStream_t stream) {
   PMCE_REQUIRE(C == 256 || C == 512, "window_tokens: C must be 256 or 512");
   PMCE_REQUIRE(x0 && win && tpos && w2 && b2 && X && XN && W > 0 && L > 0 && T > 0 && J > 0, "window_tokens: bad args");
   const long long rows = (long long)W * T * J;
   const unsigned grid = (unsigned)((rows + 3) / 4);
   if (C == 256)
     hipLaunchKernelGGL((ln_chain_kernel<256>), dim3(grid), dim3(256), 0, stream, x0, rows, nullptr, nullptr, 0.f, tpos, J, T, X,
-                       w2, b2, eps2, XN, win, L);
+                       w2, b2, eps2, XN, win, L, xn_split);
   else
     hipLaunchKernelGGL((ln_chain_kernel<512>), dim3(grid), dim3(256), 0, stream, x0, rows, nullptr, nullptr, 0.f, tpos, J, T, X,
-                       w2, b2, eps2, XN, win, L);
+                       w2, b2, eps2, XN, win, L, xn_split);
   return pmce_check_launch("window_tokens");
+}
+extern "C" int pmce_window_tokens_f32(const float* x0, const int* win, const float* tpos, const float* w2, const float* b2,
+                                      float eps2, float* X, float* XN, int W, int L, int T, int J, int C,
+                                      hipStream_t stream) {
+  return pmce_window_tokens_ex_f32(x0, win, tpos, w2, b2, eps2, X, XN, W, L, T, J, C, 0, stream);
 }
 
 // Streaming: time-major gather of per-frame rows:  dst[t][w][:] = src[frame(w,t)][:]   (ncols % 4 == 0)
@@ -506,19 +521,24 @@ extern "C" int pmce_window_rows_f32(const float* src, const int* win, float* dst
 
 template <int HD, int N>
 static int launch_seq_attention_pair(const float* qkv, float* out, int nseq, int seq_div, long long seq_lo, long long seq_hi,
-                                     long long tok_stride, hipStream_t stream) {
+                                     long long tok_stride, int out_split, hipStream_t stream) {
   constexpr int lds = N * 8 * (HD + 4) * (int)sizeof(float);
   if (lds > 65536) {
-    static std::atomic<unsigned long long> attr{0};
-    PMCE_TRY(pmce_opt_in_lds((const void*)seq_attention_pair_kernel<HD, N>, lds, attr, "seq_attention"));
+    static std::atomic<unsigned long long> attr{0}, attr_s{0};
+    PMCE_TRY(pmce_opt_in_lds((const void*)seq_attention_pair_kernel<HD, N, false>, lds, attr, "seq_attention"));
+    PMCE_TRY(pmce_opt_in_lds((const void*)seq_attention_pair_kernel<HD, N, true>, lds, attr_s, "seq_attention"));
   }
-  hipLaunchKernelGGL((seq_attention_pair_kernel<HD, N>), dim3(nseq), dim3(128), lds, stream, qkv, out, seq_div, seq_lo,
-                     seq_hi, tok_stride);
+  if (out_split)
+    hipLaunchKernelGGL((seq_attention_pair_kernel<HD, N, true>), dim3(nseq), dim3(128), lds, stream, qkv, out, seq_div, seq_lo,
+                       seq_hi, tok_stride);
+  else
+    hipLaunchKernelGGL((seq_attention_pair_kernel<HD, N, false>), dim3(nseq), dim3(128), lds, stream, qkv, out, seq_div, seq_lo,
+                       seq_hi, tok_stride);
   return pmce_check_launch("seq_attention");
 }
 
-extern "C" int pmce_seq_attention_f32(const float* qkv, float* out, int nseq, int N, int C, int seq_div, long long seq_lo,
-                                      long long seq_hi, long long tok_stride, hipStream_t stream) {
+extern "C" int pmce_seq_attention_ex_f32(const float* qkv, float* out, int nseq, int N, int C, int seq_div, long long seq_lo,
+                                         long long seq_hi, long long tok_stride, int out_split, hipStream_t stream) {
   PMCE_REQUIRE(C == 256 || C == 512, "seq_attention: C must be 256 or 512 (8 heads of 32/64)");
   PMCE_REQUIRE(N >= 1 && N <= 32 && nseq > 0, "seq_attention: N must be in 1..32 (got %d)", N);
   if (seq_div <= 0) seq_div = 0x7fffffff;
@@ -526,7 +546,7 @@ extern "C" int pmce_seq_attention_f32(const float* qkv, float* out, int nseq, in
   if (!force_v1) {  // the sequence lengths of the path: 16 frames, 17 (H36M) or 19 (COCO + pelvis, neck) joints
     // C = 512 only: at C = 256 both kernels sit at the same ~4 TB/s (the first one already has 16 waves per CU there)
 #define PMCE_PAIR(HD_, N_) \
-  if (C == 8 * HD_ && N == N_) return launch_seq_attention_pair<HD_, N_>(qkv, out, nseq, seq_div, seq_lo, seq_hi, tok_stride, stream)
+  if (C == 8 * HD_ && N == N_) return launch_seq_attention_pair<HD_, N_>(qkv, out, nseq, seq_div, seq_lo, seq_hi, tok_stride, out_split, stream)
     PMCE_PAIR(64, 16);
     PMCE_PAIR(64, 17);
     PMCE_PAIR(64, 19);
@@ -537,14 +557,18 @@ extern "C" int pmce_seq_attention_f32(const float* qkv, float* out, int nseq, in
     static std::atomic<unsigned long long> attr256{0};
     PMCE_TRY(pmce_opt_in_lds((const void*)seq_attention_kernel<32>, 65536, attr256, "seq_attention"));
     hipLaunchKernelGGL((seq_attention_kernel<32>), dim3(nseq), dim3(256), lds, stream, qkv, out, N, seq_div, seq_lo, seq_hi,
-                       tok_stride);
+                       tok_stride, out_split);
   } else {
     static std::atomic<unsigned long long> attr512{0};
     PMCE_TRY(pmce_opt_in_lds((const void*)seq_attention_kernel<64>, 131072, attr512, "seq_attention"));
     hipLaunchKernelGGL((seq_attention_kernel<64>), dim3(nseq), dim3(256), lds, stream, qkv, out, N, seq_div, seq_lo, seq_hi,
-                       tok_stride);
+                       tok_stride, out_split);
   }
   return pmce_check_launch("seq_attention");
+}
+extern "C" int pmce_seq_attention_f32(const float* qkv, float* out, int nseq, int N, int C, int seq_div, long long seq_lo,
+                                      long long seq_hi, long long tok_stride, hipStream_t stream) {
+  return pmce_seq_attention_ex_f32(qkv, out, nseq, N, C, seq_div, seq_lo, seq_hi, tok_stride, 0, stream);
 }
 
 extern "C" int pmce_lifter_head_f32(const float* x, const float* lnw, const float* lnb, const float* Wr, const float* br,

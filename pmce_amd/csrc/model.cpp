@@ -334,10 +334,15 @@ int gemm(const float* A, const float* W, const float* bias, const float* R, floa
 }
 // a large product: the f16 three-product form when the model carries the packed weight, the fp32 pipe otherwise
 int lgemm(const pmce_model* m, const float* A, const float* W, const SplitW& sw, const float* bias, const float* R, float* Cc,
-          int M, int N, int K, long long lda, long long ldc, int act, hipStream_t s) {
-  if (m->split_now && sw.wp) return pmce_gemm_nt_split_f16(A, sw.wp, sw.scale, bias, R, Cc, M, N, K, lda, ldc, act, 0, s);
+          int M, int N, int K, long long lda, long long ldc, int act, hipStream_t s, int a_packed = 0, int c_packed = 0) {
+  if (m->split_now && sw.wp)
+    return pmce_gemm_nt_split_f16_ex(A, sw.wp, sw.scale, bias, R, Cc, M, N, K, lda, ldc, act, a_packed, c_packed, s);
+  PMCE_REQUIRE(!a_packed && !c_packed, "lgemm: pre-split operands need the split-f16 form");
   return gemm(A, W, bias, R, Cc, M, N, K, lda, ldc, act, s);
 }
+// In the split-f16 form the producers of the lifter blocks' GEMM operands (LayerNorm -> XN, attention -> AO, fc1 -> Hid) write
+// them pre-split (hi | lo*2^11 f16 planes in the bytes of the fp32 row): the products then spend no vector work on splitting.
+inline int pk(const pmce_model* m) { return m->split_now ? 1 : 0; }
 
 // ---- GraphormerNet.forward --------------------------------------------------------------------------------
 // Everything up to and including SpatialBlocks[0] is PER FRAME (its attention runs over the J joints of one frame,
@@ -349,20 +354,20 @@ int lifter_block_body(pmce_model* m, int kind, int i, long long M, int nframes, 
   const LifterBlockW& bw = m->w.blk[kind][i];
   const LifterBlockSplit& sw = m->sblk[kind][i];
   RUN(P_GEMM_LIFTER, lgemm(m, w.XN, bw.qkv_w, sw.qkv, bw.qkv_b, nullptr, w.QKV,
-                          (int)M, 3 * C, C, C, 3 * C, 0, stream));
+                          (int)M, 3 * C, C, C, 3 * C, 0, stream, pk(m)));
   if (kind == 0)  // sequences = frames, tokens j contiguous                        (PoseEstimation.py:78,101)
-    RUN(P_SEQ_ATTN, pmce_seq_attention_f32(w.QKV, w.AO, nframes, J, C, 0, J, 0, 1, stream));
+    RUN(P_SEQ_ATTN, pmce_seq_attention_ex_f32(w.QKV, w.AO, nframes, J, C, 0, J, 0, 1, pk(m), stream));
   else  // sequences = (b,j), tokens t at stride J                                  (PoseEstimation.py:87,104)
-    RUN(P_SEQ_ATTN, pmce_seq_attention_f32(w.QKV, w.AO, B * J, T, C, J, 1, (long long)T * J, J, stream));
+    RUN(P_SEQ_ATTN, pmce_seq_attention_ex_f32(w.QKV, w.AO, B * J, T, C, J, 1, (long long)T * J, J, pk(m), stream));
   RUN(P_GEMM_LIFTER, lgemm(m, w.AO, bw.proj_w, sw.proj, bw.proj_b, w.X, w.X, (int)M, C,
-                          C, C, C, 0, stream));
-  RUN(P_LN, pmce_ln_chain_f32(w.X, M, C, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, bw.norm2_w,
-                              bw.norm2_b, 1e-6f, w.XN, stream));
+                          C, C, C, 0, stream, pk(m)));
+  RUN(P_LN, pmce_ln_chain_ex_f32(w.X, M, C, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, bw.norm2_w,
+                                 bw.norm2_b, 1e-6f, w.XN, pk(m), stream));
   float* Hid = w.QKV;
   RUN(P_GEMM_LIFTER, lgemm(m, w.XN, bw.fc1_w, sw.fc1, bw.fc1_b, nullptr, Hid, (int)M,
-                          2 * C, C, C, 2 * C, 1, stream));
+                          2 * C, C, C, 2 * C, 1, stream, pk(m), pk(m)));
   RUN(P_GEMM_LIFTER, lgemm(m, Hid, bw.fc2_w, sw.fc2, bw.fc2_b, w.X, w.X, (int)M, C,
-                          2 * C, 2 * C, C, 0, stream));
+                          2 * C, 2 * C, C, 0, stream, pk(m)));
   return PMCE_OK;
 }
 
@@ -375,9 +380,9 @@ int lifter_frames(pmce_model* m, const float* pose2d, const float* img_feat, int
                           nframes, C, F, F, C, 0, stream));
   RUN(P_EMBED, pmce_embed_tokens_f32(pose2d, w.E, m->w.je_w, m->w.je_b,
                                      m->w.spos, w.X, M, J, C, stream));
-  RUN(P_LN, pmce_ln_chain_f32(w.X, M, C, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr,
-                              m->w.blk[0][0].norm1_w, m->w.blk[0][0].norm1_b, 1e-6f, w.XN,
-                              stream));
+  RUN(P_LN, pmce_ln_chain_ex_f32(w.X, M, C, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr,
+                                 m->w.blk[0][0].norm1_w, m->w.blk[0][0].norm1_b, 1e-6f, w.XN, pk(m),
+                                 stream));
   return lifter_block_body(m, 0, 0, M, nframes, 0, w, stream);
 }
 
@@ -396,7 +401,7 @@ int lifter_post_norm(pmce_model* m, int kind, int i, long long M, LifterWs& w, h
     w2 = m->w.blk[0][i + 1].norm1_w;
     b2 = m->w.blk[0][i + 1].norm1_b;
   }
-  RUN(P_LN, pmce_ln_chain_f32(w.X, M, C, nw, nb, 1e-6f, add, J, T, w.X, w2, b2, 1e-6f, w2 ? w.XN : nullptr, stream));
+  RUN(P_LN, pmce_ln_chain_ex_f32(w.X, M, C, nw, nb, 1e-6f, add, J, T, w.X, w2, b2, 1e-6f, w2 ? w.XN : nullptr, pk(m), stream));
   return PMCE_OK;
 }
 
@@ -991,8 +996,8 @@ static int stream_forward_impl(pmce_model* m, const float* x0, const float* gi0,
   }
   PMCE_TRY(gru_rest(m, W, dw, gs));
   if (!single) PMCE_TRY(ev_record(m->ev_join, m->side, "stream_forward join"));
-  RUN(P_LN, pmce_window_tokens_f32(x0, win, m->w.tpos, m->w.blk[1][0].norm1_w, m->w.blk[1][0].norm1_b, 1e-6f, lw.X, lw.XN, W, L,
-                                   T, m->J, m->C, stream));
+  RUN(P_LN, pmce_window_tokens_ex_f32(x0, win, m->w.tpos, m->w.blk[1][0].norm1_w, m->w.blk[1][0].norm1_b, 1e-6f, lw.X, lw.XN, W, L,
+                                   T, m->J, m->C, pk(m), stream));
   PMCE_TRY(lifter_rest(m, pose3d, W, lw, stream));
   RUN(P_MISC, pmce_div_scalar_f32(pose3d, dw.JM, (long long)W * m->J * 3, 1000.0f, stream));
   PMCE_TRY(mark_lifter_done(m, stream));

@@ -56,7 +56,7 @@ def split_rows_f16(A):
     return Ap
 
 
-def gemm_nt_split(A, Wp, wscale, bias=None, residual=None, act=0, out=None, a_packed=False):
+def gemm_nt_split(A, Wp, wscale, bias=None, residual=None, act=0, out=None, a_packed=False, c_packed=False):
     """gemm_nt on the f16 matrix pipe (three-product split, fp32 accumulate): fp32 in, fp32 out, fp32 accuracy."""
     lib = _lib.load()
     A = _c(A)
@@ -64,28 +64,29 @@ def gemm_nt_split(A, Wp, wscale, bias=None, residual=None, act=0, out=None, a_pa
     N = Wp.shape[0]
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32)
-    _lib.check(lib.pmce_gemm_nt_split_f16(P(A), P(Wp), P(wscale), P(bias), P(residual), P(out), M, N, K, K, N, act,
-                                          1 if a_packed else 0, _st()), "gemm_nt_split")
+    _lib.check(lib.pmce_gemm_nt_split_f16_ex(P(A), P(Wp), P(wscale), P(bias), P(residual), P(out), M, N, K, K, N, act,
+                                             1 if a_packed else 0, 1 if c_packed else 0, _st()), "gemm_nt_split")
     return out
 
 
-def ln_chain(x, w1=None, b1=None, eps1=1e-6, add=None, add_div=1, add_mod=1, want_out1=True, w2=None, b2=None, eps2=1e-6):
+def ln_chain(x, w1=None, b1=None, eps1=1e-6, add=None, add_div=1, add_mod=1, want_out1=True, w2=None, b2=None, eps2=1e-6,
+             out2_split=False):
     lib = _lib.load()
     x = _c(x)
     rows, Cc = x.shape
     out1 = torch.empty_like(x) if want_out1 else None
     out2 = torch.empty_like(x) if w2 is not None else None
-    _lib.check(lib.pmce_ln_chain_f32(P(x), rows, Cc, P(w1), P(b1), eps1, P(add), add_div, add_mod, P(out1), P(w2), P(b2), eps2,
-                                     P(out2), _st()), "ln_chain")
+    _lib.check(lib.pmce_ln_chain_ex_f32(P(x), rows, Cc, P(w1), P(b1), eps1, P(add), add_div, add_mod, P(out1), P(w2), P(b2), eps2,
+                                        P(out2), 1 if out2_split else 0, _st()), "ln_chain")
     return out1, out2
 
 
-def seq_attention(qkv, nseq, N, Cc, seq_div, seq_lo, seq_hi, tok_stride):
+def seq_attention(qkv, nseq, N, Cc, seq_div, seq_lo, seq_hi, tok_stride, out_split=False):
     lib = _lib.load()
     qkv = _c(qkv)
     out = torch.empty(qkv.shape[0], Cc, device=qkv.device, dtype=torch.float32)
-    _lib.check(lib.pmce_seq_attention_f32(P(qkv), P(out), nseq, N, Cc, seq_div, seq_lo, seq_hi, tok_stride, _st()),
-               "seq_attention")
+    _lib.check(lib.pmce_seq_attention_ex_f32(P(qkv), P(out), nseq, N, Cc, seq_div, seq_lo, seq_hi, tok_stride,
+                                             1 if out_split else 0, _st()), "seq_attention")
     return out
 
 

@@ -122,6 +122,29 @@ def test_gemm_nt_split(M, N, K, act, res, tile):
     assert e < 2e-5 and e <= 1.5 * e32 + 1e-7
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(4352, 512, 256), (1000, 1024, 512), (69650, 1024, 512)])
+def test_gemm_split_packed_result(M, N, K, tile):
+    """fc1 of the lifter in the split-f16 form: packed A in, GELU, result written pre-split (it is fc2's A operand) - the same
+    bits as splitting the fp32 result of the same product afterwards."""
+    from pmce_amd import _lib, ops
+    if M > 20000 and tile != 0:
+        pytest.skip("forced small tiles at the largest size add nothing")
+    lib = _lib.load()
+    A = rnd("gemm.A", (M, K)).to(dev())
+    W = rnd("gemm.W", (N, K), scale=K ** -0.5).to(dev())
+    b = rnd("gemm.b", (N,)).to(dev())
+    Wp, ws = ops.pack_split_f16(W)
+    Ap = ops.split_rows_f16(A)
+    lib.pmce_gemm_split_set_tuning(tile)
+    try:
+        plain = ops.gemm_nt_split(Ap, Wp, ws, b, None, 1, a_packed=True)
+        packed = ops.gemm_nt_split(Ap, Wp, ws, b, None, 1, a_packed=True, c_packed=True)
+    finally:
+        lib.pmce_gemm_split_set_tuning(-1)
+    assert torch.equal(packed.view(torch.int32), ops.split_rows_f16(plain).view(torch.int32))
+
+
 def test_gemm_split_row_map():
     """GI0 form on the f16 pipe: A rows (b,t) -> C rows (t,b)."""
     from pmce_amd import _lib, ops
@@ -176,6 +199,9 @@ def test_ln_chain(C):
     assert maxabs(o1, r1) < 5e-6 and maxabs(o2, r2) < 5e-6
     _, o3 = ops.ln_chain(x, None, None, 0.0, None, 1, 1, False, w2, b2, 1e-6)
     assert maxabs(o3, F.layer_norm(x.double(), (C,), w2.double(), b2.double(), 1e-6)) < 5e-6
+    # out2 written pre-split for the three-product f16 GEMM: the same bits as splitting the fp32 output afterwards
+    _, o2p = ops.ln_chain(x, w1, b1, 1e-6, add, J, Tn, True, w2, b2, 1e-5, out2_split=True)
+    assert torch.equal(o2p.view(torch.int32), ops.split_rows_f16(o2).view(torch.int32))
 
 
 @pytest.mark.parametrize("C,J", [(256, 17), (256, 19), (512, 17), (512, 19)])
@@ -200,6 +226,11 @@ def test_seq_attention(C, J):
     es, et = maxabs(out_s, ref("s")), maxabs(out_t, ref("t"))
     print(f"seq_attention C={C} J={J}: spatial {es:.2e} temporal {et:.2e}")
     assert es < 5e-6 and et < 5e-6
+    # pre-split output (operand of the proj product in the split-f16 form): the bits of the fp32 output, split
+    ps = ops.seq_attention(qkv, B * Tn, J, C, 0, J, 0, 1, out_split=True)
+    pt = ops.seq_attention(qkv, B * J, Tn, C, J, 1, Tn * J, J, out_split=True)
+    assert torch.equal(ps.view(torch.int32), ops.split_rows_f16(out_s).view(torch.int32))
+    assert torch.equal(pt.view(torch.int32), ops.split_rows_f16(out_t).view(torch.int32))
 
 
 def test_vertex_init_gather_bit_exact(golden):
