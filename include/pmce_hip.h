@@ -201,6 +201,11 @@ int pmce_lifter_head_f32(const float* x, const float* lnw, const float* lnb, con
 int pmce_gru_step_f32(const float* gi0, const float* gi1, const float* whh0, const float* whh1, const float* bhh0,
                       const float* bhh1, const float* hp0, const float* hp1, float* ho0, float* ho1, long long gi_rs,
                       long long h_rs, int B, int H, int ndir, pmce_stream_t stream);
+/* The same step with gh = h W_hh^T in the three-product f16 form (pmce_gemm_nt_split_f16's arithmetic): whh0p / whh1p are rows of
+ * ONE weight packed by pmce_gemm_pack_split_f16 (K = H), wscale its scale pair. */
+int pmce_gru_step_split_f32(const float* gi0, const float* gi1, const float* whh0p, const float* whh1p, const float* wscale,
+                            const float* bhh0, const float* bhh1, const float* hp0, const float* hp1, float* ho0, float* ho1,
+                            long long gi_rs, long long h_rs, int B, int H, int ndir, pmce_stream_t stream);
 /* y = x / denom (PMCE.py:18). */
 int pmce_div_scalar_f32(const float* x, float* y, long long n, float denom, pmce_stream_t stream);
 

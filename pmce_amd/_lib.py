@@ -61,6 +61,7 @@ PROTOTYPES = {
     "pmce_seq_attention_f32": [_f, _f, _i, _i, _i, _i, _l, _l, _l, _s],
     "pmce_lifter_head_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _s],
     "pmce_gru_step_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _l, _l, _i, _i, _i, _s],
+    "pmce_gru_step_split_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _l, _l, _i, _i, _i, _s],
     "pmce_div_scalar_f32": [_f, _f, _l, _fl, _s],
     "pmce_vertex_init_gather_f32": [_f, _f, _f, _i, _i, _s],
     "pmce_joint_embed_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],

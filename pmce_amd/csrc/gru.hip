@@ -27,7 +27,10 @@ struct GruStepArgs {
   float* hout[2];         // + row*h_rs + unit
   long long gi_rs, h_rs;
   int B, H;
+  const float* wscale;    // SPLIT form: {2^s, 2^-s} of the packed W_hh (both directions share one scale)
 };
+
+typedef _Float16 gru_f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void gru_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff, unsigned lds_wave_base) {
   unsigned keep;  // M0 is compiler-reserved: saved and restored inside the statement
@@ -40,8 +43,12 @@ __device__ __forceinline__ void gru_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 
 // NQ = K-slices (wave groups) per workgroup: 2 -> 4 waves staging 32 k per stage, 4 -> 8 waves (two per SIMD: one wave's
 // LDS / DMA waits hide under the other's MFMAs) staging 16 k per stage.  Either way the rings fill 128 KB of LDS.
-template <int NQ>
+// SPLIT: gh on the f16 matrix pipe in the three-product form of gemm_split_f16.hip (fp32 h split in registers, W_hh packed once
+// as [row][k/16][16 hi | 16 lo] f16 of W * 2^s - the bytes and the 64-byte rows of the fp32 form, so the staging is unchanged):
+// 9 instead of 24 matrix instructions per 16-wide stage at a sixth of the pipe time each.  NQ = 4 only (16 k per stage).
+template <int NQ, bool SPLIT = false>
 __global__ __launch_bounds__(128 * NQ) void gru_step_kernel(GruStepArgs a) {
+  static_assert(!SPLIT || NQ == 4, "the split form stages exactly one 16-wide k-tile");
   constexpr int KS = 64 / NQ;              // k per stage
   constexpr int ROWB = KS * 4;             // bytes per staged row
   constexpr int LPR = KS / 4;              // lanes (16-byte chunks) per row
@@ -127,17 +134,41 @@ __global__ __launch_bounds__(128 * NQ) void gru_step_kernel(GruStepArgs a) {
       }
       const float* As = my + (kt & 1) * (STAGE / 4) + n0 * KS;
       const float* Bs = my + (kt & 1) * (STAGE / 4) + 32 * KS + n0 * KS;
+      if constexpr (SPLIT) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(As + 4 * ((2 * hb) ^ swz));      // k = 8 hb + [0, 4)
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(As + 4 * ((2 * hb + 1) ^ swz));  // k = 8 hb + [4, 8)
+        const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        gru_f16x8 ahi, alo;
 #pragma unroll
-      for (int g8 = 0; g8 < KS / 8; ++g8) {
-        const int co = 4 * ((2 * g8 + hb) ^ swz);
-        const f32x4 av = *reinterpret_cast<const f32x4*>(As + co);
-        f32x4 bv[3];
+        for (int e = 0; e < 8; ++e) ahi[e] = (_Float16)xv[e];
 #pragma unroll
-        for (int g = 0; g < 3; ++g) bv[g] = *reinterpret_cast<const f32x4*>(Bs + g * 32 * KS + co);
+        for (int e = 0; e < 8; ++e) alo[e] = (_Float16)((xv[e] - (float)ahi[e]) * 2048.0f);
+        gru_f16x8 whi[3], wlo[3], wh2[3];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int g = 0; g < 3; ++g) {
+          whi[g] = *reinterpret_cast<const gru_f16x8*>(Bs + g * 32 * KS + 4 * (hb ^ swz));        // hi plane, k = 8 hb + [0, 8)
+          wlo[g] = *reinterpret_cast<const gru_f16x8*>(Bs + g * 32 * KS + 4 * ((2 + hb) ^ swz));  // lo plane
+          wh2[g] = whi[g] * (_Float16)0.00048828125f;
+        }
 #pragma unroll
-          for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[g][s], acc[g], 0, 0, 0);
+        for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, whi[g], acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, wlo[g], acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, wh2[g], acc[g], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int g8 = 0; g8 < KS / 8; ++g8) {
+          const int co = 4 * ((2 * g8 + hb) ^ swz);
+          const f32x4 av = *reinterpret_cast<const f32x4*>(As + co);
+          f32x4 bv[3];
+#pragma unroll
+          for (int g = 0; g < 3; ++g) bv[g] = *reinterpret_cast<const f32x4*>(Bs + g * 32 * KS + co);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[g][s], acc[g], 0, 0, 0);
+        }
       }
     }
     __syncthreads();  // every wave is done with its private ring: the reduction below reuses the memory
@@ -173,6 +204,7 @@ __global__ __launch_bounds__(128 * NQ) void gru_step_kernel(GruStepArgs a) {
   // gate update on the D layout: unit = u0 + (lane & 31), batch row = m0 + rb*32 + (r&3) + 8*(r>>2) + 4*hb
   const float* __restrict__ bh = a.bhh[d];
   const float bhr = bh[u], bhz = bh[H + u], bhn = bh[2 * H + u];
+  const float w_down = SPLIT ? a.wscale[1] : 1.f;  // the packed W_hh carries 2^s
   float* __restrict__ ho = a.hout[d];
 #pragma unroll
   for (int q = 0; q < RW; ++q) {
@@ -183,6 +215,11 @@ __global__ __launch_bounds__(128 * NQ) void gru_step_kernel(GruStepArgs a) {
       ar = sel ? acc[0][r] : ar;
       az = sel ? acc[1][r] : az;
       an = sel ? acc[2][r] : an;
+    }
+    if (SPLIT) {
+      ar *= w_down;
+      az *= w_down;
+      an *= w_down;
     }
     const int r = RW * kq + q;
     const int m = m0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
@@ -195,9 +232,9 @@ __global__ __launch_bounds__(128 * NQ) void gru_step_kernel(GruStepArgs a) {
   }
 }
 
-extern "C" int pmce_gru_step_f32(const float* gi0, const float* gi1, const float* whh0, const float* whh1, const float* bhh0,
-                                 const float* bhh1, const float* hp0, const float* hp1, float* ho0, float* ho1,
-                                 long long gi_rs, long long h_rs, int B, int H, int ndir, hipStream_t stream) {
+static int gru_step_any(const float* gi0, const float* gi1, const float* whh0, const float* whh1, const float* wscale,
+                        const float* bhh0, const float* bhh1, const float* hp0, const float* hp1, float* ho0, float* ho1,
+                        long long gi_rs, long long h_rs, int B, int H, int ndir, hipStream_t stream) {
   PMCE_REQUIRE(ndir == 1 || ndir == 2, "gru_step: ndir must be 1 or 2");
   PMCE_REQUIRE(gi0 && whh0 && bhh0 && ho0 && B > 0, "gru_step: null pointer");
   PMCE_REQUIRE(ndir == 1 || (gi1 && whh1 && bhh1 && ho1), "gru_step: second direction pointers missing");
@@ -205,14 +242,30 @@ extern "C" int pmce_gru_step_f32(const float* gi0, const float* gi1, const float
   GruStepArgs a;
   a.gi[0] = gi0; a.gi[1] = gi1; a.whh[0] = whh0; a.whh[1] = whh1; a.bhh[0] = bhh0; a.bhh[1] = bhh1;
   a.hprev[0] = hp0; a.hprev[1] = hp1; a.hout[0] = ho0; a.hout[1] = ho1;
-  a.gi_rs = gi_rs; a.h_rs = h_rs; a.B = B; a.H = H;
+  a.gi_rs = gi_rs; a.h_rs = h_rs; a.B = B; a.H = H; a.wscale = wscale;
   PMCE_REQUIRE((long long)B * h_rs * 4 < (1ll << 32) && 3ll * H * H * 4 < (1ll << 32), "gru_step: h or W_hh spans 4 GiB or more");
   static const int nq = pmce_env_int("PMCE_GRU_NQ", 4);  // tuning knob, read once
-  if (nq == 2)
+  if (wscale)
+    hipLaunchKernelGGL((gru_step_kernel<4, true>), dim3(H / 32, (B + 63) / 64, ndir), dim3(512), 0, stream, a);
+  else if (nq == 2)
     hipLaunchKernelGGL((gru_step_kernel<2>), dim3(H / 32, (B + 63) / 64, ndir), dim3(256), 0, stream, a);
   else
     hipLaunchKernelGGL((gru_step_kernel<4>), dim3(H / 32, (B + 63) / 64, ndir), dim3(512), 0, stream, a);
   return pmce_check_launch("gru_step");
+}
+extern "C" int pmce_gru_step_f32(const float* gi0, const float* gi1, const float* whh0, const float* whh1, const float* bhh0,
+                                 const float* bhh1, const float* hp0, const float* hp1, float* ho0, float* ho1,
+                                 long long gi_rs, long long h_rs, int B, int H, int ndir, hipStream_t stream) {
+  return gru_step_any(gi0, gi1, whh0, whh1, nullptr, bhh0, bhh1, hp0, hp1, ho0, ho1, gi_rs, h_rs, B, H, ndir, stream);
+}
+// The same step with gh = h W_hh^T in the three-product f16 form: whh0 / whh1 are rows of ONE weight packed by
+// pmce_gemm_pack_split_f16 (K = H), wscale its scale pair.
+extern "C" int pmce_gru_step_split_f32(const float* gi0, const float* gi1, const float* whh0p, const float* whh1p,
+                                       const float* wscale, const float* bhh0, const float* bhh1, const float* hp0,
+                                       const float* hp1, float* ho0, float* ho1, long long gi_rs, long long h_rs, int B, int H,
+                                       int ndir, hipStream_t stream) {
+  PMCE_REQUIRE(wscale, "gru_step_split: null wscale");
+  return gru_step_any(gi0, gi1, whh0p, whh1p, wscale, bhh0, bhh1, hp0, hp1, ho0, ho1, gi_rs, h_rs, B, H, ndir, stream);
 }
 
 // joints(m) = pose3d(mm) / 1000   (reference PMCE.py:18 — a true division, kept as one)

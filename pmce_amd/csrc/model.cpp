@@ -98,7 +98,7 @@ struct pmce_model {
   bool split_gemm = true;  // pmce_model_set_gemm_mode / PMCE_SPLIT_F16=0 at create
   float* split_arena = nullptr;  // owned (hipMalloc): every packed weight + its scale
   LifterBlockSplit sblk[2][8];
-  SplitW s_ie, s_wih0, s_wih1, s_ada, s_final;
+  SplitW s_ie, s_wih0, s_wih1, s_whh0, s_whh1, s_ada, s_final;
   // Below this many clips per call the products stay on the fp32 pipe: a small batch is bound by its 25 dependent GRU launches,
   // which the two-stream schedule (fp32 mode only, see two_streams) hides under the pose lifter - worth more than the GEMM time
   // the f16 form saves there (B = 1: 1.8 ms against 2.7 ms).  PMCE_SPLIT_MIN_BATCH at create.
@@ -433,8 +433,15 @@ int lifter_impl(pmce_model* m, const float* pose2d, const float* img_feat, float
 int gru_layer(pmce_model* m, int layer, const float* gi_f, const float* gi_b, long long gi_rs, int t_f0, int t_b0,
               int nsteps_f, int nsteps_b, float* Y, int B, hipStream_t stream) {
   // direction 0 walks t = t_f0, t_f0+1, ...; direction 1 walks t = t_b0, t_b0-1, ...  Y is [T][B][2*GH].
-  const float* whh = layer == 0 ? m->w.whh0 : m->w.whh1;
+  const SplitW& sw = layer == 0 ? m->s_whh0 : m->s_whh1;
+  const bool split = m->split_now && sw.wp;
+  const float* whh = split ? sw.wp : (layer == 0 ? m->w.whh0 : m->w.whh1);  // the packed rows keep the fp32 row stride
   const float* bhh = layer == 0 ? m->w.bhh0 : m->w.bhh1;
+  auto step = [&](const float* gi0, const float* gi1, const float* w0, const float* w1, const float* b0, const float* b1,
+                  const float* hp0, const float* hp1, float* ho0, float* ho1, int ndir) {
+    return split ? pmce_gru_step_split_f32(gi0, gi1, w0, w1, sw.scale, b0, b1, hp0, hp1, ho0, ho1, gi_rs, 2 * GH, B, GH, ndir, stream)
+                 : pmce_gru_step_f32(gi0, gi1, w0, w1, b0, b1, hp0, hp1, ho0, ho1, gi_rs, 2 * GH, B, GH, ndir, stream);
+  };
   const long long YS = (long long)B * 2 * GH;
   const int nsteps = nsteps_f > nsteps_b ? nsteps_f : nsteps_b;
   for (int s = 0; s < nsteps; ++s) {
@@ -449,13 +456,11 @@ int gru_layer(pmce_model* m, int layer, const float* gi_f, const float* gi_b, lo
     const float* whh_b = whh + (long long)3 * GH * GH;
     const float* bhh_b = bhh + 3 * GH;
     if (af && ab)
-      RUN(P_GRU_STEP, pmce_gru_step_f32(gif, gib, whh, whh_b, bhh, bhh_b, hp_f, hp_b, ho_f, ho_b, gi_rs, 2 * GH, B, GH, 2, stream));
+      RUN(P_GRU_STEP, step(gif, gib, whh, whh_b, bhh, bhh_b, hp_f, hp_b, ho_f, ho_b, 2));
     else if (af)
-      RUN(P_GRU_STEP, pmce_gru_step_f32(gif, nullptr, whh, nullptr, bhh, nullptr, hp_f, nullptr, ho_f, nullptr, gi_rs, 2 * GH, B, GH,
-                                        1, stream));
+      RUN(P_GRU_STEP, step(gif, nullptr, whh, nullptr, bhh, nullptr, hp_f, nullptr, ho_f, nullptr, 1));
     else
-      RUN(P_GRU_STEP, pmce_gru_step_f32(gib, nullptr, whh_b, nullptr, bhh_b, nullptr, hp_b, nullptr, ho_b, nullptr, gi_rs, 2 * GH, B,
-                                        GH, 1, stream));
+      RUN(P_GRU_STEP, step(gib, nullptr, whh_b, nullptr, bhh_b, nullptr, hp_b, nullptr, ho_b, nullptr, 1));
   }
   return PMCE_OK;
 }
@@ -656,7 +661,7 @@ int build_split_weights(pmce_model* m) {
   }
   for (auto& kind : m->sblk)
     for (auto& b : kind) b = LifterBlockSplit{};
-  m->s_ie = m->s_wih0 = m->s_wih1 = m->s_ada = m->s_final = SplitW{};
+  m->s_ie = m->s_wih0 = m->s_wih1 = m->s_whh0 = m->s_whh1 = m->s_ada = m->s_final = SplitW{};
   if (!m->split_gemm) return PMCE_OK;
   const int C = m->C;
   struct Item { const float* w; int n, k; SplitW* dst; };
@@ -676,6 +681,8 @@ int build_split_weights(pmce_model* m) {
   if (m->has_decoder) {
     items.push_back({m->w.wih0, 6 * GH, F, &m->s_wih0});
     items.push_back({m->w.wih1, 6 * GH, 2 * GH, &m->s_wih1});
+    items.push_back({m->w.whh0, 6 * GH, GH, &m->s_whh0});  // recurrent weights, both directions: gru_step's three-product form
+    items.push_back({m->w.whh1, 6 * GH, GH, &m->s_whh1});
     items.push_back({m->w.ada_w, N_ADA * 128, 2 * GH, &m->s_ada});
     items.push_back({m->w.final_w, NVF * 3, FINAL_K, &m->s_final});
   }
