@@ -64,6 +64,9 @@ int pmce_model_finalize(pmce_model* m);
  * each against an fp64 product); may be called at any time between forwards. */
 int pmce_model_set_gemm_mode(pmce_model* m, int split_f16);
 int pmce_model_gemm_mode(const pmce_model* m);
+/* A second handle on the SAME registered weights (a pipeline lane) takes the source's packed planes instead of packing its own copy:
+ * call after the last pmce_model_set_tensor of `dst` and before its pmce_model_finalize; the planes live until the last handle goes. */
+int pmce_model_share_split_weights(pmce_model* dst, const pmce_model* src);
 /* Calls with fewer clips (windows) than this stay on the fp32 pipe and keep its two-stream schedule even in split_f16 mode
  * (default 48, env PMCE_SPLIT_MIN_BATCH at create): a small batch is bound by the GRU's dependent launches, not by the products. */
 int pmce_model_set_split_min_batch(pmce_model* m, int clips);

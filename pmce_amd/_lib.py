@@ -41,6 +41,7 @@ PROTOTYPES = {
     "pmce_model_profile": [C.c_void_p, _i],
     "pmce_model_set_gemm_mode": [C.c_void_p, _i],
     "pmce_model_gemm_mode": [C.c_void_p],
+    "pmce_model_share_split_weights": [C.c_void_p, C.c_void_p],
     "pmce_model_set_split_min_batch": [C.c_void_p, _i],
     "pmce_model_profile_read": [C.c_void_p, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_longlong)],
     "pmce_gemm_nt_f32": [_f, _f, _f, _f, _f, _i, _i, _i, _l, _i, _l, _i, _i, _l, _l, _i, _l, _l, _i, _l, _l, _l, _l, _s],

@@ -10,6 +10,7 @@
 
 #include <stdlib.h>
 
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -96,7 +97,8 @@ struct pmce_model {
   bool fused_ca = true;    // CrossAttentionBlock of the vertex stream as one launch (PMCE_VERTEX_FUSED=0 at create: two)
   // the large products on the f16 matrix pipe (three-product split, fp32 accuracy) instead of the fp32 one
   bool split_gemm = true;  // pmce_model_set_gemm_mode / PMCE_SPLIT_F16=0 at create
-  float* split_arena = nullptr;  // owned (hipMalloc): every packed weight + its scale
+  std::shared_ptr<float> split_arena;  // hipMalloc'ed: every packed weight + its scale; shared by handles cloned onto the same weights
+  bool split_adopted = false;          // the planes came from another handle (pmce_model_share_split_weights): finalize keeps them
   LifterBlockSplit sblk[2][8];
   SplitW s_ie, s_wih0, s_wih1, s_whh0, s_whh1, s_ada, s_final;
   // Below this many clips per call the products stay on the fp32 pipe: a small batch is bound by its 25 dependent GRU launches,
@@ -654,10 +656,11 @@ namespace {
 // (Re)build the packed f16 planes of every lifter Linear weight in model-owned memory, or drop them (fp32 mode / no
 // lifter).  Runs on the null stream and waits: a load-time step, like the packing the host side does.
 int build_split_weights(pmce_model* m) {
+  if (m->split_adopted && m->split_gemm && m->split_arena) return PMCE_OK;  // another handle's planes of the same weights
+  m->split_adopted = false;
   if (m->split_arena) {
     (void)hipDeviceSynchronize();  // forwards in flight may still read the old planes
-    (void)hipFree(m->split_arena);
-    m->split_arena = nullptr;
+    m->split_arena.reset();        // frees them unless another handle shares them
   }
   for (auto& kind : m->sblk)
     for (auto& b : kind) b = LifterBlockSplit{};
@@ -689,14 +692,15 @@ int build_split_weights(pmce_model* m) {
   if (items.empty()) return PMCE_OK;
   size_t floats = 0;
   for (auto& it : items) floats += (((size_t)it.n * it.k + 63) & ~(size_t)63) + 64;
-  const hipError_t rc = hipMalloc(reinterpret_cast<void**>(&m->split_arena), floats * sizeof(float));
+  float* arena = nullptr;
+  const hipError_t rc = hipMalloc(reinterpret_cast<void**>(&arena), floats * sizeof(float));
+  if (rc == hipSuccess) m->split_arena = std::shared_ptr<float>(arena, [](float* q) { (void)hipFree(q); });
   if (rc != hipSuccess) {
-    m->split_arena = nullptr;
     pmce_set_error("model_finalize: hipMalloc(%zu bytes) for the split weights failed: %s", floats * sizeof(float),
                    hipGetErrorString(rc));
     return PMCE_ERR_LAUNCH;
   }
-  float* p = m->split_arena;
+  float* p = m->split_arena.get();
   for (auto& it : items) {
     float* wp = p;
     float* sc = p + (((size_t)it.n * it.k + 63) & ~(size_t)63);
@@ -746,7 +750,6 @@ void pmce_model_destroy(pmce_model* m) {
   for (hipEvent_t e : {m->ev_fork, m->ev_join, m->ev_a, m->ev_b, m->ev_c, m->ev_d, m->ev_lifter})
     if (e) (void)hipEventDestroy(e);
   if (m->side) (void)hipStreamDestroy(m->side);
-  if (m->split_arena) (void)hipFree(m->split_arena);
   delete m;
 }
 
@@ -769,6 +772,7 @@ int pmce_model_set_tensor(pmce_model* m, const char* name, const void* dev_ptr) 
   PMCE_REQUIRE((reinterpret_cast<uintptr_t>(dev_ptr) & 15) == 0, "model_set_tensor: '%s' is not 16-byte aligned", name);
   m->ptr[n] = dev_ptr;
   m->finalized = false;
+  m->split_adopted = false;
   return PMCE_OK;
 }
 
@@ -818,6 +822,25 @@ int pmce_model_set_gemm_mode(pmce_model* m, int split_f16) {
   return PMCE_OK;
 }
 int pmce_model_gemm_mode(const pmce_model* m) { return m && m->split_gemm ? 1 : 0; }
+int pmce_model_share_split_weights(pmce_model* dst, const pmce_model* src) {
+  PMCE_REQUIRE(dst && src && src->finalized, "model_share_split_weights: need a destination and a finalized source");
+  PMCE_REQUIRE(dst->J == src->J && dst->C == src->C && dst->depth == src->depth, "model_share_split_weights: different configurations");
+  for (auto& n : dst->names) {  // the same weights, tensor by tensor
+    const auto a = static_cast<const pmce_model*>(dst)->ptr.find(n);
+    const auto b = src->ptr.find(n);
+    PMCE_REQUIRE((a == dst->ptr.end()) == (b == src->ptr.end()) && (a == dst->ptr.end() || a->second == b->second),
+                 "model_share_split_weights: tensor '%s' differs between the two handles", n.c_str());
+  }
+  if (!src->split_arena) return PMCE_OK;  // fp32 mode: nothing to share
+  dst->split_arena = src->split_arena;
+  for (int k = 0; k < 2; ++k)
+    for (int i = 0; i < 8; ++i) dst->sblk[k][i] = src->sblk[k][i];
+  dst->s_ie = src->s_ie; dst->s_wih0 = src->s_wih0; dst->s_wih1 = src->s_wih1; dst->s_whh0 = src->s_whh0; dst->s_whh1 = src->s_whh1;
+  dst->s_ada = src->s_ada; dst->s_final = src->s_final;
+  dst->split_gemm = true;
+  dst->split_adopted = true;
+  return PMCE_OK;
+}
 int pmce_model_set_split_min_batch(pmce_model* m, int clips) {
   PMCE_REQUIRE(m && clips >= 1, "model_set_split_min_batch: need a model and clips >= 1");
   m->split_min_batch = clips;

@@ -92,6 +92,7 @@ class HipEngine:
             other.set_split_min_batch(self.split_min_batch)
         other.split_min_batch = self.split_min_batch
         other.register(self.packed)
+        _lib.check(other.lib.pmce_model_share_split_weights(other.handle, self.handle), "model_share_split_weights")
         if self.regressor_rows:
             _lib.check(other.lib.pmce_model_set_regressor_rows(other.handle, self.regressor_rows), "set_regressor_rows")
             other.regressor_rows = self.regressor_rows

@@ -310,6 +310,35 @@ def test_pipeline_matches_direct_forward():
     pipe.synchronize()
 
 
+def test_pipeline_lanes_share_packed_weights_and_split_batches():
+    """Pipeline lanes in split_f16 mode: (1) batches large enough for the three-product f16 form come out bit-identical to direct
+    forwards (the lanes share one stream there); (2) a lane does not pack its own copy of the f16 weight planes (0.5 GB at
+    C = 256): building three lanes costs workspaces only."""
+    from pmce_amd import synth
+    J, B = 17, 64
+    model = get_model(J, 256)
+    assert model.gemm_mode() == "split_f16"
+    batches = []
+    for i in range(3):
+        p, f = synth.make_inputs(B, J, 900 + i)
+        batches.append((T(p).to(dev()), T(f).to(dev())))
+    direct = [tuple(t.clone() for t in model.forward_with_joints(p, f)) for p, f in batches]
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    pipe = model.pipeline(depth=3).prepare(B)
+    torch.cuda.synchronize()
+    used = free0 - torch.cuda.mem_get_info()[0]
+    ws = model._engine.lib.pmce_model_workspace_bytes(model._engine.handle, B)
+    print(f"three lanes at B={B}: {used / 2**20:.0f} MiB (one workspace is {ws / 2**20:.0f} MiB)")
+    assert used < 3 * ws + (128 << 20)
+    tickets = [pipe.submit(p, f) for p, f in batches]
+    for d, t in zip(direct, tickets):
+        for a, b in zip(d, t.result()):
+            assert torch.equal(a, b)
+    pipe.synchronize()
+
+
 def test_pipeline_follows_reloaded_weights():
     """A pipeline created before load_state_dict must serve the NEW weights afterwards (lanes share the model's packed copy)."""
     from pmce_amd import synth
