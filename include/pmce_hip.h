@@ -241,6 +241,16 @@ int pmce_vertex_ca_mlp_f32(const float* xq, const float* vt, const float* Wv3, c
                            const float* s0, const float* Vf, const float* bp, const float* GB, int gb_stride, int inst,
                            const float* W1, const float* b1, const float* W2, const float* b2, float* yout, float* scratch,
                            int B, int J, pmce_stream_t stream);
+/* _ex forms of the two FFN-carrying kernels: split_f16 != 0 runs the 64->256->64 FFN in the three-product f16 form (weights split
+ * into f16 planes while they are staged into LDS, activations split in registers; fp32 accumulate, fp32 results) - only for calls
+ * that do not overlap other kernels. */
+int pmce_adaln_mlp_ex_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* W1, const float* b1,
+                          const float* W2, const float* b2, float* yout, const float* Wc, const float* bc, const float* vt_in,
+                          float* vt_out, int B, int split_f16, pmce_stream_t stream);
+int pmce_vertex_ca_mlp_ex_f32(const float* xq, const float* vt, const float* Wv3, const float* Eq, const float* Kf,
+                              const float* s0, const float* Vf, const float* bp, const float* GB, int gb_stride, int inst,
+                              const float* W1, const float* b1, const float* W2, const float* b2, float* yout, float* scratch,
+                              int B, int J, int split_f16, pmce_stream_t stream);
 
 /* qkv = Linear(64->192)(AdaLN(x)) on [B,431,64] (CoevoDecoder.py:103,120). */
 int pmce_adaln_qkv_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* Wqkv, const float* bqkv,

@@ -69,6 +69,8 @@ PROTOTYPES = {
     "pmce_ca_fold_f32": [_f, _f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],
     "pmce_vertex_ca_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],
     "pmce_adaln_mlp_f32": [_f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _s],
+    "pmce_adaln_mlp_ex_f32": [_f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],
+    "pmce_vertex_ca_mlp_ex_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _s],
     "pmce_vertex_ca_mlp_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _s],
     "pmce_adaln_qkv_f32": [_f, _f, _i, _i, _f, _f, _f, _i, _s],
     "pmce_vertex_sa_f32": [_f, _f, _f, _f, _f, _i, _s],

@@ -288,41 +288,71 @@ __global__ __launch_bounds__(448, 4) void vertex_ca_kernel(const float* __restri
   }
 }
 
+
 // ======================================================================================================
-// adaln_mlp:  y = x + fc2(gelu(fc1(AdaLN(x))))   (hidden 256), optionally followed by the coordinate head
-//   vt_out = Wc*y + bc + vt_in  (proj_vertx_feat2coor + residual, CoevoDecoder.py:189).
-// Persistent workgroups (4 waves); fc1/fc2 weights live in LDS (137 KB) for the whole kernel; each wave walks
-// over 32-token tiles; the 256-wide hidden activation exists only as 16 registers at a time.
+// The 64 -> 256 -> 64 AdaLN-FFN of a 32-token wave tile (shared by adaln_mlp and vertex_ca_mlp), two arithmetic forms.
+//  F16 = false: fp32 matrix pipe (tl_gemm), weights staged as fp32.
+//  F16 = true : the three-product f16 form of gemm_split_f16.hip.  A token's activation in slot layout is, per 16-channel k-step
+//    s, the registers [8s, 8s+8) of a lane - exactly one f16x8 B fragment once split into (hi, lo*2^11) - and the weights are
+//    staged into LDS as the matching A fragments: row r holds, per k-step s and lane half hb, 8 f16 hi then 8 f16 lo of
+//    W[r][c(s,hb,e)] * 2^sw, c(s,hb,e) = 16s + 4hb + e (e < 4), 16s + 8 + 4hb + e - 4 (e >= 4): the bytes and the row stride of the
+//    fp32 staging.  acc_main += whi*xhi + wlo*xhi, acc_corr += whi*xlo (lo carries 2^11), result = (acc_main + acc_corr*2^-11)*2^-sw:
+//    12 + 12 matrix instructions of 32 cycles per 32 hidden units instead of 32 + 32 of 64 cycles.
 // ======================================================================================================
-__global__ __launch_bounds__(512) void adaln_mlp_kernel(const float* __restrict__ xin, const float* __restrict__ GB,
-                                                        int gb_stride, int inst, const float* __restrict__ W1,
-                                                        const float* __restrict__ b1, const float* __restrict__ W2,
-                                                        const float* __restrict__ b2, float* __restrict__ yout,
-                                                        const float* __restrict__ Wc, const float* __restrict__ bc,
-                                                        const float* __restrict__ vt_in, float* __restrict__ vt_out, int B) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sW1 = smem;                    // [256][68]
-  float* sW2 = sW1 + 256 * LDW64;       // [64][260]
-  float* sB1 = sW2 + 64 * LDW256;       // [256]
-  float* sB2 = sB1 + 256;               // [64]
-  const int tid = threadIdx.x;
-  stage_weight<64>(sW1, W1, 256, tid, 512);
-  stage_weight<256>(sW2, W2, 64, tid, 512);
-  if (tid < 256) sB1[tid] = b1[tid];
-  if (tid < 64) sB2[tid] = b2[tid];
+typedef _Float16 tl_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 tl_f16x4 __attribute__((ext_vector_type(4)));
+
+// fp32 [rows][K] global -> LDS [rows][K+4 floats] of f16 fragments (see above), scaled by `up` (a power of two)
+template <int K>
+__device__ __forceinline__ void stage_weight_split(float* __restrict__ dst, const float* __restrict__ src, int rows, float up,
+                                                   int tid, int nthreads) {
+  constexpr int C4 = K / 4;
+  for (int i = tid; i < rows * C4; i += nthreads) {
+    const int r = i / C4, c = i % C4;  // channels 4c .. 4c+3 of row r
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)r * K + 4 * c) * up;
+    tl_f16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hi[e] = (_Float16)v[e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lo[e] = (_Float16)(v[e] - (float)hi[e]);
+    const int ks = c >> 2, g = c & 3;  // k-step, group of 4 inside it: g = 0: hb 0 e 0..3, 1: hb 1 e 0..3, 2: hb 0 e 4..7, 3: hb 1 e 4..7
+    _Float16* chunk = reinterpret_cast<_Float16*>(dst + r * (K + 4) + ((ks * 2 + (g & 1)) * 2) * 4) + (g >> 1) * 4;
+    *reinterpret_cast<tl_f16x4*>(chunk) = hi;
+    *reinterpret_cast<tl_f16x4*>(chunk + 8) = lo;
+  }
+}
+// max |w| of a weight over the workgroup -> (2^s, 2^-s) with max|w| * 2^s in [2^14, 2^15); red: 16 floats of LDS scratch
+__device__ __forceinline__ void weight_scale(const float* __restrict__ src, int n, float* red, int tid, int nthreads, float& up,
+                                            float& down) {
+  float m = 0.f;
+  for (int i = tid; i < n / 4; i += nthreads) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
+    m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(m, fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  m = wave_max(m);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
   __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6;
-  const int n0 = lane & 31, hb = lane >> 5;
-  const int ntiles = B * NTILE;
-  for (int wt = blockIdx.x * 8 + wave; wt < ntiles; wt += gridDim.x * 8) {
-    const int b = wt / NTILE, tile = wt % NTILE;
-    const int v = tile * 32 + n0;
-    const bool valid = v < NV;
-    const long long tok = (long long)b * NV + (valid ? v : NV - 1);
-    float x[32], a[32];
-    load_slots(xin + tok * 64, x, hb);
-    adaln_slots(x, a, GB + (long long)b * gb_stride + inst * 128, hb);
-    f32x16 acc2[2];
+  float mx = 0.f;
+  for (int w = 0; w < (nthreads + 63) / 64; ++w) mx = fmaxf(mx, red[w]);
+  __syncthreads();
+  int e = 0;
+  if (mx > 0.f) frexpf(mx, &e);
+  up = mx > 0.f ? ldexpf(1.f, 15 - e) : 1.f;
+  down = mx > 0.f ? ldexpf(1.f, e - 15) : 1.f;
+}
+// slots [8s, 8s+8) of an activation -> the (hi, lo*2^11) B fragments of k-step s
+__device__ __forceinline__ void split_slots8(const float* x, tl_f16x8& hi, tl_f16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) hi[e] = (_Float16)x[e];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) lo[e] = (_Float16)((x[e] - (float)hi[e]) * 2048.0f);
+}
+
+// a: AdaLN output of the tile (32 slots); x: the residual input; returns y = x + fc2(gelu(fc1(a))) in acc2 (D layout = slot layout)
+template <bool F16>
+__device__ __forceinline__ void ffn_slots(const float* sW1, const float* sW2, const float* sB1, const float* sB2, const float* sSc,
+                                          const float* a, const float* x, f32x16 (&acc2)[2], int n0, int hb) {
+  if constexpr (!F16) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -342,6 +372,116 @@ __global__ __launch_bounds__(512) void adaln_mlp_kernel(const float* __restrict_
       }
       tl_gemm<4, 2, LDW256>(sW2 + ht * 32, hreg, acc2, n0, hb);
     }
+  } else {
+    const float down1 = sSc[1], down2 = sSc[3];
+    tl_f16x8 ahi[4], alo[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) split_slots8(a + 8 * s, ahi[s], alo[s]);
+    f32x16 m2[2], c2[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m2[nt][r] = c2[nt][r] = 0.f;
+#pragma unroll 1
+    for (int ht = 0; ht < 8; ++ht) {
+      f32x16 m1, c1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m1[r] = c1[r] = 0.f;
+      const float* w1 = sW1 + (ht * 32 + n0) * LDW64 + hb * 8;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const tl_f16x8 whi = *reinterpret_cast<const tl_f16x8*>(w1 + s * 16), wlo = *reinterpret_cast<const tl_f16x8*>(w1 + s * 16 + 4);
+        m1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, ahi[s], m1, 0, 0, 0);
+        m1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, ahi[s], m1, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, alo[s], c1, 0, 0, 0);
+      }
+      float hreg[16];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int u = ht * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;  // r and r+1: consecutive hidden units (r even)
+        const f32x2 pre = {fmaf(fmaf(c1[r], 0.00048828125f, m1[r]), down1, sB1[u]),
+                           fmaf(fmaf(c1[r + 1], 0.00048828125f, m1[r + 1]), down1, sB1[u + 1])};
+        const f32x2 g = gelu_erf2(pre);
+        hreg[r] = g.x;
+        hreg[r + 1] = g.y;
+      }
+      tl_f16x8 hhi[2], hlo[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) split_slots8(hreg + 8 * s, hhi[s], hlo[s]);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const float* w2 = sW2 + (nt * 32 + n0) * LDW256 + ht * 32 + hb * 8;  // k-steps 2 ht, 2 ht + 1 of the 256-wide row
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const tl_f16x8 whi = *reinterpret_cast<const tl_f16x8*>(w2 + s * 16), wlo = *reinterpret_cast<const tl_f16x8*>(w2 + s * 16 + 4);
+          m2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, hhi[s], m2[nt], 0, 0, 0);
+          m2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, hhi[s], m2[nt], 0, 0, 0);
+          c2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, hlo[s], c2[nt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        acc2[nt][r] = fmaf(fmaf(c2[nt][r], 0.00048828125f, m2[nt][r]), down2, sB2[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb]) + x[16 * nt + r];
+  }
+}
+// stage the FFN's two weights (and, in the f16 form, their scales into sSc[4] = {2^s1, 2^-s1, 2^s2, 2^-s2})
+template <bool F16>
+__device__ __forceinline__ void stage_ffn(float* sW1, float* sW2, float* sSc, const float* W1, const float* W2, int tid, int nthreads) {
+  if constexpr (F16) {
+    float up1, down1, up2, down2;
+    weight_scale(W1, 256 * 64, sSc + 4, tid, nthreads, up1, down1);
+    weight_scale(W2, 64 * 256, sSc + 4, tid, nthreads, up2, down2);
+    if (tid == 0) {
+      sSc[0] = up1; sSc[1] = down1; sSc[2] = up2; sSc[3] = down2;
+    }
+    stage_weight_split<64>(sW1, W1, 256, up1, tid, nthreads);
+    stage_weight_split<256>(sW2, W2, 64, up2, tid, nthreads);
+  } else {
+    stage_weight<64>(sW1, W1, 256, tid, nthreads);
+    stage_weight<256>(sW2, W2, 64, tid, nthreads);
+  }
+}
+
+// ======================================================================================================
+// adaln_mlp:  y = x + fc2(gelu(fc1(AdaLN(x))))   (hidden 256), optionally followed by the coordinate head
+//   vt_out = Wc*y + bc + vt_in  (proj_vertx_feat2coor + residual, CoevoDecoder.py:189).
+// Persistent workgroups (4 waves); fc1/fc2 weights live in LDS (137 KB) for the whole kernel; each wave walks
+// over 32-token tiles; the 256-wide hidden activation exists only as 16 registers at a time.
+// ======================================================================================================
+template <bool F16>
+__global__ __launch_bounds__(512) void adaln_mlp_kernel(const float* __restrict__ xin, const float* __restrict__ GB,
+                                                        int gb_stride, int inst, const float* __restrict__ W1,
+                                                        const float* __restrict__ b1, const float* __restrict__ W2,
+                                                        const float* __restrict__ b2, float* __restrict__ yout,
+                                                        const float* __restrict__ Wc, const float* __restrict__ bc,
+                                                        const float* __restrict__ vt_in, float* __restrict__ vt_out, int B) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sW1 = smem;                    // [256][68]
+  float* sW2 = sW1 + 256 * LDW64;       // [64][260]
+  float* sB1 = sW2 + 64 * LDW256;       // [256]
+  float* sB2 = sB1 + 256;               // [64]
+  float* sSc = sB2 + 64;                // [4 + 16] scales of the f16 form + reduction scratch
+  const int tid = threadIdx.x;
+  stage_ffn<F16>(sW1, sW2, sSc, W1, W2, tid, 512);
+  if (tid < 256) sB1[tid] = b1[tid];
+  if (tid < 64) sB2[tid] = b2[tid];
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n0 = lane & 31, hb = lane >> 5;
+  const int ntiles = B * NTILE;
+  for (int wt = blockIdx.x * 8 + wave; wt < ntiles; wt += gridDim.x * 8) {
+    const int b = wt / NTILE, tile = wt % NTILE;
+    const int v = tile * 32 + n0;
+    const bool valid = v < NV;
+    const long long tok = (long long)b * NV + (valid ? v : NV - 1);
+    float x[32], a[32];
+    load_slots(xin + tok * 64, x, hb);
+    adaln_slots(x, a, GB + (long long)b * gb_stride + inst * 128, hb);
+    f32x16 acc2[2];
+    ffn_slots<F16>(sW1, sW2, sB1, sB2, sSc, a, x, acc2, n0, hb);
     if (yout && valid) {
       float y[32];
 #pragma unroll
@@ -391,6 +531,7 @@ __global__ __launch_bounds__(512) void adaln_mlp_kernel(const float* __restrict_
 // launcher falls back to the two kernels above beyond that.  Same arithmetic in the same order as vertex_ca + adaln_mlp.
 // ======================================================================================================
 #define CAM_VLD 52  // Vf compact row stride: 2 heads x 24 keys + 4 (conflict-free ds_read_b128 across 32 rows)
+template <bool F16>
 __global__ __launch_bounds__(448) void vertex_ca_mlp_kernel(const float* __restrict__ xq, const float* __restrict__ vt,
                                                             const float* __restrict__ Wv3, const float* __restrict__ Eq,
                                                             const float* __restrict__ Kf, const float* __restrict__ s0,
@@ -404,12 +545,12 @@ __global__ __launch_bounds__(448) void vertex_ca_mlp_kernel(const float* __restr
   float* sW2 = sW1 + 256 * LDW64;       // [64][260]
   float* sB1 = sW2 + 64 * LDW256;       // [256]
   float* sB2 = sB1 + 256;               // [64]
-  float* sS0 = sB2 + 64;                // [2][32]
+  float* sSc = sB2 + 64;                // [4 + 16] scales of the f16 FFN form + reduction scratch (+ 12 pad)
+  float* sS0 = sSc + 32;                // [2][32]
   float* sV = sS0 + 64;                 // [64][CAM_VLD]   Vf[c][h*24 + i], i < 24
   float* sK = sV + 64 * CAM_VLD;        // [2*J][68]       Kf[h*J + i][c], i < J
   const int tid = threadIdx.x;
-  stage_weight<64>(sW1, W1, 256, tid, 448);
-  stage_weight<256>(sW2, W2, 64, tid, 448);
+  stage_ffn<F16>(sW1, sW2, sSc, W1, W2, tid, 448);
   if (tid < 256) sB1[tid] = b1[tid];
   if (tid < 64) sB2[tid] = b2[tid];
   const int lane = tid & 63, wave = tid >> 6;
@@ -538,25 +679,7 @@ __global__ __launch_bounds__(448) void vertex_ca_mlp_kernel(const float* __restr
     float a[32];
     adaln_slots(x, a, GB + (long long)b * gb_stride + inst * 128, hb);
     f32x16 acc2[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[nt][r] = sB2[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb] + x[16 * nt + r];
-#pragma unroll 1
-    for (int ht = 0; ht < 8; ++ht) {
-      f32x16 acc1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc1[r] = sB1[ht * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb];
-      tl_gemm<8, 1, LDW64>(sW1 + ht * 32 * LDW64, a, &acc1, n0, hb);
-      float hreg[16];
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const f32x2 g = gelu_erf2(f32x2{acc1[r], acc1[r + 1]});
-        hreg[r] = g.x;
-        hreg[r + 1] = g.y;
-      }
-      tl_gemm<4, 2, LDW256>(sW2 + ht * 32, hreg, acc2, n0, hb);
-    }
+    ffn_slots<F16>(sW1, sW2, sB1, sB2, sSc, a, x, acc2, n0, hb);
     if (valid) {
       float y[32];
 #pragma unroll
@@ -1129,38 +1252,63 @@ extern "C" int pmce_vertex_ca_f32(const float* xq, const float* vt, const float*
   return pmce_check_launch("vertex_ca");
 }
 
+extern "C" int pmce_adaln_mlp_ex_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* W1,
+                                     const float* b1, const float* W2, const float* b2, float* yout, const float* Wc,
+                                     const float* bc, const float* vt_in, float* vt_out, int B, int split_f16,
+                                     hipStream_t stream) {
+  PMCE_REQUIRE(xin && GB && W1 && b1 && W2 && b2 && (yout || vt_out), "adaln_mlp: null pointer");
+  PMCE_REQUIRE(!vt_out || (Wc && bc && vt_in), "adaln_mlp: coordinate head needs Wc, bc, vt_in");
+  const size_t lds = (size_t)(256 * LDW64 + 64 * LDW256 + 256 + 64 + 32) * sizeof(float);
+  static std::atomic<unsigned long long> attr{0}, attr_s{0};
+  if (split_f16) {
+    PMCE_TRY(pmce_opt_in_lds((const void*)adaln_mlp_kernel<true>, (int)lds, attr_s, "adaln_mlp"));
+    hipLaunchKernelGGL(adaln_mlp_kernel<true>, dim3(mlp_grid(B)), dim3(512), lds, stream, xin, GB, gb_stride, inst, W1, b1, W2, b2,
+                       yout, Wc, bc, vt_in, vt_out, B);
+  } else {
+    PMCE_TRY(pmce_opt_in_lds((const void*)adaln_mlp_kernel<false>, (int)lds, attr, "adaln_mlp"));
+    hipLaunchKernelGGL(adaln_mlp_kernel<false>, dim3(mlp_grid(B)), dim3(512), lds, stream, xin, GB, gb_stride, inst, W1, b1, W2, b2,
+                       yout, Wc, bc, vt_in, vt_out, B);
+  }
+  return pmce_check_launch("adaln_mlp");
+}
 extern "C" int pmce_adaln_mlp_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* W1,
                                   const float* b1, const float* W2, const float* b2, float* yout, const float* Wc,
                                   const float* bc, const float* vt_in, float* vt_out, int B, hipStream_t stream) {
-  PMCE_REQUIRE(xin && GB && W1 && b1 && W2 && b2 && (yout || vt_out), "adaln_mlp: null pointer");
-  PMCE_REQUIRE(!vt_out || (Wc && bc && vt_in), "adaln_mlp: coordinate head needs Wc, bc, vt_in");
-  const size_t lds = (size_t)(256 * LDW64 + 64 * LDW256 + 256 + 64) * sizeof(float);
-  static std::atomic<unsigned long long> attr{0};
-  PMCE_TRY(pmce_opt_in_lds((const void*)adaln_mlp_kernel, (int)lds, attr, "adaln_mlp"));
-  hipLaunchKernelGGL(adaln_mlp_kernel, dim3(mlp_grid(B)), dim3(512), lds, stream, xin, GB, gb_stride, inst, W1, b1, W2, b2,
-                     yout, Wc, bc, vt_in, vt_out, B);
-  return pmce_check_launch("adaln_mlp");
+  return pmce_adaln_mlp_ex_f32(xin, GB, gb_stride, inst, W1, b1, W2, b2, yout, Wc, bc, vt_in, vt_out, B, 0, stream);
 }
 
-extern "C" int pmce_vertex_ca_mlp_f32(const float* xq, const float* vt, const float* Wv3, const float* Eq, const float* Kf,
-                                      const float* s0, const float* Vf, const float* bp, const float* GB, int gb_stride,
-                                      int inst, const float* W1, const float* b1, const float* W2, const float* b2, float* yout,
-                                      float* scratch, int B, int J, hipStream_t stream) {
+extern "C" int pmce_vertex_ca_mlp_ex_f32(const float* xq, const float* vt, const float* Wv3, const float* Eq, const float* Kf,
+                                         const float* s0, const float* Vf, const float* bp, const float* GB, int gb_stride,
+                                         int inst, const float* W1, const float* b1, const float* W2, const float* b2,
+                                         float* yout, float* scratch, int B, int J, int split_f16, hipStream_t stream) {
   PMCE_REQUIRE((xq || (vt && Wv3 && Eq)) && Kf && s0 && Vf && bp && GB && W1 && b1 && W2 && b2 && yout,
                "vertex_ca_mlp: null pointer");
   PMCE_REQUIRE(J >= 1 && J <= 32 && B > 0, "vertex_ca_mlp: J must be in 1..32");
   if (J > 23) {  // one clip's folded operands no longer fit beside the FFN weights: the two-launch form
     PMCE_REQUIRE(scratch, "vertex_ca_mlp: J > 23 needs a [B,431,64] scratch buffer");
     PMCE_TRY(pmce_vertex_ca_f32(xq, vt, Wv3, Eq, Kf, s0, Vf, bp, scratch, B, J, stream));
-    return pmce_adaln_mlp_f32(scratch, GB, gb_stride, inst, W1, b1, W2, b2, yout, nullptr, nullptr, nullptr, nullptr, B, stream);
+    return pmce_adaln_mlp_ex_f32(scratch, GB, gb_stride, inst, W1, b1, W2, b2, yout, nullptr, nullptr, nullptr, nullptr, B, split_f16,
+                                 stream);
   }
-  const size_t lds = (size_t)(256 * LDW64 + 64 * LDW256 + 256 + 64 + 64 + 64 * CAM_VLD + 2 * J * LDW64) * sizeof(float);
-  static std::atomic<unsigned long long> attr{0};
-  PMCE_TRY(pmce_opt_in_lds((const void*)vertex_ca_mlp_kernel, 163840, attr, "vertex_ca_mlp"));
+  const size_t lds = (size_t)(256 * LDW64 + 64 * LDW256 + 256 + 64 + 32 + 64 + 64 * CAM_VLD + 2 * J * LDW64) * sizeof(float);
+  static std::atomic<unsigned long long> attr{0}, attr_s{0};
   const int g = 2 * B < 256 ? 2 * B : 256;
-  hipLaunchKernelGGL(vertex_ca_mlp_kernel, dim3(g), dim3(448), lds, stream, xq, vt, Wv3, Eq, Kf, s0, Vf, bp, GB, gb_stride, inst,
-                     W1, b1, W2, b2, yout, B, J);
+  if (split_f16) {
+    PMCE_TRY(pmce_opt_in_lds((const void*)vertex_ca_mlp_kernel<true>, 163840, attr_s, "vertex_ca_mlp"));
+    hipLaunchKernelGGL(vertex_ca_mlp_kernel<true>, dim3(g), dim3(448), lds, stream, xq, vt, Wv3, Eq, Kf, s0, Vf, bp, GB, gb_stride,
+                       inst, W1, b1, W2, b2, yout, B, J);
+  } else {
+    PMCE_TRY(pmce_opt_in_lds((const void*)vertex_ca_mlp_kernel<false>, 163840, attr, "vertex_ca_mlp"));
+    hipLaunchKernelGGL(vertex_ca_mlp_kernel<false>, dim3(g), dim3(448), lds, stream, xq, vt, Wv3, Eq, Kf, s0, Vf, bp, GB, gb_stride,
+                       inst, W1, b1, W2, b2, yout, B, J);
+  }
   return pmce_check_launch("vertex_ca_mlp");
+}
+extern "C" int pmce_vertex_ca_mlp_f32(const float* xq, const float* vt, const float* Wv3, const float* Eq, const float* Kf,
+                                      const float* s0, const float* Vf, const float* bp, const float* GB, int gb_stride,
+                                      int inst, const float* W1, const float* b1, const float* W2, const float* b2, float* yout,
+                                      float* scratch, int B, int J, hipStream_t stream) {
+  return pmce_vertex_ca_mlp_ex_f32(xq, vt, Wv3, Eq, Kf, s0, Vf, bp, GB, gb_stride, inst, W1, b1, W2, b2, yout, scratch, B, J, 0, stream);
 }
 
 extern "C" int pmce_adaln_qkv_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* Wqkv,

@@ -545,21 +545,21 @@ int vertex_block(pmce_model* m, int k, const float* vt_cur, float* vt_next, int 
   const VertexBlockW& v = m->w.vb[k - 1];
   const int ib = (k - 1) * 6;  // AdaLN instances: vca.normq,normk,normv,norm2, vsa.norm1,norm2
   if (m->fused_ca) {  // CrossAttentionBlock (CoevoDecoder.py:82-87) in one launch, bit-identical to the two below
-    RUN(P_VERTEX_CA_MLP, pmce_vertex_ca_mlp_f32(nullptr, vt_cur, v.vertx_proj_w, v.Eq, w.KF[k - 1], w.S0[k - 1], w.VF[k - 1],
-                                                v.vca_proj_b, w.GB, gbs, ib + 3, v.vca_fc1_w, v.vca_fc1_b, v.vca_fc2_w,
-                                                v.vca_fc2_b, w.F2, w.F1, B, J, stream));
+    RUN(P_VERTEX_CA_MLP, pmce_vertex_ca_mlp_ex_f32(nullptr, vt_cur, v.vertx_proj_w, v.Eq, w.KF[k - 1], w.S0[k - 1], w.VF[k - 1],
+                                                   v.vca_proj_b, w.GB, gbs, ib + 3, v.vca_fc1_w, v.vca_fc1_b, v.vca_fc2_w,
+                                                   v.vca_fc2_b, w.F2, w.F1, B, J, pk(m), stream));
   } else {
     RUN(P_VERTEX_CA, pmce_vertex_ca_f32(nullptr, vt_cur, v.vertx_proj_w, v.Eq, w.KF[k - 1], w.S0[k - 1], w.VF[k - 1],
                                         v.vca_proj_b, w.F1, B, J, stream));
-    RUN(P_ADALN_MLP, pmce_adaln_mlp_f32(w.F1, w.GB, gbs, ib + 3, v.vca_fc1_w, v.vca_fc1_b, v.vca_fc2_w, v.vca_fc2_b, w.F2, nullptr,
-                                        nullptr, nullptr, nullptr, B, stream));
+    RUN(P_ADALN_MLP, pmce_adaln_mlp_ex_f32(w.F1, w.GB, gbs, ib + 3, v.vca_fc1_w, v.vca_fc1_b, v.vca_fc2_w, v.vca_fc2_b, w.F2, nullptr,
+                                           nullptr, nullptr, nullptr, B, pk(m), stream));
   }
   RUN(P_ADALN_QKV, pmce_adaln_qkv_f32(w.F2, w.GB, gbs, ib + 4, v.vsa_qkv_w, v.vsa_qkv_b, w.QKV, B,
                                       stream));
   RUN(P_VERTEX_SA, pmce_vertex_sa_f32(w.F2, w.QKV, v.vsa_proj_w, v.vsa_proj_b, w.F1, B, stream));
-  RUN(P_ADALN_MLP, pmce_adaln_mlp_f32(w.F1, w.GB, gbs, ib + 5, v.vsa_fc1_w, v.vsa_fc1_b,
-                                      v.vsa_fc2_w, v.vsa_fc2_b, nullptr,
-                                      v.vcoor_w, v.vcoor_b, vt_cur, vt_next, B, stream));
+  RUN(P_ADALN_MLP, pmce_adaln_mlp_ex_f32(w.F1, w.GB, gbs, ib + 5, v.vsa_fc1_w, v.vsa_fc1_b,
+                                         v.vsa_fc2_w, v.vsa_fc2_b, nullptr,
+                                         v.vcoor_w, v.vcoor_b, vt_cur, vt_next, B, pk(m), stream));
   return PMCE_OK;
 }
 

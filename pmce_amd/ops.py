@@ -131,7 +131,7 @@ def cross_attn_vertex(xq, xk, xv, g, sd, p):
     return out
 
 
-def cross_attn_block_vertex(xq, xk, xv, g, sd, p):
+def cross_attn_block_vertex(xq, xk, xv, g, sd, p, split_f16=False):
     """The whole vertex-stream CrossAttentionBlock in one launch (CoevoDecoder.py:82-87), p = '...vertx_CA_FFN':
     xq + CA(...) then + Mlp(AdaLN_2(.)).  Bit-identical to cross_attn_vertex followed by adaln_mlp."""
     lib = _lib.load()
@@ -152,13 +152,13 @@ def cross_attn_block_vertex(xq, xk, xv, g, sd, p):
     m = [_c(sd[p + k]) for k in (".mlp.fc1.weight", ".mlp.fc1.bias", ".mlp.fc2.weight", ".mlp.fc2.bias")]
     out = torch.empty_like(xq)
     scratch = torch.empty_like(xq) if J > 23 else None
-    _lib.check(lib.pmce_vertex_ca_mlp_f32(P(xq), None, None, None, P(Kf), P(s0), P(Vf), P(w["proj.bias"]), P(GB), GB.shape[1],
-                                          3, P(m[0]), P(m[1]), P(m[2]), P(m[3]), P(out), P(scratch), B, J, _st()),
-               "vertex_ca_mlp")
+    _lib.check(lib.pmce_vertex_ca_mlp_ex_f32(P(xq), None, None, None, P(Kf), P(s0), P(Vf), P(w["proj.bias"]), P(GB), GB.shape[1],
+                                             3, P(m[0]), P(m[1]), P(m[2]), P(m[3]), P(out), P(scratch), B, J,
+                                             1 if split_f16 else 0, _st()), "vertex_ca_mlp")
     return out
 
 
-def adaln_mlp(x, g, sd, p_norm, p_mlp, coor=None, vt_in=None, want_features=True):
+def adaln_mlp(x, g, sd, p_norm, p_mlp, coor=None, vt_in=None, want_features=True, split_f16=False):
     """x + Mlp(AdaLN(x)) on [B,431,64]; optional coordinate head (Wc[3,64], bc[3]) + vt_in residual."""
     lib = _lib.load()
     x = _c(x)
@@ -172,8 +172,8 @@ def adaln_mlp(x, g, sd, p_norm, p_mlp, coor=None, vt_in=None, want_features=True
         Wc, bc = _c(coor[0]), _c(coor[1])
         vt_in = _c(vt_in)
         vt_out = torch.empty_like(vt_in)
-    _lib.check(lib.pmce_adaln_mlp_f32(P(x), P(GB), GB.shape[1], 0, P(w[0]), P(w[1]), P(w[2]), P(w[3]), P(y), P(Wc), P(bc),
-                                      P(vt_in), P(vt_out), B, _st()), "adaln_mlp")
+    _lib.check(lib.pmce_adaln_mlp_ex_f32(P(x), P(GB), GB.shape[1], 0, P(w[0]), P(w[1]), P(w[2]), P(w[3]), P(y), P(Wc), P(bc),
+                                         P(vt_in), P(vt_out), B, 1 if split_f16 else 0, _st()), "adaln_mlp")
     return y, vt_out
 
 

@@ -304,8 +304,10 @@ def test_cross_attn_block_vertex_fused(golden):
         with torch.no_grad():
             ref3 = O.cross_attention_block(xq3, xk3, xk3, g3, sd, p, 2)
         e_or, e_two = maxabs(fused, ref3), maxabs(fused, two)
-        print(f"fused CrossAttentionBlock J={J}: vs oracle {e_or:.2e}; vs vertex_ca + adaln_mlp {e_two:.2e}")
-        assert e_or < 2e-5 and e_two < 5e-6
+        fused16 = ops.cross_attn_block_vertex(xq3.to(dev()), xk3.to(dev()), xk3.to(dev()), g3.to(dev()), sdd, p, split_f16=True)
+        e_16 = maxabs(fused16, ref3)          # the FFN in the three-product f16 form
+        print(f"fused CrossAttentionBlock J={J}: vs oracle {e_or:.2e} (f16-split FFN {e_16:.2e}); vs vertex_ca + adaln_mlp {e_two:.2e}")
+        assert e_or < 2e-5 and e_two < 5e-6 and e_16 < 2e-5
     print(f"fused CrossAttentionBlock vs reference fixture {e_ref:.2e}")
     assert e_ref < 2e-5
 
@@ -328,6 +330,12 @@ def test_adaln_mlp(golden):
     e1, e2 = maxabs(y, ref), maxabs(vt_out, ref_vt)
     print(f"adaln_mlp: features {e1:.2e}, coords {e2:.2e}")
     assert e1 < 2e-5 and e2 < 2e-5
+    y16, vt16 = ops.adaln_mlp(x.to(dev()), g.to(dev()), sdd, p + ".norm2", p + ".mlp",
+                              coor=(sdd[BLK + ".proj_vertx_feat2coor.weight"], sdd[BLK + ".proj_vertx_feat2coor.bias"]),
+                              vt_in=vt.to(dev()), split_f16=True)
+    e3, e4 = maxabs(y16, ref), maxabs(vt16, ref_vt)
+    print(f"adaln_mlp, FFN in the three-product f16 form: features {e3:.2e}, coords {e4:.2e}")
+    assert e3 < 2e-5 and e4 < 2e-5
 
 
 def test_vertex_self_attn(golden):
