@@ -170,7 +170,7 @@ def pmc_traffic_per_launch(kernel, C):
     return None, None
 
 
-def north_star_record(kernel_ms, launches, B, J):
+def north_star_record(kernel_ms, launches, B, J, f16_ffn=False):
     """The CoEvoDecoder vertex<-joint cross-attention (north_star's kernel) against its two floors.  After round 2 it is
     fused with its FFN (`vertex_ca_mlp`); both floors are printed: HBM = SURVEY §8a(a8)'s 229,376 B per clip*direction*block
     at the 8 TB/s peak, MFMA = the matrix instructions the fused kernel must issue (per 32-vertex wave tile: 64 score +
@@ -182,15 +182,19 @@ def north_star_record(kernel_ms, launches, B, J):
     ms = kernel_ms[name] / n
     byt = 229376.0 * B
     tiles = B * 14
-    mfma_per_tile = 64 + 16 * ((J + 7) // 8) + (512 if name == "vertex_ca_mlp" else 0)
+    # matrix-pipe cycles per 32-vertex wave tile: scores + output on the fp32 pipe (64 cycles per instruction), the FFN either
+    # 512 fp32 instructions or - in the split-f16 mode (batches of 48 clips and more) - 192 f16 ones of 32 cycles
+    ffn_cycles = 0 if name != "vertex_ca_mlp" else (192 * 32 if f16_ffn else 512 * 64)
+    cyc_per_tile = (64 + 16 * ((J + 7) // 8)) * 64 + ffn_cycles
     t_hbm = byt / (PEAK_HBM_GBS * 1e9) * 1e3
-    t_mfma = tiles * mfma_per_tile * 64 / N_SIMD / (CLOCK_GHZ * 1e9) * 1e3
+    t_mfma = tiles * cyc_per_tile / N_SIMD / (CLOCK_GHZ * 1e9) * 1e3
     floor = max(t_hbm, t_mfma)
     ach = byt / (ms * 1e-3) / 1e9
     return {"kernel": name, "bound": "hbm" if t_hbm >= t_mfma else "mfma", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
             "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "bytes_per_clip_dir_block": 229376,
             "avg_launch_ms": round(ms, 5), "hbm_floor_ms": round(t_hbm, 5), "mfma_floor_ms": round(t_mfma, 5),
-            "frac_of_floor": round(floor / ms, 4)}
+            "frac_of_floor": round(floor / ms, 4),
+            "ffn_arithmetic": "3 x f16 MFMA per fp32 product" if (f16_ffn and name == "vertex_ca_mlp") else "fp32 MFMA"}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -329,7 +333,7 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
             ach = work / secs / 1e9
             roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(ach / PEAK_HBM_GBS, 4), **common}
-    rec.update({"roofline": roofline, "roofline_cross_attention": north_star_record(kernel_ms, launches, B, J),
+    rec.update({"roofline": roofline, "roofline_cross_attention": north_star_record(kernel_ms, launches, B, J, f16_ffn=(gemm_mode == "split_f16" and B >= 48)),
                 "kernel_ms_per_step": kernel_ms, "launches_per_step": launches,
                 "kernel_ms_total_single_stream": round(sum(kernel_ms.values()), 4), "gemm_mode": gemm_mode})
     return rec, model, pipe, inputs, sd

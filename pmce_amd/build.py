@@ -13,6 +13,11 @@ CSRC = osp.join(HERE, "csrc")
 LIB = osp.join(HERE, "libpmce_hip.so")
 SOURCES = ["common.cpp", "gemm_f32.hip", "gemm_split_f16.hip", "lifter.hip", "gru.hip", "coevo.hip", "metrics.hip", "dbg_victims.hip", "model.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# Files whose kernels issue f16 matrix instructions: on MI355X those disturb packed-fp32 (v_pk_*_f32) arithmetic of OTHER waves on
+# the same CU - including waves of the same kernel that are in a vector phase while their neighbours are in the
+# matrix phase.  Across kernels the model serialises; inside these kernels no packed-fp32 instruction is generated at all.
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+FILE_FLAGS = {"coevo.hip": NO_PACKED_FP32, "gemm_split_f16.hip": NO_PACKED_FP32, "gru.hip": NO_PACKED_FP32}
 
 
 def _hipcc():
@@ -40,12 +45,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
     def compile_one(src):
         obj = osp.join(objdir, osp.splitext(src)[0] + ".o")
         extra = os.environ.get("PMCE_EXTRA_HIPCC_FLAGS", "").split()
-        cmd = [hipcc, *FLAGS, *extra, "-x", "hip", "-c", osp.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(src, []), *extra, "-x", "hip", "-c", osp.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
-        if verbose and r.stderr.strip():
-            sys.stderr.write(r.stderr)
+        # the host pass of a -target-feature meant for the device prints "not a recognized feature for this target (ignoring)"
+        err = "".join(l for l in r.stderr.splitlines(True) if "packed-fp32-ops' is not a recognized feature" not in l)
+        if verbose and err.strip():
+            sys.stderr.write(err)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:

@@ -105,6 +105,7 @@ struct pmce_model {
   // which the two-stream schedule (fp32 mode only, see two_streams) hides under the pose lifter - worth more than the GEMM time
   // the f16 form saves there (B = 1: 1.8 ms against 2.7 ms).  PMCE_SPLIT_MIN_BATCH at create.
   int split_min_batch = 48;
+  bool ffn_f16 = true;
   bool split_now = false;  // decision for the call in progress (set by check_ws, the first thing every entry point does)
   // regressor (optional)
   const int* jr_indptr = nullptr;
@@ -345,6 +346,8 @@ int lgemm(const pmce_model* m, const float* A, const float* W, const SplitW& sw,
 // In the split-f16 form the producers of the lifter blocks' GEMM operands (LayerNorm -> XN, attention -> AO, fc1 -> Hid) write
 // them pre-split (hi | lo*2^11 f16 planes in the bytes of the fp32 row): the products then spend no vector work on splitting.
 inline int pk(const pmce_model* m) { return m->split_now ? 1 : 0; }
+// the decoder's FFNs in the same form (PMCE_FFN_F16=0 at create keeps them on the fp32 pipe: an A/B knob)
+inline int pkf(const pmce_model* m) { return m->split_now && m->ffn_f16 ? 1 : 0; }
 
 // ---- GraphormerNet.forward --------------------------------------------------------------------------------
 // Everything up to and including SpatialBlocks[0] is PER FRAME (its attention runs over the J joints of one frame,
@@ -547,19 +550,19 @@ int vertex_block(pmce_model* m, int k, const float* vt_cur, float* vt_next, int 
   if (m->fused_ca) {  // CrossAttentionBlock (CoevoDecoder.py:82-87) in one launch, bit-identical to the two below
     RUN(P_VERTEX_CA_MLP, pmce_vertex_ca_mlp_ex_f32(nullptr, vt_cur, v.vertx_proj_w, v.Eq, w.KF[k - 1], w.S0[k - 1], w.VF[k - 1],
                                                    v.vca_proj_b, w.GB, gbs, ib + 3, v.vca_fc1_w, v.vca_fc1_b, v.vca_fc2_w,
-                                                   v.vca_fc2_b, w.F2, w.F1, B, J, pk(m), stream));
+                                                   v.vca_fc2_b, w.F2, w.F1, B, J, pkf(m), stream));
   } else {
     RUN(P_VERTEX_CA, pmce_vertex_ca_f32(nullptr, vt_cur, v.vertx_proj_w, v.Eq, w.KF[k - 1], w.S0[k - 1], w.VF[k - 1],
                                         v.vca_proj_b, w.F1, B, J, stream));
     RUN(P_ADALN_MLP, pmce_adaln_mlp_ex_f32(w.F1, w.GB, gbs, ib + 3, v.vca_fc1_w, v.vca_fc1_b, v.vca_fc2_w, v.vca_fc2_b, w.F2, nullptr,
-                                           nullptr, nullptr, nullptr, B, pk(m), stream));
+                                           nullptr, nullptr, nullptr, B, pkf(m), stream));
   }
   RUN(P_ADALN_QKV, pmce_adaln_qkv_f32(w.F2, w.GB, gbs, ib + 4, v.vsa_qkv_w, v.vsa_qkv_b, w.QKV, B,
                                       stream));
   RUN(P_VERTEX_SA, pmce_vertex_sa_f32(w.F2, w.QKV, v.vsa_proj_w, v.vsa_proj_b, w.F1, B, stream));
   RUN(P_ADALN_MLP, pmce_adaln_mlp_ex_f32(w.F1, w.GB, gbs, ib + 5, v.vsa_fc1_w, v.vsa_fc1_b,
                                          v.vsa_fc2_w, v.vsa_fc2_b, nullptr,
-                                         v.vcoor_w, v.vcoor_b, vt_cur, vt_next, B, pk(m), stream));
+                                         v.vcoor_w, v.vcoor_b, vt_cur, vt_next, B, pkf(m), stream));
   return PMCE_OK;
 }
 
@@ -732,6 +735,7 @@ int pmce_model_create(int num_joint, int embed_dim, int depth, pmce_model** out)
   m->fused_ca = pmce_env_int("PMCE_VERTEX_FUSED", 1) != 0;
   m->split_gemm = pmce_env_int("PMCE_SPLIT_F16", 1) != 0;
   m->split_min_batch = pmce_env_int("PMCE_SPLIT_MIN_BATCH", 48);
+  m->ffn_f16 = pmce_env_int("PMCE_FFN_F16", 1) != 0;
   build_names(m);
   *out = m;
   return PMCE_OK;
