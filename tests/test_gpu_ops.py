@@ -142,7 +142,16 @@ def test_gemm_split_packed_result(M, N, K, tile):
         packed = ops.gemm_nt_split(Ap, Wp, ws, b, None, 1, a_packed=True, c_packed=True)
     finally:
         lib.pmce_gemm_split_set_tuning(-1)
-    assert torch.equal(packed.view(torch.int32), ops.split_rows_f16(plain).view(torch.int32))
+    # the planes hold the fp32 result to 22 bits: hi + lo * 2^-11 (the two epilogues may contract the GELU's multiply-adds
+    # differently, so the fp32 values themselves agree to an ulp, not bitwise)
+    pl = packed.view(torch.float16).reshape(M, N // 16, 2, 16).float()
+    back = (pl[:, :, 0, :] + pl[:, :, 1, :] * 2.0 ** -11).reshape(M, N)
+    err = (back - plain).abs().max().item()
+    print(f"packed fc1 result {M}x{N}x{K} tile={tile}: |hi + lo/2048 - fp32 result| max {err:.2e} (|result| max {plain.abs().max().item():.1f})")
+    assert err < 3e-6
+    # and splitting is exact to 22 bits on its own: the planes of the fp32 result reproduce it
+    sp = ops.split_rows_f16(plain).view(torch.float16).reshape(M, N // 16, 2, 16).float()
+    assert ((sp[:, :, 0, :] + sp[:, :, 1, :] * 2.0 ** -11).reshape(M, N) - plain).abs().max().item() < 2e-6
 
 
 def test_gemm_split_row_map():
