@@ -258,6 +258,10 @@ int pmce_adaln_qkv_f32(const float* xin, const float* GB, int gb_stride, int ins
 /* y = x + proj(softmax(q k^T/sqrt(32)) v), 2 heads, 431x431 per clip (CoevoDecoder.py:118-131,103). */
 int pmce_vertex_sa_f32(const float* xin, const float* qkv, const float* Wp, const float* bp, float* yout, int B,
                        pmce_stream_t stream);
+/* The same with split_f16 != 0: both contractions (q k^T and p v) as three f16 matrix products of (hi, lo) halves, fp32
+ * accumulate (K, V split while their tile is staged; the 64x64 projection stays fp32).  Same exclusivity rule as the split GEMM. */
+int pmce_vertex_sa_ex_f32(const float* xin, const float* qkv, const float* Wp, const float* bp, float* yout, int B,
+                          int split_f16, pmce_stream_t stream);
 /* k|v of the joint<-vertex CrossAttention for the 431 vertex tokens: kv[B,431,128] (CoevoDecoder.py:52-53,83,183). */
 int pmce_tokens_kv_f32(const float* xk, const float* xv, const float* vt, const float* Wv3, const float* Ev,
                        const float* Wv2j, const float* Ek, const float* GB, int gb_stride, int ik, int iv, const float* Wk,

@@ -74,6 +74,7 @@ PROTOTYPES = {
     "pmce_vertex_ca_mlp_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _s],
     "pmce_adaln_qkv_f32": [_f, _f, _i, _i, _f, _f, _f, _i, _s],
     "pmce_vertex_sa_f32": [_f, _f, _f, _f, _f, _i, _s],
+    "pmce_vertex_sa_ex_f32": [_f, _f, _f, _f, _f, _i, _i, _s],
     "pmce_tokens_kv_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _f, _f, _f, _i, _s],
     "pmce_joint_stream_f32": [_f, _f, _f, _f, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_int), _f, _f, _f, _i, _i, _i, _s],
     "pmce_build_final_operand_f32": [_f, _f, _f, _i, _i, _s],

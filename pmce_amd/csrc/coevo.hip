@@ -767,11 +767,18 @@ __global__ __launch_bounds__(256) void adaln_qkv_kernel(const float* __restrict_
 // ======================================================================================================
 #define SA_KLD 68
 #define SA_VLD 64
+#define SA_VTLD 36  // F16 form: V^T rows (one channel, 32 keys as 2 k-steps x 2 lane halves x (hi | lo) x 8 f16 = 32 floats) + 4
+// F16 = the three-product f16 form for both contractions (scores and output; the 64x64 projection stays on the fp32 pipe).  The
+// key tile is split into f16 (hi, lo*2^11) planes WHILE it is staged: K rows as A fragments in the slot order of the head's 32
+// channels, V TRANSPOSED (rows = channels, 8 keys per fragment) so that it is the A operand of O^T += V^T P^T; q is split once,
+// P (scaled by 2^14: every probability that matters is a normal f16) per key tile.  Two accumulators per product (main / corr,
+// corr carries the 2^11): 24 matrix instructions of 32 cycles per key tile instead of 64 of 64.
+template <bool F16>
 __global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict__ xin, const float* __restrict__ qkv,
                                                         const float* __restrict__ Wp, const float* __restrict__ bp,
                                                         float* __restrict__ yout) {
   __shared__ __attribute__((aligned(16))) float sK[2][32 * SA_KLD];
-  __shared__ __attribute__((aligned(16))) float sVv[2][32 * SA_VLD];
+  __shared__ __attribute__((aligned(16))) float sVv[2][F16 ? 64 * SA_VTLD : 32 * SA_VLD];
   __shared__ __attribute__((aligned(16))) float sWp[64 * LDW64];
   const int b = blockIdx.y, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -799,10 +806,32 @@ __global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict_
       const int idx = tid + it * 448;
       if (idx < 1024) {
         const int rr = idx >> 5, c4 = idx & 31;
-        if (c4 < 16)
-          *reinterpret_cast<f32x4*>(&sK[buf][rr * SA_KLD + 4 * c4]) = pre[it];
-        else
-          *reinterpret_cast<f32x4*>(&sVv[buf][rr * SA_VLD + 4 * (c4 - 16)]) = pre[it];
+        if constexpr (!F16) {
+          if (c4 < 16)
+            *reinterpret_cast<f32x4*>(&sK[buf][rr * SA_KLD + 4 * c4]) = pre[it];
+          else
+            *reinterpret_cast<f32x4*>(&sVv[buf][rr * SA_VLD + 4 * (c4 - 16)]) = pre[it];
+        } else {
+          tl_f16x4 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hi[e] = (_Float16)pre[it][e];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lo[e] = (_Float16)((pre[it][e] - (float)hi[e]) * 2048.0f);
+          if (c4 < 16) {  // K: channels 4 c4 .. +3 of key rr -> head c4 / 8, k-step (c4 % 8) / 4, group c4 % 4 (stage_weight_split's order)
+            const int h = c4 >> 3, ks = (c4 >> 2) & 1, g = c4 & 3;
+            _Float16* d = reinterpret_cast<_Float16*>(&sK[buf][rr * SA_KLD + ((h * 2 + ks) * 2 + (g & 1)) * 8]) + (g >> 1) * 4;
+            *reinterpret_cast<tl_f16x4*>(d) = hi;
+            *reinterpret_cast<tl_f16x4*>(d + 8) = lo;
+          } else {  // V^T: key rr -> k-step rr / 16, group (rr % 16) / 4, element (rr % 4) (+ 4 for groups 2, 3); one 16-bit store per channel
+            const int ks = rr >> 4, g = (rr >> 2) & 3, e = (g >> 1) * 4 + (rr & 3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              _Float16* d = reinterpret_cast<_Float16*>(&sVv[buf][(4 * (c4 - 16) + i) * SA_VTLD + (ks * 2 + (g & 1)) * 8]) + e;
+              d[0] = hi[i];
+              d[8] = lo[i];
+            }
+          }
+        }
       }
     }
   };
@@ -817,15 +846,22 @@ __global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict_
   const float scale = 0.17677669529663688110f * 1.44269504088896340736f;
 #pragma unroll
   for (int s = 0; s < 32; ++s) q[s] *= scale;
+  tl_f16x8 qhi[2][2], qlo[2][2];  // [head][k-step]
+  if constexpr (F16) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) split_slots8(q + 16 * h + 8 * ks, qhi[h][ks], qlo[h][ks]);
+  }
 
-  f32x16 O[2];
+  f32x16 O[2], Oc[2];  // Oc: the f16 form's correction accumulator (carries 2^11)
   float mrun[2], lrun[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     mrun[h] = -INFINITY;
     lrun[h] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) O[h][r] = 0.f;
+    for (int r = 0; r < 16; ++r) O[h][r] = Oc[h][r] = 0.f;
   }
 
   gload(0);
@@ -839,7 +875,23 @@ __global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict_
       f32x16 S;
 #pragma unroll
       for (int r = 0; r < 16; ++r) S[r] = 0.f;
-      tl_gemm<4, 1, SA_KLD>(&sK[buf][32 * h], q + 16 * h, &S, n0, hb);
+      if constexpr (!F16) {
+        tl_gemm<4, 1, SA_KLD>(&sK[buf][32 * h], q + 16 * h, &S, n0, hb);
+      } else {
+        f32x16 Sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Sc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const float* kp = &sK[buf][n0 * SA_KLD + ((h * 2 + ks) * 2 + hb) * 8];
+          const tl_f16x8 khi = *reinterpret_cast<const tl_f16x8*>(kp), klo = *reinterpret_cast<const tl_f16x8*>(kp + 4);
+          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qhi[h][ks], S, 0, 0, 0);
+          Sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo, qhi[h][ks], Sc, 0, 0, 0);
+          Sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qlo[h][ks], Sc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = fmaf(Sc[r], 0.00048828125f, S[r]);
+      }
       float mt = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -861,11 +913,29 @@ __global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict_
       mrun[h] = mn;
 #pragma unroll
       for (int r = 0; r < 16; ++r) O[h][r] *= corr;
-      const float* vb = &sVv[buf][4 * hb * SA_VLD + 32 * h + n0];
+      if constexpr (!F16) {
+        const float* vb = &sVv[buf][4 * hb * SA_VLD + 32 * h + n0];
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const float a = vb[((s & 3) + 8 * (s >> 2)) * SA_VLD];
-        O[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pr[s], O[h], 0, 0, 0);
+        for (int s = 0; s < 16; ++s) {
+          const float a = vb[((s & 3) + 8 * (s >> 2)) * SA_VLD];
+          O[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pr[s], O[h], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          Oc[h][r] *= corr;
+          pr[r] *= 16384.0f;  // 2^14 (undone with 1/l below): probabilities down to 4e-9 stay normal f16 numbers
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          tl_f16x8 phi, plo;
+          split_slots8(pr + 8 * ks, phi, plo);
+          const float* vp = &sVv[buf][(32 * h + n0) * SA_VTLD + (ks * 2 + hb) * 8];
+          const tl_f16x8 vhi = *reinterpret_cast<const tl_f16x8*>(vp), vlo = *reinterpret_cast<const tl_f16x8*>(vp + 4);
+          O[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, phi, O[h], 0, 0, 0);
+          Oc[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo, phi, Oc[h], 0, 0, 0);
+          Oc[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, plo, Oc[h], 0, 0, 0);
+        }
       }
     }
     if (jt + 1 < NTILE) lstore(buf ^ 1);
@@ -874,9 +944,9 @@ __global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict_
   float att[32];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const float inv = 1.0f / lrun[h];
+    const float inv = (F16 ? 6.103515625e-05f : 1.0f) / lrun[h];  // 2^-14 undoes the scale of P
 #pragma unroll
-    for (int r = 0; r < 16; ++r) att[16 * h + r] = O[h][r] * inv;
+    for (int r = 0; r < 16; ++r) att[16 * h + r] = (F16 ? fmaf(Oc[h][r], 0.00048828125f, O[h][r]) : O[h][r]) * inv;
   }
   float x[32];
   load_slots(xin + tok * 64, x, hb);
@@ -1318,11 +1388,16 @@ extern "C" int pmce_adaln_qkv_f32(const float* xin, const float* GB, int gb_stri
   return pmce_check_launch("adaln_qkv");
 }
 
+extern "C" int pmce_vertex_sa_ex_f32(const float* xin, const float* qkv, const float* Wp, const float* bp, float* yout, int B,
+                                     int split_f16, hipStream_t stream) {
+  PMCE_REQUIRE(xin && qkv && Wp && bp && yout && B > 0, "vertex_sa: null pointer");
+  if (split_f16) hipLaunchKernelGGL(vertex_sa_kernel<true>, dim3(2, B), dim3(448), 0, stream, xin, qkv, Wp, bp, yout);
+  else hipLaunchKernelGGL(vertex_sa_kernel<false>, dim3(2, B), dim3(448), 0, stream, xin, qkv, Wp, bp, yout);
+  return pmce_check_launch("vertex_sa");
+}
 extern "C" int pmce_vertex_sa_f32(const float* xin, const float* qkv, const float* Wp, const float* bp, float* yout, int B,
                                   hipStream_t stream) {
-  PMCE_REQUIRE(xin && qkv && Wp && bp && yout && B > 0, "vertex_sa: null pointer");
-  hipLaunchKernelGGL(vertex_sa_kernel, dim3(2, B), dim3(448), 0, stream, xin, qkv, Wp, bp, yout);
-  return pmce_check_launch("vertex_sa");
+  return pmce_vertex_sa_ex_f32(xin, qkv, Wp, bp, yout, B, 0, stream);
 }
 
 extern "C" int pmce_tokens_kv_f32(const float* xk, const float* xv, const float* vt, const float* Wv3, const float* Ev,

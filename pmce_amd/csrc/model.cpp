@@ -559,7 +559,7 @@ int vertex_block(pmce_model* m, int k, const float* vt_cur, float* vt_next, int 
   }
   RUN(P_ADALN_QKV, pmce_adaln_qkv_f32(w.F2, w.GB, gbs, ib + 4, v.vsa_qkv_w, v.vsa_qkv_b, w.QKV, B,
                                       stream));
-  RUN(P_VERTEX_SA, pmce_vertex_sa_f32(w.F2, w.QKV, v.vsa_proj_w, v.vsa_proj_b, w.F1, B, stream));
+  RUN(P_VERTEX_SA, pmce_vertex_sa_ex_f32(w.F2, w.QKV, v.vsa_proj_w, v.vsa_proj_b, w.F1, B, pkf(m), stream));
   RUN(P_ADALN_MLP, pmce_adaln_mlp_ex_f32(w.F1, w.GB, gbs, ib + 5, v.vsa_fc1_w, v.vsa_fc1_b,
                                          v.vsa_fc2_w, v.vsa_fc2_b, nullptr,
                                          v.vcoor_w, v.vcoor_b, vt_cur, vt_next, B, pkf(m), stream));

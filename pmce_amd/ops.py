@@ -177,8 +177,9 @@ def adaln_mlp(x, g, sd, p_norm, p_mlp, coor=None, vt_in=None, want_features=True
     return y, vt_out
 
 
-def vertex_self_attn(x, g, sd, p):
-    """x + SA(AdaLN(x)) on [B,431,64], 2 heads (first line of Block.forward, CoevoDecoder.py:103); p = '...vertx_SA_FFN'."""
+def vertex_self_attn(x, g, sd, p, split_f16=False):
+    """x + SA(AdaLN(x)) on [B,431,64], 2 heads (first line of Block.forward, CoevoDecoder.py:103); p = '...vertx_SA_FFN'.
+    split_f16: the attention's two contractions as three f16 matrix products each."""
     lib = _lib.load()
     x = _c(x)
     B = x.shape[0]
@@ -187,8 +188,8 @@ def vertex_self_attn(x, g, sd, p):
     _lib.check(lib.pmce_adaln_qkv_f32(P(x), P(GB), GB.shape[1], 0, P(_c(sd[p + ".attn.qkv.weight"])),
                                       P(_c(sd[p + ".attn.qkv.bias"])), P(qkv), B, _st()), "adaln_qkv")
     y = torch.empty_like(x)
-    _lib.check(lib.pmce_vertex_sa_f32(P(x), P(qkv), P(_c(sd[p + ".attn.proj.weight"])), P(_c(sd[p + ".attn.proj.bias"])),
-                                      P(y), B, _st()), "vertex_sa")
+    _lib.check(lib.pmce_vertex_sa_ex_f32(P(x), P(qkv), P(_c(sd[p + ".attn.proj.weight"])), P(_c(sd[p + ".attn.proj.bias"])),
+                                         P(y), B, int(split_f16), _st()), "vertex_sa")
     return y, qkv
 
 

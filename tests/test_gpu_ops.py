@@ -347,14 +347,15 @@ def test_adaln_mlp(golden):
     assert e3 < 2e-5 and e4 < 2e-5
 
 
-def test_vertex_self_attn(golden):
+@pytest.mark.parametrize("split_f16", [False, True])
+def test_vertex_self_attn(golden, split_f16):
     from oracle import pmce_oracle as O
     from pmce_amd import ops
     sd = cached_state_dict(17, 256)
     p = BLK + ".vertx_SA_FFN"
     sdd = sd_dev(sd, p)
     g, xv, _ = _mod_inputs()
-    y, qkv = ops.vertex_self_attn(xv.to(dev()), g.to(dev()), sdd, p)
+    y, qkv = ops.vertex_self_attn(xv.to(dev()), g.to(dev()), sdd, p, split_f16=split_f16)
     with torch.no_grad():
         a = O.ada_layer_norm(xv, g, sd, p + ".norm1", torch.float32)
         ref_qkv = O.linear(a, sd, p + ".attn.qkv", torch.float32)
