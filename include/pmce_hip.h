@@ -175,6 +175,10 @@ int pmce_gemm_split_set_skew(int units);
  * MI355X - the reason the split-f16 mode runs every kernel of a forward on one stream.  bad4: 4 unsigned counters. */
 int pmce_dbg_victim(int kind, unsigned* bad4, int blocks, int iters, const float* table, pmce_stream_t stream);
 int pmce_dbg_mfma_spin(int kind, float* sink, int blocks, int iters, pmce_stream_t stream);
+/* Diagnostic: one 32x32x16 f16 matrix instruction with A = a, B = b everywhere; out2[0] = its result (16 a b if subnormal f16
+ * inputs are read as they are - what pmce_vertex_sa_ex_f32's f16 form relies on for the lo halves of small k / v elements),
+ * out2[1] = a as f16. */
+int pmce_dbg_mfma_subnormal(float a, float b, float* out2, pmce_stream_t stream);
 
 /* PoseEstimation.py:78-81 — x[tok] = joint_embed(pose2d) + imgfeat_embed(img_feat)[b,t] + spatial_pos[j]. */
 int pmce_embed_tokens_f32(const float* pose2d, const float* E, const float* Wje, const float* bje, const float* spos,

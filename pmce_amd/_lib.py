@@ -56,6 +56,7 @@ PROTOTYPES = {
     "pmce_gemm_split_set_tuning": [_i],
     "pmce_dbg_victim": [_i, _f, _i, _i, _f, _s],
     "pmce_dbg_mfma_spin": [_i, _f, _i, _i, _s],
+    "pmce_dbg_mfma_subnormal": [_fl, _fl, _f, _s],
     "pmce_gemm_split_set_skew": [_i],
     "pmce_embed_tokens_f32": [_f, _f, _f, _f, _f, _f, _l, _i, _i, _s],
     "pmce_ln_chain_f32": [_f, _l, _i, _f, _f, _fl, _f, _i, _i, _f, _f, _f, _fl, _f, _s],

@@ -348,6 +348,35 @@ __device__ __forceinline__ void split_slots8(const float* x, tl_f16x8& hi, tl_f1
   for (int e = 0; e < 8; ++e) lo[e] = (_Float16)((x[e] - (float)hi[e]) * 2048.0f);
 }
 
+// the same with lo at its true magnitude (for operands that carry their own power of two).  lo = rne16(x - hi) is one mixed-precision
+// multiply-add per element (v_fma_mix{lo,hi}_f16: fp32 x * 1.0 - f16 hi, rounded to f16) instead of convert back / subtract / convert.
+typedef _Float16 tl_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_plain(float x0, float x1, tl_f16x2& hi, tl_f16x2& lo) {
+  hi[0] = (_Float16)x0;
+  hi[1] = (_Float16)x1;
+  const unsigned H = __builtin_bit_cast(unsigned, hi);
+  unsigned L;
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(L) : "v"(x0), "v"(H));
+  asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(L) : "v"(x1), "v"(H));
+  lo = __builtin_bit_cast(tl_f16x2, L);
+}
+__device__ __forceinline__ void split_slots8_plain(const float* x, tl_f16x8& hi, tl_f16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    tl_f16x2 h, l;
+    split_pair_plain(x[e], x[e + 1], h, l);
+    hi[e] = h[0], hi[e + 1] = h[1];
+    lo[e] = l[0], lo[e + 1] = l[1];
+  }
+}
+__device__ __forceinline__ void split4_plain(float x0, float x1, float x2, float x3, tl_f16x4& hi, tl_f16x4& lo) {
+  tl_f16x2 h0, l0, h1, l1;
+  split_pair_plain(x0, x1, h0, l0);
+  split_pair_plain(x2, x3, h1, l1);
+  hi = tl_f16x4{h0[0], h0[1], h1[0], h1[1]};
+  lo = tl_f16x4{l0[0], l0[1], l1[0], l1[1]};
+}
+
 // a: AdaLN output of the tile (32 slots); x: the residual input; returns y = x + fc2(gelu(fc1(a))) in acc2 (D layout = slot layout)
 template <bool F16>
 __device__ __forceinline__ void ffn_slots(const float* sW1, const float* sW2, const float* sB1, const float* sB2, const float* sSc,
@@ -769,10 +798,14 @@ __global__ __launch_bounds__(256) void adaln_qkv_kernel(const float* __restrict_
 #define SA_VLD 64
 #define SA_VTLD 36  // F16 form: V^T rows (one channel, 32 keys as 2 k-steps x 2 lane halves x (hi | lo) x 8 f16 = 32 floats) + 4
 // F16 = the three-product f16 form for both contractions (scores and output; the 64x64 projection stays on the fp32 pipe).  The
-// key tile is split into f16 (hi, lo*2^11) planes WHILE it is staged: K rows as A fragments in the slot order of the head's 32
+// key tile is split into f16 (hi, lo) planes WHILE it is staged: K rows as A fragments in the slot order of the head's 32
 // channels, V TRANSPOSED (rows = channels, 8 keys per fragment) so that it is the A operand of O^T += V^T P^T; q is split once,
-// P (scaled by 2^14: every probability that matters is a normal f16) per key tile.  Two accumulators per product (main / corr,
-// corr carries the 2^11): 24 matrix instructions of 32 cycles per key tile instead of 64 of 64.
+// P per key tile.  One accumulator per product: the lo planes are kept at their true magnitude, and the register-side operands
+// carry a power of two that keeps THEIR lo halves normal f16 numbers (q: 2^10, undone inside the exp2's multiply-add; P: 2^6,
+// cancelled by 1/l).  The lo halves of small K / V elements (|x| < 0.25) are subnormal f16; the matrix pipe reads subnormals as
+// they are (scripts/microbench/mfma_denorm.hip, test_mfma_reads_f16_subnormals), so each costs at most 2^-25 absolute.
+// 24 matrix instructions of 32 cycles per key tile instead of 64 of 64.  The softmax rescales lazily: the reference maximum only
+// moves (a wave-uniform branch) when some query's tile maximum exceeds it by more than 2^8 - same mathematics, P <= 2^14 in f16.
 template <bool F16>
 __global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict__ xin, const float* __restrict__ qkv,
                                                         const float* __restrict__ Wp, const float* __restrict__ bp,
@@ -786,51 +819,79 @@ __global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict_
   const float* qkv_b = qkv + (long long)b * NV * 192;
   stage_weight<64>(sWp, Wp, 64, tid, 448);
 
-  // staging assignment: 32 rows x 32 float4 (16 of k, 16 of v) = 1024 float4 per key tile
-  f32x4 pre[3];
+  // staging assignment: 32 rows x 32 float4 (16 of k, 16 of v) = 1024 float4 per key tile.  fp32 form: thread -> (row, float4) in
+  // order.  f16 form: waves 0, 1 stage V - a thread takes 4 consecutive keys x 4 channels and writes, per channel, the 4 keys of
+  // its fragment group as one 8-byte (hi) and one 8-byte (lo) store into the transposed tile; waves 2 .. 6 stage K (512 float4
+  // over 320 threads), each float4 = 4 channels of one key = half a fragment group.
+  f32x4 pre[F16 ? 4 : 3];
+  const int vg = (tid >> 3) & 7, vq = (tid & 7) + 8 * (tid >> 6);  // V role: key group (keys 4 vg .. +3), channel quad
   auto gload = [&](int jt) {
+    if constexpr (!F16) {
 #pragma unroll
-    for (int it = 0; it < 3; ++it) {
-      const int idx = tid + it * 448;
-      if (idx < 1024) {
-        const int rr = idx >> 5, c4 = idx & 31;
-        const int j = jt * 32 + rr;
-        pre[it] = (j < NV) ? *reinterpret_cast<const f32x4*>(qkv_b + (long long)j * 192 + 64 + 4 * c4)
-                           : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int it = 0; it < 3; ++it) {
+        const int idx = tid + it * 448;
+        if (idx < 1024) {
+          const int rr = idx >> 5, c4 = idx & 31;
+          const int j = jt * 32 + rr;
+          pre[it] = (j < NV) ? *reinterpret_cast<const f32x4*>(qkv_b + (long long)j * 192 + 64 + 4 * c4)
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    } else if (wave < 2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = jt * 32 + 4 * vg + k;
+        pre[k] = (j < NV) ? *reinterpret_cast<const f32x4*>(qkv_b + (long long)j * 192 + 128 + 4 * vq) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int idx = tid - 128 + it * 320;
+        if (idx < 512) {
+          const int j = jt * 32 + (idx >> 4);
+          pre[it] = (j < NV) ? *reinterpret_cast<const f32x4*>(qkv_b + (long long)j * 192 + 64 + 4 * (idx & 15))
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
     }
   };
   auto lstore = [&](int buf) {
+    if constexpr (!F16) {
 #pragma unroll
-    for (int it = 0; it < 3; ++it) {
-      const int idx = tid + it * 448;
-      if (idx < 1024) {
-        const int rr = idx >> 5, c4 = idx & 31;
-        if constexpr (!F16) {
+      for (int it = 0; it < 3; ++it) {
+        const int idx = tid + it * 448;
+        if (idx < 1024) {
+          const int rr = idx >> 5, c4 = idx & 31;
           if (c4 < 16)
             *reinterpret_cast<f32x4*>(&sK[buf][rr * SA_KLD + 4 * c4]) = pre[it];
           else
             *reinterpret_cast<f32x4*>(&sVv[buf][rr * SA_VLD + 4 * (c4 - 16)]) = pre[it];
-        } else {
+        }
+      }
+    } else if (wave < 2) {
+      // V^T: key group vg -> k-step vg / 4, lane half (vg % 4) & 1, elements 4 ((vg % 4) >> 1) .. +3 of the 8-key fragment
+      const int ks = vg >> 2, g = vg & 3;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        tl_f16x4 hi, lo;
+        split4_plain(pre[0][i], pre[1][i], pre[2][i], pre[3][i], hi, lo);
+        _Float16* d = reinterpret_cast<_Float16*>(&sVv[buf][(4 * vq + i) * SA_VTLD + (ks * 2 + (g & 1)) * 8]) + (g >> 1) * 4;
+        *reinterpret_cast<tl_f16x4*>(d) = hi;
+        *reinterpret_cast<tl_f16x4*>(d + 8) = lo;
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int idx = tid - 128 + it * 320;
+        if (idx < 512) {
+          const int rr = idx >> 4, c4 = idx & 15;
           tl_f16x4 hi, lo;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) hi[e] = (_Float16)pre[it][e];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) lo[e] = (_Float16)((pre[it][e] - (float)hi[e]) * 2048.0f);
-          if (c4 < 16) {  // K: channels 4 c4 .. +3 of key rr -> head c4 / 8, k-step (c4 % 8) / 4, group c4 % 4 (stage_weight_split's order)
-            const int h = c4 >> 3, ks = (c4 >> 2) & 1, g = c4 & 3;
-            _Float16* d = reinterpret_cast<_Float16*>(&sK[buf][rr * SA_KLD + ((h * 2 + ks) * 2 + (g & 1)) * 8]) + (g >> 1) * 4;
-            *reinterpret_cast<tl_f16x4*>(d) = hi;
-            *reinterpret_cast<tl_f16x4*>(d + 8) = lo;
-          } else {  // V^T: key rr -> k-step rr / 16, group (rr % 16) / 4, element (rr % 4) (+ 4 for groups 2, 3); one 16-bit store per channel
-            const int ks = rr >> 4, g = (rr >> 2) & 3, e = (g >> 1) * 4 + (rr & 3);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              _Float16* d = reinterpret_cast<_Float16*>(&sVv[buf][(4 * (c4 - 16) + i) * SA_VTLD + (ks * 2 + (g & 1)) * 8]) + e;
-              d[0] = hi[i];
-              d[8] = lo[i];
-            }
-          }
+          split4_plain(pre[it][0], pre[it][1], pre[it][2], pre[it][3], hi, lo);
+          // K: channels 4 c4 .. +3 of key rr -> head c4 / 8, k-step (c4 % 8) / 4, group c4 % 4 (stage_weight_split's order)
+          const int h = c4 >> 3, ks = (c4 >> 2) & 1, g = c4 & 3;
+          _Float16* d = reinterpret_cast<_Float16*>(&sK[buf][rr * SA_KLD + ((h * 2 + ks) * 2 + (g & 1)) * 8]) + (g >> 1) * 4;
+          *reinterpret_cast<tl_f16x4*>(d) = hi;
+          *reinterpret_cast<tl_f16x4*>(d + 8) = lo;
         }
       }
     }
@@ -842,8 +903,8 @@ __global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict_
   const long long tok = (long long)b * NV + (valid ? v : NV - 1);
   float q[32];
   load_slots(qkv + tok * 192, q, hb);
-  // 32^-0.5 * log2(e): scores are kept in log2 units so the softmax uses the native v_exp_f32 (2^x)
-  const float scale = 0.17677669529663688110f * 1.44269504088896340736f;
+  // 32^-0.5 * log2(e): scores are kept in log2 units so the softmax uses the native v_exp_f32 (2^x); the f16 form carries 2^10 more
+  const float scale = 0.17677669529663688110f * 1.44269504088896340736f * (F16 ? 1024.0f : 1.0f);
 #pragma unroll
   for (int s = 0; s < 32; ++s) q[s] *= scale;
   tl_f16x8 qhi[2][2], qlo[2][2];  // [head][k-step]
@@ -851,102 +912,145 @@ __global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict_
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) split_slots8(q + 16 * h + 8 * ks, qhi[h][ks], qlo[h][ks]);
+      for (int ks = 0; ks < 2; ++ks) split_slots8_plain(q + 16 * h + 8 * ks, qhi[h][ks], qlo[h][ks]);
   }
 
-  f32x16 O[2], Oc[2];  // Oc: the f16 form's correction accumulator (carries 2^11)
+  f32x16 O[2];
   float mrun[2], lrun[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     mrun[h] = -INFINITY;
     lrun[h] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) O[h][r] = Oc[h][r] = 0.f;
+    for (int r = 0; r < 16; ++r) O[h][r] = 0.f;
   }
+  constexpr float kQs = 0.0009765625f;     // 2^-10: scores of the f16 form -> log2 units
+  constexpr float kLazy = 8.0f * 1024.0f;  // the reference maximum moves when a tile maximum exceeds it by 2^8 (in score units)
+  float off[2] = {0.f, 0.f};               // 6 - mrun * 2^-10: P = 2^(s * 2^-10 + off) <= 2^14
 
+  // tile jt + 1 is written to LDS at the TOP of iteration jt (from the registers iteration jt - 1 loaded), tile jt + 2 is fetched
+  // right after: the staging arithmetic runs under the fragment reads' latency instead of in front of the barrier
   gload(0);
   lstore(0);
+  if (NTILE > 1) gload(1);
   __syncthreads();
   for (int jt = 0; jt < NTILE; ++jt) {
     const int buf = jt & 1;
-    if (jt + 1 < NTILE) gload(jt + 1);
+    if constexpr (!F16) {
+      if (jt + 1 < NTILE) lstore(buf ^ 1);
+      if (jt + 2 < NTILE) gload(jt + 2);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      f32x16 S;
+      for (int h = 0; h < 2; ++h) {
+        f32x16 S;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) S[r] = 0.f;
-      if constexpr (!F16) {
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
         tl_gemm<4, 1, SA_KLD>(&sK[buf][32 * h], q + 16 * h, &S, n0, hb);
-      } else {
-        f32x16 Sc;
+        float mt = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Sc[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const float* kp = &sK[buf][n0 * SA_KLD + ((h * 2 + ks) * 2 + hb) * 8];
-          const tl_f16x8 khi = *reinterpret_cast<const tl_f16x8*>(kp), klo = *reinterpret_cast<const tl_f16x8*>(kp + 4);
-          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qhi[h][ks], S, 0, 0, 0);
-          Sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo, qhi[h][ks], Sc, 0, 0, 0);
-          Sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qlo[h][ks], Sc, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) {
+          const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
+          const float sv = (j < NV) ? S[r] : -INFINITY;
+          S[r] = sv;
+          mt = fmaxf(mt, sv);
         }
+        mt = pair_max(mt);
+        const float mn = fmaxf(mrun[h], mt);
+        const float corr = __builtin_amdgcn_exp2f(mrun[h] - mn);
+        float pr[16], sum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S[r] = fmaf(Sc[r], 0.00048828125f, S[r]);
-      }
-      float mt = -INFINITY;
+        for (int r = 0; r < 16; ++r) {
+          pr[r] = __builtin_amdgcn_exp2f(S[r] - mn);
+          sum += pr[r];
+        }
+        lrun[h] = lrun[h] * corr + pair_sum(sum);
+        mrun[h] = mn;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
-        const float sv = (j < NV) ? S[r] : -INFINITY;
-        S[r] = sv;
-        mt = fmaxf(mt, sv);
-      }
-      mt = pair_max(mt);
-      const float mn = fmaxf(mrun[h], mt);
-      const float corr = __builtin_amdgcn_exp2f(mrun[h] - mn);
-      float pr[16], sum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        pr[r] = __builtin_amdgcn_exp2f(S[r] - mn);
-        sum += pr[r];
-      }
-      lrun[h] = lrun[h] * corr + pair_sum(sum);
-      mrun[h] = mn;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) O[h][r] *= corr;
-      if constexpr (!F16) {
+        for (int r = 0; r < 16; ++r) O[h][r] *= corr;
         const float* vb = &sVv[buf][4 * hb * SA_VLD + 32 * h + n0];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
           const float a = vb[((s & 3) + 8 * (s >> 2)) * SA_VLD];
           O[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pr[s], O[h], 0, 0, 0);
         }
-      } else {
+      }
+    } else {
+      // all 16 fragments of the tile are read up front (one exposed LDS latency per tile; 1 workgroup per CU leaves the registers)
+      tl_f16x8 kf[2][2][2], vf[2][2][2];  // [head][k-step][hi | lo]
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const float* kp = &sK[buf][n0 * SA_KLD + ((h * 2 + ks) * 2 + hb) * 8];
+          kf[h][ks][0] = *reinterpret_cast<const tl_f16x8*>(kp);
+          kf[h][ks][1] = *reinterpret_cast<const tl_f16x8*>(kp + 4);
+        }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const float* vp = &sVv[buf][(32 * h + n0) * SA_VTLD + (ks * 2 + hb) * 8];
+          vf[h][ks][0] = *reinterpret_cast<const tl_f16x8*>(vp);
+          vf[h][ks][1] = *reinterpret_cast<const tl_f16x8*>(vp + 4);
+        }
+      asm volatile("" ::: "memory");
+      if (jt + 1 < NTILE) lstore(buf ^ 1);
+      if (jt + 2 < NTILE) gload(jt + 2);
+      f32x16 S[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[h][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          S[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[h][ks][0], qhi[h][ks], S[h], 0, 0, 0);
+          S[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[h][ks][1], qhi[h][ks], S[h], 0, 0, 0);
+          S[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[h][ks][0], qlo[h][ks], S[h], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float mt = -INFINITY;  // this lane's half of the tile; the pair is only joined when the reference maximum moves
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          Oc[h][r] *= corr;
-          pr[r] *= 16384.0f;  // 2^14 (undone with 1/l below): probabilities down to 4e-9 stay normal f16 numbers
+          const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
+          const float sv = (j < NV) ? S[h][r] : -INFINITY;
+          S[h][r] = sv;
+          mt = fmaxf(mt, sv);
         }
+        if (__builtin_amdgcn_ballot_w64(mt > mrun[h] + kLazy) != 0) {  // always on the first tile (mrun = -inf), rarely afterwards
+          const float mn = fmaxf(mrun[h], pair_max(mt));
+          const float corr = __builtin_amdgcn_exp2f((mrun[h] - mn) * kQs);
+          mrun[h] = mn;
+          off[h] = fmaf(mn, -kQs, 6.0f);
+          lrun[h] *= corr;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) O[h][r] *= corr;
+        }
+        float pr[16], sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pr[r] = __builtin_amdgcn_exp2f(fmaf(S[h][r], kQs, off[h]));
+          sum += pr[r];
+        }
+        lrun[h] += sum;  // per lane (its 16 keys of every tile); the pair is summed once after the loop
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           tl_f16x8 phi, plo;
-          split_slots8(pr + 8 * ks, phi, plo);
-          const float* vp = &sVv[buf][(32 * h + n0) * SA_VTLD + (ks * 2 + hb) * 8];
-          const tl_f16x8 vhi = *reinterpret_cast<const tl_f16x8*>(vp), vlo = *reinterpret_cast<const tl_f16x8*>(vp + 4);
-          O[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, phi, O[h], 0, 0, 0);
-          Oc[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo, phi, Oc[h], 0, 0, 0);
-          Oc[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, plo, Oc[h], 0, 0, 0);
+          split_slots8_plain(pr + 8 * ks, phi, plo);
+          O[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[h][ks][0], phi, O[h], 0, 0, 0);
+          O[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[h][ks][1], phi, O[h], 0, 0, 0);
+          O[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[h][ks][0], plo, O[h], 0, 0, 0);
         }
       }
     }
-    if (jt + 1 < NTILE) lstore(buf ^ 1);
     __syncthreads();
   }
   float att[32];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const float inv = (F16 ? 6.103515625e-05f : 1.0f) / lrun[h];  // 2^-14 undoes the scale of P
+    const float inv = 1.0f / (F16 ? pair_sum(lrun[h]) : lrun[h]);  // (the f16 form's l carries the same 2^6 as its O)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) att[16 * h + r] = (F16 ? fmaf(Oc[h][r], 0.00048828125f, O[h][r]) : O[h][r]) * inv;
+    for (int r = 0; r < 16; ++r) att[16 * h + r] = O[h][r] * inv;
   }
   float x[32];
   load_slots(xin + tok * 64, x, hb);

@@ -159,3 +159,27 @@ extern "C" int pmce_dbg_mfma_spin(int kind, float* sink, int blocks, int iters, 
   }
   return pmce_check_launch("dbg_mfma_spin");
 }
+
+// One v_mfma_f32_32x32x16_f16 with A = a, B = b in every element: out[0] = the (uniform) result = 16 a b when the matrix pipe
+// reads subnormal f16 inputs as they are, out[1] = a after the conversion to f16.  vertex_sa's f16 form stores the lo halves of
+// small K / V elements as subnormals (coevo.hip); the test pins the hardware behaviour it relies on.
+typedef _Float16 dbg_f16x8 __attribute__((ext_vector_type(8)));
+__global__ void mfma_subnormal_kernel(float* out, float a, float b) {
+  dbg_f16x8 A, B;
+  for (int e = 0; e < 8; ++e) {
+    A[e] = (_Float16)a;
+    B[e] = (_Float16)b;
+  }
+  f32x16 C;
+  for (int r = 0; r < 16; ++r) C[r] = 0.f;
+  C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0);
+  if (threadIdx.x == 0) {
+    out[0] = C[0];
+    out[1] = (float)A[0];
+  }
+}
+extern "C" int pmce_dbg_mfma_subnormal(float a, float b, float* out2, hipStream_t stream) {
+  PMCE_REQUIRE(out2, "dbg_mfma_subnormal: null pointer");
+  hipLaunchKernelGGL(mfma_subnormal_kernel, dim3(1), dim3(64), 0, stream, out2, a, b);
+  return pmce_check_launch("dbg_mfma_subnormal");
+}

@@ -347,6 +347,19 @@ def test_adaln_mlp(golden):
     assert e3 < 2e-5 and e4 < 2e-5
 
 
+def test_mfma_reads_f16_subnormals():
+    """The f16 form of vertex_sa keeps the lo halves of k / v at their true magnitude: for |x| < 0.25 they are subnormal f16
+    numbers.  The matrix pipe must read them as they are (a flush to zero would cost 2^-12 relative on those elements)."""
+    from pmce_amd import _lib
+    lib = _lib.load()
+    out = torch.zeros(2, device=dev())
+    for a in (2.0 ** -20, 2.0 ** -24, 3 * 2.0 ** -24, 2.0 ** -14):
+        _lib.check(lib.pmce_dbg_mfma_subnormal(a, 1024.0, _lib.ptr(out), None), "dbg_mfma_subnormal")
+        torch.cuda.synchronize()
+        got, a16 = out.tolist()
+        assert a16 == a and got == 16 * 1024.0 * a, (a, a16, got)
+
+
 @pytest.mark.parametrize("split_f16", [False, True])
 def test_vertex_self_attn(golden, split_f16):
     from oracle import pmce_oracle as O
