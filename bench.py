@@ -183,7 +183,7 @@ def north_star_record(kernel_ms, launches, B, J, f16_ffn=False):
     byt = 229376.0 * B
     tiles = B * 14
     # matrix-pipe cycles per 32-vertex wave tile: scores + output on the fp32 pipe (64 cycles per instruction), the FFN either
-    # 512 fp32 instructions or - in the split-f16 mode (batches of 48 clips and more) - 192 f16 ones of 32 cycles
+    # 512 fp32 instructions or - in the split-f16 mode - 192 f16 ones of 32 cycles
     ffn_cycles = 0 if name != "vertex_ca_mlp" else (192 * 32 if f16_ffn else 512 * 64)
     cyc_per_tile = (64 + 16 * ((J + 7) // 8)) * 64 + ffn_cycles
     t_hbm = byt / (PEAK_HBM_GBS * 1e9) * 1e3
@@ -201,7 +201,7 @@ def north_star_record(kernel_ms, launches, B, J, f16_ffn=False):
 def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full=True):
     """Throughput + per-kernel-class timing of one configuration.  Returns (record, model, pipe, inputs)."""
     import torch
-    from pmce_amd import assets, models, sharding, synth
+    from pmce_amd import _lib, assets, models, sharding, synth
     from pmce_amd.workload import flops_per_clip
 
     assets.allow_synthetic_base_data()                                  # no SMPL-derived files offline: synthetic template
@@ -275,7 +275,7 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
                       "global_batch": B * world, "seq_len": 16, "joints": J, "embed_dim": C,
                       "parallelism": f"clip-sharded dp{world}, weights replicated",
                       "gemm_mode": gemm_mode,
-                      "streams": 1 if (args.single_stream or gemm_mode == "split_f16") else 2 * depth,
+                      "streams": 1 if (args.single_stream or (gemm_mode == "split_f16" and not _lib.split_overlap())) else 2 * depth,
                       "batches_enqueued_ahead": depth, "distinct_input_batches": NB},
            "ref_equiv_tflops": round(fpc * clips_per_s / 1e12, 2), "outputs_finite": finite}
     if not full:
@@ -333,7 +333,7 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
             ach = work / secs / 1e9
             roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(ach / PEAK_HBM_GBS, 4), **common}
-    rec.update({"roofline": roofline, "roofline_cross_attention": north_star_record(kernel_ms, launches, B, J, f16_ffn=(gemm_mode == "split_f16" and B >= 48)),
+    rec.update({"roofline": roofline, "roofline_cross_attention": north_star_record(kernel_ms, launches, B, J, f16_ffn=(gemm_mode == "split_f16")),
                 "kernel_ms_per_step": kernel_ms, "launches_per_step": launches,
                 "kernel_ms_total_single_stream": round(sum(kernel_ms.values()), 4), "gemm_mode": gemm_mode})
     return rec, model, pipe, inputs, sd
@@ -475,8 +475,8 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the B=1 / B=8 latency record")
     ap.add_argument("--no-variant", action="store_true", help="skip the second complete record (the other pose-encoder width)")
     ap.add_argument("--gemm-mode", choices=("split_f16", "f32"), default="split_f16",
-                    help="the large products as three f16 matrix products each (fp32 accumulate, fp32 accuracy; every kernel on one "
-                         "stream) or on the fp32 matrix pipe (two streams, two batches in flight)")
+                    help="the large products as three f16 matrix products each (fp32 accumulate, fp32 accuracy) or on the fp32 matrix "
+                         "pipe; both with two streams inside a forward and two batches in flight")
     ap.add_argument("--dist-check", action="store_true",
                     help="rendezvous + the path's collectives only (no GPU work): what the non-GPU test of the N>1 entry point runs")
     args = ap.parse_args()

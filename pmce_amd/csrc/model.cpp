@@ -101,10 +101,15 @@ struct pmce_model {
   bool split_adopted = false;          // the planes came from another handle (pmce_model_share_split_weights): finalize keeps them
   LifterBlockSplit sblk[2][8];
   SplitW s_ie, s_wih0, s_wih1, s_whh0, s_whh1, s_ada, s_final;
-  // Below this many clips per call the products stay on the fp32 pipe: a small batch is bound by its 25 dependent GRU launches,
-  // which the two-stream schedule (fp32 mode only, see two_streams) hides under the pose lifter - worth more than the GEMM time
-  // the f16 form saves there (B = 1: 1.8 ms against 2.7 ms).  PMCE_SPLIT_MIN_BATCH at create.
-  int split_min_batch = 48;
+  // Below this many clips per call the products stay on the fp32 pipe (PMCE_SPLIT_MIN_BATCH at create).  Default 1 = never: with
+  // the two-stream schedule in both modes the f16 form is faster at every batch size (B = 1: 1.57 ms against 1.85 ms at C = 512;
+  // scripts/microbench/small_batch_modes.py).  With PMCE_SPLIT_OVERLAP=0 a threshold near 48 pays: a small batch is bound by its
+  // 25 dependent GRU launches, which only the second stream hides.
+  int split_min_batch = 1;
+  // Two streams also in split mode.  f16 matrix instructions disturb packed-fp32 arithmetic of co-resident waves on MI355X (DESIGN
+  // 3.4); the library therefore contains no packed-fp32 instruction at all (build.py), which makes its kernels safe next to each
+  // other.  PMCE_SPLIT_OVERLAP=0 at create restores the strictly serial schedule of the split mode (diagnostic).
+  bool split_overlap = true;
   bool ffn_f16 = true;
   bool split_now = false;  // decision for the call in progress (set by check_ws, the first thing every entry point does)
   // regressor (optional)
@@ -633,10 +638,10 @@ int fail_after_fork(pmce_model* m, hipStream_t stream, int rc) {
   return rc;
 }
 
-// Two streams inside one forward only on the fp32 matrix pipe.  A wave executing the f16 matrix instructions disturbs packed-fp32
-// arithmetic of OTHER kernels' waves on the same CU (measured: scripts/microbench/victims.py), so kernels of the
-// split-f16 form must never share the GPU with another kernel of this path: everything goes down one stream, in order.
-bool two_streams(const pmce_model* m) { return m->concurrent && !m->split_now; }
+// A wave executing f16 matrix instructions disturbs packed-fp32 arithmetic of OTHER waves on the same CU (measured:
+// scripts/microbench/victims.py).  No kernel of this library contains packed-fp32 instructions (build.py), so the
+// split-f16 form keeps the two-stream schedule; split_overlap = false (PMCE_SPLIT_OVERLAP=0) sends everything down one stream.
+bool two_streams(const pmce_model* m) { return m->concurrent && (!m->split_now || m->split_overlap); }
 
 int ensure_side(pmce_model* m) {
   if (m->side) return PMCE_OK;
@@ -734,8 +739,9 @@ int pmce_model_create(int num_joint, int embed_dim, int depth, pmce_model** out)
   m->concurrent = getenv("PMCE_SINGLE_STREAM") == nullptr;
   m->fused_ca = pmce_env_int("PMCE_VERTEX_FUSED", 1) != 0;
   m->split_gemm = pmce_env_int("PMCE_SPLIT_F16", 1) != 0;
-  m->split_min_batch = pmce_env_int("PMCE_SPLIT_MIN_BATCH", 48);
+  m->split_min_batch = pmce_env_int("PMCE_SPLIT_MIN_BATCH", 1);
   m->ffn_f16 = pmce_env_int("PMCE_FFN_F16", 1) != 0;
+  m->split_overlap = pmce_env_int("PMCE_SPLIT_OVERLAP", 1) != 0;
   build_names(m);
   *out = m;
   return PMCE_OK;

@@ -178,10 +178,9 @@ class Pipeline:
             # every lane is a handle of its own (the model's handle and workspace stay free for direct forward() calls)
             self._main = main
             self.engines = [main.clone_shared() for _ in range(self.depth)]
-            if main.gemm_mode() == "split_f16":
-                # kernels of the f16 three-product form must not share the GPU with other kernels (runtime.HipModuleBase.
-                # set_gemm_mode): the lanes keep their own handles and workspaces (batches are enqueued ahead of the GPU) but
-                # run down ONE stream, in order
+            if main.gemm_mode() == "split_f16" and not _lib.split_overlap():
+                # diagnostic (PMCE_SPLIT_OVERLAP=0): the lanes keep their own handles and workspaces (batches are enqueued ahead
+                # of the GPU) but run down ONE stream, in order
                 st = torch.cuda.Stream(device=main.device)
                 self.streams = [st] * self.depth
             else:

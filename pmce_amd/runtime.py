@@ -167,15 +167,17 @@ class HipModuleBase(nn.Module):
         self._split_min_batch = None
 
     def set_gemm_mode(self, mode, min_batch=None):
-        """Arithmetic of the large products (min_batch: calls with fewer clips stay on the fp32 pipe, default 48): 'split_f16' (three f16 products per fp32 product on the f16 matrix
+        """Arithmetic of the large products (min_batch: calls with fewer clips stay on the fp32 pipe, default 1 = none): 'split_f16' (three f16 products per fp32 product on the f16 matrix
         pipe, fp32 accumulate; fp32-grade accuracy, the default) or 'f32' (fp32 matrix pipe).  Takes effect at the next
         forward; pipelines and captured graphs made before must be rebuilt.
 
-        In 'split_f16' mode every kernel of a forward runs on ONE stream and a Pipeline's lanes share one stream: on MI355X a
-        wave executing the f16 matrix instructions corrupts packed-fp32 arithmetic of other kernels' waves on the same CU
-        (scripts/microbench/victims.py), so these kernels are never overlapped with anything.  Do not run other GPU work
-        (another model, another stream of this process) concurrently with a forward in this mode; 'f32' mode has no such
-        restriction and keeps the two-stream / two-batches-in-flight execution."""
+        On MI355X a wave executing f16 matrix instructions corrupts packed-fp32 arithmetic (v_pk_{fma,mul,add}_f32) of other waves
+        on the same CU (scripts/microbench/victims.py).  The library is therefore built without any packed-fp32 instruction
+        (build.py; checked on the device code by tests/test_host_logic.py), which makes its own kernels safe next to each other:
+        both modes use the two-stream / two-batches-in-flight execution, and overlapped runs are bitwise equal to serial ones
+        (tests/test_gpu_e2e.py::test_overlapped_split_mode_equals_serial).  OTHER GPU work of the process that contains
+        packed-fp32 arithmetic (e.g. elementwise torch kernels on another stream) must not run concurrently with a forward in
+        'split_f16' mode; 'f32' mode has no such restriction.  PMCE_SPLIT_OVERLAP=0 restores the strictly serial schedule."""
         if mode not in (None, "split_f16", "f32"):
             raise ValueError("gemm mode must be 'split_f16', 'f32' or None")
         self._gemm_mode = mode

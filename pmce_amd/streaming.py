@@ -123,7 +123,7 @@ def stream_forward_cached(model, cache: FrameCache, windows=None, batch: int = 2
     nb = (len(windows) + batch - 1) // batch
     lanes = max(1, min(lanes, nb))
     if getattr(model, "_stream_lanes", None) is None or len(model._stream_lanes[0]) < lanes or model._stream_lanes[0][0] is not main:
-        if main.gemm_mode() == "split_f16":   # kernels of this mode never overlap other kernels: one stream for every lane
+        if main.gemm_mode() == "split_f16" and not _lib.split_overlap():   # diagnostic: one stream for every lane
             sts = [torch.cuda.Stream(device=dev)] * lanes
         else:
             sts = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
