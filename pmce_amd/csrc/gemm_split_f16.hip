@@ -305,35 +305,53 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
               }
             }
         }
-      } else
+      } else if (full) {
+        // Full tile, buffer-form accesses: ONE set of 16 lane offsets (row r of a 32x32 block, this lane's column) serves every
+        // block of the tile and both R and C - the block's position goes into the scalar offset - instead of a 64-bit address pair
+        // per row and block.  The residual of block b + 1 is requested BEFORE block b is stored (two 16-register sets): left to
+        // itself every block starts with 16 dependent loads whose latency nothing hides - 8 exposed round trips per tile.
+        constexpr int NBLK = TM * TN;
+        const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(p.C + (size_t)m_base * p.ldc, 0, 0xffffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_r =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RES ? p.R + (size_t)m_base * p.ldc : p.C), 0, 0xffffffff, 0x00020000);
+        unsigned voff[16];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n_base + wn * WN + j * 32 + n0;
+        for (int r = 0; r < 16; ++r) voff[r] = ((unsigned)(4 * hb + (r & 3) + 8 * (r >> 2)) * p.ldc + (unsigned)n0) * 4u;
+        auto blk_off = [&](int b) __attribute__((always_inline)) {  // wave-uniform
+          return ((unsigned)(wm * WM + (b % TM) * 32) * p.ldc + (unsigned)(n_base + wn * WN + (b / TM) * 32)) * 4u;
+        };
+        float rv[2][16];
+        auto res_load = [&](int b, float (&dst)[16]) __attribute__((always_inline)) {
+          const unsigned so = blk_off(b);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int mrow = m_base + wm * WM + i * 32 + 4 * hb;
-          float* __restrict__ Cp = p.C + (size_t)mrow * p.ldc + n;
-          const float* __restrict__ Rp = RES ? p.R + (size_t)mrow * p.ldc + n : nullptr;
-          if (full) {
-            float rv[16];
-            if (RES) {
+          for (int r = 0; r < 16; ++r) dst[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_r, voff[r], so, 0));
+        };
+        if (RES) res_load(0, rv[0]);
 #pragma unroll
-              for (int r = 0; r < 16; ++r) rv[r] = Rp[((r & 3) + 8 * (r >> 2)) * p.ldc];
-            }
+        for (int b = 0; b < NBLK; ++b) {
+          const int j = b / TM, i = b % TM;
+          if (RES && b + 1 < NBLK) res_load(b + 1, rv[(b + 1) & 1]);
+          const unsigned so = blk_off(b);
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-              f32x2 v = {acc[i][j][r] * w_down, acc[i][j][r + 1] * w_down};
-              if (ACT == 1) v = gelu_erf2(v);
-              if (RES) v += f32x2{rv[r], rv[r + 1]};
-#ifndef PMCE_SPLIT_PLAIN_STORES  // streaming stores measure 5-9 % faster than write-back ones here
-              __builtin_nontemporal_store(v.x, Cp + ((r & 3) + 8 * (r >> 2)) * p.ldc);
-              __builtin_nontemporal_store(v.y, Cp + (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * p.ldc);
-#else
-              Cp[((r & 3) + 8 * (r >> 2)) * p.ldc] = v.x;
-              Cp[(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * p.ldc] = v.y;
-#endif
-            }
-          } else {
+          for (int r = 0; r < 16; r += 2) {
+            f32x2 v = {acc[i][j][r] * w_down, acc[i][j][r + 1] * w_down};
+            if (ACT == 1) v = gelu_erf2(v);
+            if (RES) v += f32x2{rv[b & 1][r], rv[b & 1][r + 1]};
+            // aux 2 = nt: streaming stores measure 5-9 % faster than write-back ones here
+            const float vx = v.x, vy = v.y;  // (a bit_cast applied to the vector component itself reads component 0 both times)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vx), rsrc_c, voff[r], so, 2);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vy), rsrc_c, voff[r + 1], so, 2);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n_base + wn * WN + j * 32 + n0;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int mrow = m_base + wm * WM + i * 32 + 4 * hb;
+            float* __restrict__ Cp = p.C + (size_t)mrow * p.ldc + n;
+            const float* __restrict__ Rp = RES ? p.R + (size_t)mrow * p.ldc + n : nullptr;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {  // the same arithmetic as the full-tile path (results do not depend on tile shape)
               f32x2 v = {acc[i][j][r] * w_down, acc[i][j][r + 1] * w_down};
