@@ -445,6 +445,7 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
   PMCE_REQUIRE(!a_packed || lda == K, "gemm_split: a packed A has lda == K");
   PMCE_REQUIRE((long long)M * lda * 4 < (1ll << 32) && (long long)N * K * 4 < (1ll << 32) && (long long)M * ldc < (1ll << 32),
                "gemm_split: an operand spans 4 GiB or more (split the batch)");
+  PMCE_REQUIRE(ldc < (1ll << 21), "gemm_split: ldc=%lld (the tile epilogue addresses a 256-row window of C / R with 32-bit byte offsets)", ldc);
   PMCE_REQUIRE(c_div == 0 || R == nullptr, "gemm_split: a C row map cannot be combined with a residual");
   PMCE_REQUIRE(!c_packed || (a_packed && act == 1 && R == nullptr && c_div == 0 && N % 32 == 0 && ldc == N),
                "gemm_split: a packed result is supported for the packed-A + GELU form with N %% 32 == 0 and ldc == N");
