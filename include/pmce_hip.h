@@ -169,8 +169,14 @@ int pmce_gemm_nt_split_f16_rowmap(const float* A, const float* Wp, const float* 
 /* a_packed != 0: A is not fp32 but already split, [M][K/16][hi 16 f16 | lo*2^11 16 f16] (the layout the lifter's own
  * producers write; pmce_split_rows_f16 makes it from fp32 rows). */
 int pmce_split_rows_f16(const float* A, long long M, int K, long long lda, float* Ap, pmce_stream_t stream);
-/* Tuning aid only: force the tile configuration of pmce_gemm_nt_split_f16 (0: 128x256, 1: 128x128, 2: 64x128; -1 automatic). */
+/* Tuning aid only: force the tile configuration of pmce_gemm_nt_split_f16 (0: 128x256, 1: 128x128, 2: 64x128 - the 4-wave
+ * kernel; 3: the wave-specialised 192x256 kernel of gemm_split_ws.hip wherever it applies; -1 automatic). */
 int pmce_gemm_split_set_tuning(int tile);
+/* Tuning aid only: 0 keeps the automatic choice away from the wave-specialised kernel (PMCE_SPLIT_WS=0 at load does the same). */
+int pmce_gemm_split_set_ws(int on);
+/* Number of wavefronts of the wave-specialised kernel that gave up waiting on an in-kernel hand-off since the library was
+ * loaded: 0 in a healthy process (every spin is bounded instead of hanging the device).  Synchronises the device. */
+int pmce_gemm_ws_timeouts(void);
 /* Tuning aid only: start delay of every CU's second workgroup in units of 4096 cycles (-1: half a tile of matrix time). */
 int pmce_gemm_split_set_skew(int units);
 /* Diagnostics (scripts/microbench/victims.py; not on the product path): self-checking bystander kernels and matrix-pipe

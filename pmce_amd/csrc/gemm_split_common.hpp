@@ -1,0 +1,46 @@
+// Shared pieces of the three-product f16 GEMM kernels (gemm_split_f16.hip: the 4-wave tiles; gemm_split_ws.hip: the
+// wave-specialised 192x256 tile).  Arithmetic and operand layout: see the header of gemm_split_f16.hip.
+#pragma once
+#include "common.hpp"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct SplitParams {
+  const float* A;       // fp32 [M][lda], or packed planes [M][K/16][16 hi | 16 lo*2^11] f16 (APACK)
+  const float* W;       // packed planes [N][K/16][16 hi | 16 lo] f16 of W * 2^s
+  const float* wscale;  // {2^s, 2^-s}
+  const float* bias;    // [N] or null
+  const float* R;       // residual [M][ldc] or null
+  float* C;
+  int M, N, K;
+  unsigned lda, ldc;
+  int ntm, ntn;
+  int c_div;             // > 0: C row r lives at (r % c_div) * c_lo + (r / c_div) * c_hi (elements); never with R
+  long long c_lo, c_hi;
+  int skew;  // start delay of the second workgroup per CU, in units of 4096 cycles
+};
+
+// LDS-DMA: 64 lanes x 16 B from per-lane buffer offsets into LDS at M0 + lane*16 (see gemm_f32.hip)
+__device__ __forceinline__ void sdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff, unsigned lds_wave_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(lds_wave_base), "s"(soff)
+      : "memory");
+}
+
+// fp32 -> (hi, lo * 2^11) f16
+__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, f16x8& hi, f16x8& lo) {
+  const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) hi[e] = (_Float16)v[e];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) lo[e] = (_Float16)((v[e] - (float)hi[e]) * 2048.0f);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+

@@ -27,48 +27,7 @@
 //    2^-s, GELU, residual, stores) runs straight from the accumulators while the CU's other workgroup keeps the pipe busy.
 #include <atomic>
 
-#include "common.hpp"
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-struct SplitParams {
-  const float* A;       // fp32 [M][lda], or packed planes [M][K/16][16 hi | 16 lo*2^11] f16 (APACK)
-  const float* W;       // packed planes [N][K/16][16 hi | 16 lo] f16 of W * 2^s
-  const float* wscale;  // {2^s, 2^-s}
-  const float* bias;    // [N] or null
-  const float* R;       // residual [M][ldc] or null
-  float* C;
-  int M, N, K;
-  unsigned lda, ldc;
-  int ntm, ntn;
-  int c_div;             // > 0: C row r lives at (r % c_div) * c_lo + (r / c_div) * c_hi (elements); never with R
-  long long c_lo, c_hi;
-  int skew;  // start delay of the second workgroup per CU, in units of 4096 cycles
-};
-
-// LDS-DMA: 64 lanes x 16 B from per-lane buffer offsets into LDS at M0 + lane*16 (see gemm_f32.hip)
-__device__ __forceinline__ void sdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff, unsigned lds_wave_base) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(rsrc), "s"(lds_wave_base), "s"(soff)
-      : "memory");
-}
-
-// fp32 -> (hi, lo * 2^11) f16
-__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, f16x8& hi, f16x8& lo) {
-  const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-#pragma unroll
-  for (int e = 0; e < 8; ++e) hi[e] = (_Float16)v[e];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) lo[e] = (_Float16)((v[e] - (float)hi[e]) * 2048.0f);
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
+#include "gemm_split_common.hpp"
 
 template <int TM, int TN>
 struct SplitCfg {
@@ -435,6 +394,15 @@ static int pick_split_tile(int M, int N) {
   return best;
 }
 
+// gemm_split_ws.hip: the wave-specialised 192x256 kernel (pre-split A, large M)
+bool pmce_gemm_split_ws_wants(int M, int N, int K, int a_packed, int c_div);
+int pmce_gemm_split_ws_launch(SplitParams& p, int act, int c_packed, hipStream_t stream);
+static std::atomic<int> g_split_ws{pmce_env_int("PMCE_SPLIT_WS", 1)};
+extern "C" int pmce_gemm_split_set_ws(int on) {
+  g_split_ws.store(on, std::memory_order_relaxed);
+  return PMCE_OK;
+}
+
 static int gemm_split_any(const float* A, const float* Wp, const float* wscale, const float* bias, const float* R, float* C, int M,
                           int N, int K, long long lda, long long ldc, int act, int a_packed, int c_packed, int c_div,
                           long long c_lo, long long c_hi, hipStream_t stream) {
@@ -456,6 +424,13 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
   {  // half a tile of matrix time: nk iterations x 3*TM*TN instructions x 32 cycles (TM*TN = 8 or 4), / 2, in 4096-cycle units
     const int knob = g_split_skew.load(std::memory_order_relaxed);
     p.skew = knob >= 0 ? knob : (K / 16) * 12 * 32 / 4096 + 1;
+  }
+  {
+    const int forced = g_split_tile.load(std::memory_order_relaxed);
+    if ((forced == 3 || (forced < 0 && g_split_ws.load(std::memory_order_relaxed) != 0)) && pmce_gemm_split_ws_wants(M, N, K, a_packed, c_div)) {
+      PMCE_TRY(pmce_gemm_split_ws_launch(p, act, c_packed, stream));
+      return pmce_check_launch("gemm_nt_split_f16 (ws)");
+    }
   }
   switch (pick_split_tile(M, N)) {
     case 0: PMCE_TRY((launch_cfg<2, 4>(p, act, a_packed != 0, c_packed != 0, stream))); break;
