@@ -79,26 +79,26 @@ __device__ __forceinline__ float erf_fast(float x) {
   const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
   return copysignf(fmaf(-p * t, e, 1.0f), x);
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
-
-// Two GELUs at once on the packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32: two elements per issue slot): the same
-// formula and constants as gelu_erf, about 8 instead of 15 vector instructions per element next to the matrix pipe.
-__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
-  const f32x2 z = x * 0.70710678118654752440f;
-  const f32x2 az = {fabsf(z.x), fabsf(z.y)};
-  const f32x2 den = az * 0.3275911f + 1.0f;
-  const f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-  f32x2 p = t * 1.061405429f + -1.453152027f;
-  p = p * t + 1.421413741f;
-  p = p * t + -0.284496736f;
-  p = p * t + 0.254829592f;
-  const f32x2 arg = (az * az) * -1.44269504088896340736f;
-  const f32x2 e = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
-  const f32x2 r = 1.0f - (p * t) * e;
-  const f32x2 erfv = {copysignf(r.x, z.x), copysignf(r.y, z.y)};
-  const f32x2 h = x * 0.5f;
-  return h * erfv + h;
+// The GELU of the path, one formula for every kernel and every template instantiation: each fused multiply-add is spelled out and
+// contraction is off, because hipcc's default (-ffp-contract=fast) fuses the SAME source differently from one instantiation to
+// the next - the split GEMM's packed-output form came out a 1-ulp different GELU than its fp32-output form, which shows as
+// different (hi, lo) planes and breaks "the result does not depend on which kernel a batch size selects".
+__device__ __forceinline__ float gelu_erf(float x) {
+#pragma clang fp contract(off)
+  const float z = x * 0.70710678118654752440f;
+  const float az = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(az, 0.3275911f, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f((az * az) * -1.44269504088896340736f);
+  const float r = fmaf(-(p * t), e, 1.0f);
+  const float h = x * 0.5f;
+  return fmaf(h, copysignf(r, z), h);
 }
+// two elements (the packed-fp32 form this once was is gone with -packed-fp32-ops)
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) { return f32x2{gelu_erf(x.x), gelu_erf(x.y)}; }
 
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 

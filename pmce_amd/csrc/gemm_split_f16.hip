@@ -397,7 +397,7 @@ static int pick_split_tile(int M, int N) {
 // gemm_split_ws.hip: the wave-specialised 192x256 kernel (pre-split A, large M)
 bool pmce_gemm_split_ws_wants(int M, int N, int K, int a_packed, int c_div);
 int pmce_gemm_split_ws_launch(SplitParams& p, int act, int c_packed, hipStream_t stream);
-static std::atomic<int> g_split_ws{pmce_env_int("PMCE_SPLIT_WS", 1)};
+static std::atomic<int> g_split_ws{pmce_env_int("PMCE_SPLIT_WS", 0)};  // off: it is not faster than the 4-wave kernel
 extern "C" int pmce_gemm_split_set_ws(int on) {
   g_split_ws.store(on, std::memory_order_relaxed);
   return PMCE_OK;

@@ -142,8 +142,9 @@ def test_gemm_split_packed_result(M, N, K, tile):
         packed = ops.gemm_nt_split(Ap, Wp, ws, b, None, 1, a_packed=True, c_packed=True)
     finally:
         lib.pmce_gemm_split_set_tuning(-1)
-    # the planes hold the fp32 result to 22 bits: hi + lo * 2^-11 (the two epilogues may contract the GELU's multiply-adds
-    # differently, so the fp32 values themselves agree to an ulp, not bitwise)
+    # the same bits as splitting the fp32 result afterwards (the GELU spells out its fused multiply-adds: round 2's form came out
+    # an ulp different from one template instantiation to the next)
+    assert torch.equal(packed.view(torch.int32), ops.split_rows_f16(plain).view(torch.int32))
     pl = packed.view(torch.float16).reshape(M, N // 16, 2, 16).float()
     back = (pl[:, :, 0, :] + pl[:, :, 1, :] * 2.0 ** -11).reshape(M, N)
     err = (back - plain).abs().max().item()
@@ -152,6 +153,40 @@ def test_gemm_split_packed_result(M, N, K, tile):
     # and splitting is exact to 22 bits on its own: the planes of the fp32 result reproduce it
     sp = ops.split_rows_f16(plain).view(torch.float16).reshape(M, N // 16, 2, 16).float()
     assert ((sp[:, :, 0, :] + sp[:, :, 1, :] * 2.0 ** -11).reshape(M, N) - plain).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K,act,res,cpk", [
+    (69632, 1536, 512, 0, False, False),   # qkv at B = 256, C = 512
+    (69632, 512, 1024, 0, True, False),    # fc2 + residual
+    (69632, 1024, 512, 1, False, True),    # fc1: GELU, result written pre-split
+    (40000, 640, 256, 1, False, False),    # last row tile 64 of 192 rows, last column tile 128 of 256 columns
+    (50001, 1024, 128, 0, True, False),    # ragged M inside a wave's 64 rows, shortest K
+    (37000, 256, 256, 1, False, True),
+])
+def test_gemm_split_wave_specialised(M, N, K, act, res, cpk):
+    """gemm_split_ws.hip (12 compute + 4 loader waves, LDS progress words instead of barriers; an opt-in alternative to the 4-wave
+    kernel, tuning knob 3) computes the same bits as the 4-wave kernel - same per-accumulator order of the three products - run
+    after run, and no wave ever gives up on a hand-off."""
+    from pmce_amd import _lib, ops
+    lib = _lib.load()
+    A = rnd("gemm.A", (M, K)).to(dev())
+    A[::5] *= 1e-3
+    W = rnd("gemm.W", (N, K), scale=K ** -0.5).to(dev())
+    b = rnd("gemm.b", (N,)).to(dev())
+    R = rnd("gemm.R", (M, N)).to(dev()) if res else None
+    Wp, ws = ops.pack_split_f16(W)
+    Ap = ops.split_rows_f16(A)
+    run = lambda: ops.gemm_nt_split(Ap, Wp, ws, b, R, act, a_packed=True, c_packed=cpk)
+    try:
+        lib.pmce_gemm_split_set_tuning(0)
+        ref = run().clone()
+        lib.pmce_gemm_split_set_tuning(3)
+        outs = [run().clone() for _ in range(6)]
+    finally:
+        lib.pmce_gemm_split_set_tuning(-1)
+    assert lib.pmce_gemm_ws_timeouts() == 0
+    for o in outs:
+        assert torch.equal(o.view(torch.int32), ref.view(torch.int32))
 
 
 def test_gemm_split_row_map():
