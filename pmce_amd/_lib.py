@@ -25,6 +25,8 @@ PROTOTYPES = {
     "pmce_model_tensor_name": [C.c_void_p, _i],
     "pmce_model_set_regressor_rows": [C.c_void_p, _i],
     "pmce_model_finalize": [C.c_void_p],
+    "pmce_model_finalize_on": [C.c_void_p, _s],
+    "pmce_model_set_gemm_mode_on": [C.c_void_p, _i, _s],
     "pmce_model_workspace_bytes": [C.c_void_p, _i],
     "pmce_model_workspace_offset": [C.c_void_p, _i, C.c_char_p],
     "pmce_lifter_forward": [C.c_void_p, _f, _f, _f, _i, _f, C.c_size_t, _s],
@@ -43,6 +45,8 @@ PROTOTYPES = {
     "pmce_model_gemm_mode": [C.c_void_p],
     "pmce_model_share_split_weights": [C.c_void_p, C.c_void_p],
     "pmce_model_set_split_min_batch": [C.c_void_p, _i],
+    "pmce_model_overflowed": [C.c_void_p],
+    "pmce_model_clear_overflow": [C.c_void_p],
     "pmce_model_profile_read": [C.c_void_p, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_longlong)],
     "pmce_gemm_nt_f32": [_f, _f, _f, _f, _f, _i, _i, _i, _l, _i, _l, _i, _i, _l, _l, _i, _l, _l, _i, _l, _l, _l, _l, _s],
     "pmce_gemm_set_tuning": [_i, _i],

@@ -1,4 +1,5 @@
-// Host-side error slot + version for libpmce_hip.so (no global mutable state besides a thread-local string).
+// Host-side error slot + version for libpmce_hip.so (no global mutable state besides a thread-local string and the thread-local
+// overflow sink of the call in progress).
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -6,6 +7,10 @@
 #include "common.hpp"
 
 static thread_local char g_err[512] = "";
+static thread_local unsigned* g_overflow_sink = nullptr;
+
+unsigned* pmce_overflow_sink(void) { return g_overflow_sink; }
+void pmce_set_overflow_sink(unsigned* w) { g_overflow_sink = w; }
 
 void pmce_set_error(const char* fmt, ...) {
   va_list ap;

@@ -11,10 +11,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define PMCE_ERR_ARG (-1)
 #define PMCE_ERR_LAUNCH (-2)
 #define PMCE_ERR_WORKSPACE (-3)
+#define PMCE_ERR_OVERFLOW (-4)
 
 // host-side error slot (thread-local; pmce_last_error_string() returns it)
 void pmce_set_error(const char* fmt, ...);
 int pmce_check_launch(const char* what);
+// Where the launchers of the calling thread point their kernels' "non-finite result" reports (a device-visible word, or null):
+// set by the model entry points for the duration of a call (model.cpp), null for stand-alone operator calls.
+unsigned* pmce_overflow_sink(void);
+void pmce_set_overflow_sink(unsigned* device_visible_word);
 
 // opt a kernel into > 64 KB of dynamic LDS, once per device (the attribute is per device: a process-wide flag would leave
 // the second GPU of a process without it).  `done` is the call site's static bit mask of devices already set.

@@ -7,8 +7,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct SplitParams {
   const float* A;       // fp32 [M][lda], or packed planes [M][K/16][16 hi | 16 lo*2^11] f16 (APACK)
-  const float* W;       // packed planes [N][K/16][16 hi | 16 lo] f16 of W * 2^s
-  const float* wscale;  // {2^s, 2^-s}
+  const float* W;       // packed planes [N][K/16][16 hi | 16 lo] f16 of W[n] * 2^s(n)
+  const float* wscale;  // [N]: 2^-s(n), one power of two per OUTPUT row of W (pmce_gemm_pack_split_f16)
   const float* bias;    // [N] or null
   const float* R;       // residual [M][ldc] or null
   float* C;
@@ -18,6 +18,7 @@ struct SplitParams {
   int c_div;             // > 0: C row r lives at (r % c_div) * c_lo + (r / c_div) * c_hi (elements); never with R
   long long c_lo, c_hi;
   int skew;  // start delay of the second workgroup per CU, in units of 4096 cycles
+  unsigned* oflow;  // device-visible word set to 1 when a result is not finite (an activation beyond f16's 65504, or fp32 overflow); may be null
 };
 
 // LDS-DMA: 64 lanes x 16 B from per-lane buffer offsets into LDS at M0 + lane*16 (see gemm_f32.hip)
@@ -37,6 +38,15 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, f16x8& 
   for (int e = 0; e < 8; ++e) hi[e] = (_Float16)v[e];
 #pragma unroll
   for (int e = 0; e < 8; ++e) lo[e] = (_Float16)((v[e] - (float)hi[e]) * 2048.0f);
+}
+
+// 1 / x for x = 2^e, e in [-126, 126], exactly: the exponent field mirrored around the bias
+__device__ __forceinline__ float pow2_recip(float x) { return __uint_as_float(0x7f000000u - __float_as_uint(x)); }
+
+// exponent field all ones: infinity or NaN
+__device__ __forceinline__ bool nonfinite(float v) { return __builtin_amdgcn_class(v, 0x203); }  // signalling / quiet NaN, -inf, +inf
+__device__ __forceinline__ void report_nonfinite(unsigned* sink, bool lane_saw_one) {
+  if (sink && __builtin_amdgcn_ballot_w64(lane_saw_one) != 0ull && (threadIdx.x & 63) == 0) *reinterpret_cast<volatile unsigned*>(sink) = 1u;
 }
 
 template <int N>

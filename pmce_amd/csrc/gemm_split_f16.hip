@@ -7,9 +7,10 @@
 //     a = ahi + alo * 2^-11,  w * 2^s = whi + wlo            (hi = rne16(x), lo = rne16(x - hi); 22 mantissa bits each)
 //     a * w * 2^s  =  ahi whi + ahi wlo + alo (whi 2^-11)  +  O(2^-22)
 // (the dropped lo*lo term and the planes' own rounding sit below the fp32 product's accumulation error: measured against an
-// fp64 product the result is CLOSER than the fp32 pipe's, tests/test_gpu_ops.py).  2^s (a power of two per weight, chosen
-// by pmce_gemm_pack_split_f16) lifts max|w| to [2^14, 2^15) so that wlo and whi 2^-11 are normal f16 numbers for every weight
-// that matters; alo carries 2^11 so that it is normal wherever ahi is.  No operand relies on f16 sub-normals.
+// fp64 product the result is CLOSER than the fp32 pipe's, tests/test_gpu_ops.py).  2^s - a power of two per OUTPUT ROW of W
+// (round 3; per tensor before), chosen by pmce_gemm_pack_split_f16 - lifts the row's max|w| to [2^14, 2^15) so that wlo and
+// whi 2^-11 are normal f16 numbers for every weight within 2^-17 of the row's largest: an outlier row cannot starve the other
+// rows' lo planes.  alo carries 2^11 so that it is normal wherever ahi is.  No operand relies on f16 sub-normals.
 //
 // Kernel: 256 threads = 2x2 waves, wave tile (32 TM) x (32 TN), block tile (64 TM) x (64 TN), k-tile 16.
 //  * W is PACKED once: per row and 16-wide k-tile, 16 f16 hi then 16 f16 lo (64 bytes - the size of a 16-wide fp32 k-tile of
@@ -38,7 +39,7 @@ struct SplitCfg {
 #else
   static constexpr int NS = STAGE_FLOATS * 4 * 4 <= 64 * 1024 ? 4 : 3;
 #endif
-  static constexpr int LDS_BYTES = NS * STAGE_FLOATS * 4 + 2 * 1024;  // + two bias slices (this tile's, the next one's)
+  static constexpr int LDS_BYTES = NS * STAGE_FLOATS * 4 + 4 * 1024;  // + two {bias, 2^-s} slice pairs (this tile's, the next one's)
   static constexpr int DPW = (BM + BN) / 64;  // DMA instructions per wave per k-tile (16 rows each)
 };
 
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, 0xffffffff, 0x00020000);
   // bounded: lanes past bias[N-1] read zeros
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.N * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wscale), 0, p.N * 4, 0x00020000);
 
   // ---- DMA side.  Instruction q of a wave moves row group g = wave + 4 q of a stage: lane L -> row 16 g + (L >> 2), PHYSICAL
   // chunk L & 3, which holds logical chunk (L & 3) ^ ((row >> 2) & 3) = (L & 3) ^ ((L >> 4) & 3). ----
@@ -119,8 +121,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
     set_ptrs(mb, i_nb);
   }
   auto issue_next = [&]() {
-    if (i_kt == 0) {  // the tile's bias slice: 64 lanes x 4 floats
-      if (p.bias && wave == 0) sdma16(rsrc_b, (unsigned)lane * 16u, i_nb * 4, lds0 + NS * SF * 4 + i_par * 1024);
+    if (i_kt == 0) {  // the tile's bias and 2^-s slices: 64 lanes x 4 floats each
+      if (p.bias && wave == 0) sdma16(rsrc_b, (unsigned)lane * 16u, i_nb * 4, lds0 + NS * SF * 4 + i_par * 2048);
+      if (wave == 1) sdma16(rsrc_s, (unsigned)lane * 16u, i_nb * 4, lds0 + NS * SF * 4 + i_par * 2048 + 1024);
       i_par ^= 1;
     }
     issue(i_kt, i_stage);
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
   for (int q = 0; q < NS - 1; ++q)
     if (issued < total) issue_next();
 
-  const float w_up = p.wscale[0], w_down = p.wscale[1];
+  float w_down[TN];  // 2^-s of this lane's column in each of the wave's TN 32-column blocks
   const int swz = (n0 >> 2) & 3;
   const int a_row = (wm * WM + n0) * 16, w_row = BM * 16 + (wn * WN + n0) * 16;  // floats inside a stage
   // chunk offsets (floats) of this lane's operand fragments
@@ -162,12 +165,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
     __syncthreads();  // every wave's part of k-tile `it` is in LDS; every wave is done reading the stage of k-tile it-1
     if (issued < total) issue_next();
 
-    if (kt == 0) {  // the bias slice (scaled like W) is the accumulators' initial value
-      const float* sB = lds + NS * SF + c_par * 256 + wn * WN + n0;
+    if (kt == 0) {  // the bias slice (scaled like its row of W) is the accumulators' initial value
+      const float* sB = lds + NS * SF + c_par * 512 + wn * WN + n0;
       c_par ^= 1;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const float bv = p.bias ? sB[j * 32] * w_up : 0.f;
+        w_down[j] = sB[256 + j * 32];
+        const float bv = p.bias ? sB[j * 32] * pow2_recip(w_down[j]) : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -212,6 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
     if (++kt == nk) {
       // ---- epilogue of the finished tile, straight from the accumulators ----
       kt = 0;
+      bool bad = false;  // this lane produced a non-finite value (an operand beyond the f16 range, or fp32 overflow)
       if constexpr (OPACK) {
         // The result is itself the A operand of the next product (fc1 -> fc2): written pre-split, [row][K/16][16 hi | 16 lo*2^11]
         // f16 in the bytes of the fp32 row.  A lane holds ONE column of 16 rows; adjacent lanes pair up (DPP quad_perm) so that
@@ -227,12 +232,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
             _Float16* __restrict__ Cp = reinterpret_cast<_Float16*>(p.C) + (size_t)mrow * (2 * p.ldc) + 2 * cb + colf;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-              f32x2 v = {acc[i][j][r] * w_down, acc[i][j][r + 1] * w_down};
+              f32x2 v = {acc[i][j][r] * w_down[j], acc[i][j][r + 1] * w_down[j]};
               if (ACT == 1) v = gelu_erf2(v);
 #pragma unroll
               for (int e = 0; e < 2; ++e) {
                 const float x = e ? v.y : v.x;
                 const _Float16 h = (_Float16)x;
+                bad = bad || nonfinite((float)h);  // also a finite x beyond f16's 65504: the next product could not read it
                 const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
                 const unsigned w = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
                 const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);  // lane ^ 1
@@ -243,6 +249,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
             }
           }
         }
+        report_nonfinite(p.oflow, bad);
         li += gx;
         if (li < chunk_len) tile_coords(chunk_start + li, m_base, n_base);
         continue;
@@ -258,8 +265,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
             for (int r = 0; r < 16; ++r) {
               const int mm = m_base + wm * WM + i * 32 + 4 * hb + (r & 3) + 8 * (r >> 2);
               if (n < p.N && mm < p.M) {
-                float v = acc[i][j][r] * w_down;
+                float v = acc[i][j][r] * w_down[j];
                 if (ACT == 1) v = gelu_erf(v);
+                bad = bad || nonfinite(v);
                 p.C[(long long)(mm % p.c_div) * p.c_lo + (long long)(mm / p.c_div) * p.c_hi + n] = v;
               }
             }
@@ -293,11 +301,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
           const unsigned so = blk_off(b);
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
-            f32x2 v = {acc[i][j][r] * w_down, acc[i][j][r + 1] * w_down};
+            f32x2 v = {acc[i][j][r] * w_down[j], acc[i][j][r + 1] * w_down[j]};
             if (ACT == 1) v = gelu_erf2(v);
             if (RES) v += f32x2{rv[b & 1][r], rv[b & 1][r + 1]};
             // aux 2 = nt: streaming stores measure 5-9 % faster than write-back ones here
             const float vx = v.x, vy = v.y;  // (a bit_cast applied to the vector component itself reads component 0 both times)
+            bad = bad || nonfinite(vx) || nonfinite(vy);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vx), rsrc_c, voff[r], so, 2);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vy), rsrc_c, voff[r + 1], so, 2);
           }
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
             const float* __restrict__ Rp = RES ? p.R + (size_t)mrow * p.ldc + n : nullptr;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {  // the same arithmetic as the full-tile path (results do not depend on tile shape)
-              f32x2 v = {acc[i][j][r] * w_down, acc[i][j][r + 1] * w_down};
+              f32x2 v = {acc[i][j][r] * w_down[j], acc[i][j][r + 1] * w_down[j]};
               if (ACT == 1) v = gelu_erf2(v);
 #pragma unroll
               for (int e = 0; e < 2; ++e) {
@@ -321,6 +330,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
                 if (n < p.N && mrow + rr < p.M) {
                   float o = e ? v.y : v.x;
                   if (RES) o += Rp[rr * p.ldc];
+                  bad = bad || nonfinite(o);
                   Cp[rr * p.ldc] = o;
                 }
               }
@@ -328,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
           }
         }
       }
+      report_nonfinite(p.oflow, bad);
       li += gx;
       if (li < chunk_len) tile_coords(chunk_start + li, m_base, n_base);
     }
@@ -421,6 +432,7 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
   p.A = A; p.W = Wp; p.wscale = wscale; p.bias = bias; p.R = R; p.C = C;
   p.M = M; p.N = N; p.K = K; p.lda = (unsigned)lda; p.ldc = (unsigned)ldc;
   p.c_div = c_div; p.c_lo = c_lo; p.c_hi = c_hi;
+  p.oflow = pmce_overflow_sink();
   {  // half a tile of matrix time: nk iterations x 3*TM*TN instructions x 32 cycles (TM*TN = 8 or 4), / 2, in 4096-cycle units
     const int knob = g_split_skew.load(std::memory_order_relaxed);
     p.skew = knob >= 0 ? knob : (K / 16) * 12 * 32 / 4096 + 1;
@@ -458,50 +470,36 @@ extern "C" int pmce_gemm_nt_split_f16_rowmap(const float* A, const float* Wp, co
 }
 
 // ---- operand packing ------------------------------------------------------------------------------------------------------
-// W[N][ldw] fp32 -> Wp[N][K/16][2][16] f16 (N*K floats of storage) and wscale = {2^s, 2^-s, max|W| bits, 0}, s chosen so
-// that max|W| * 2^s lies in [2^14, 2^15): hi = rne16(W 2^s), lo = rne16(W 2^s - hi) - both normal f16 for every weight within
-// 2^-17 of the largest (smaller ones lose bits that are 2^-28 of the largest product).
-__global__ void split_absmax_kernel(const float* __restrict__ W, int N, int K, int ldw, unsigned* __restrict__ out) {
-  float m = 0.f;
-  const long long total = (long long)N * K;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
-    m = fmaxf(m, fabsf(W[(i / K) * ldw + (i % K)]));
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order like their bit patterns
-}
-__global__ void split_pack_kernel(const float* __restrict__ W, int N, int K, int ldw, _Float16* __restrict__ Wp,
-                                  float* __restrict__ wscale) {
-  const float mx = __uint_as_float(reinterpret_cast<const unsigned*>(wscale)[2]);
-  int e = 0;
-  if (mx > 0.f) frexpf(mx, &e);  // mx = f * 2^e, f in [0.5, 1)
-  const float up = mx > 0.f ? ldexpf(1.f, 15 - e) : 1.f, down = mx > 0.f ? ldexpf(1.f, e - 15) : 1.f;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    wscale[0] = up;
-    wscale[1] = down;
-  }
-  const long long total = (long long)N * K;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long n = i / K;
-    const int k = (int)(i % K);
-    const float ws = W[n * ldw + k] * up;
-    const _Float16 hi = (_Float16)ws;
-    const _Float16 lo = (_Float16)(ws - (float)hi);
-    _Float16* row = Wp + (n * K + (k / 16) * 16) * 2;  // 32 f16 per (row, k-tile)
-    row[k % 16] = hi;
-    row[16 + k % 16] = lo;
+// W[N][ldw] fp32 -> Wp[N][K/16][2][16] f16 (N*K floats of storage) and wscale[N] = 2^-s(n), s(n) chosen per row so that the
+// row's max|W| * 2^s lies in [2^14, 2^15): hi = rne16(W 2^s), lo = rne16(W 2^s - hi) - both normal f16 for every weight within
+// 2^-17 of the row's largest (smaller ones lose bits that are 2^-28 of the row's largest product).  One wave per row.
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ W, int N, int K, int ldw, _Float16* __restrict__ Wp,
+                                                         float* __restrict__ wscale) {
+  const int lane = threadIdx.x & 63;
+  for (long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); n < N; n += (long long)gridDim.x * 4) {
+    const float* __restrict__ row = W + n * ldw;
+    float m = 0.f;
+    for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(row[k]));
+    m = wave_max(m);
+    int e = 0;
+    if (m > 0.f && m < 3.0e38f) frexpf(m, &e);  // m = f * 2^e, f in [0.5, 1)
+    e = max(-110, min(e, 125));                  // keeps 2^(15-e) and 2^(e-15) normal fp32 numbers
+    const float up = m > 0.f ? ldexpf(1.f, 15 - e) : 1.f, down = m > 0.f ? ldexpf(1.f, e - 15) : 1.f;
+    if (lane == 0) wscale[n] = down;
+    _Float16* __restrict__ out = Wp + n * K * 2;
+    for (int k = lane; k < K; k += 64) {
+      const float ws = row[k] * up;
+      const _Float16 hi = (_Float16)ws;
+      const _Float16 lo = (_Float16)(ws - (float)hi);
+      out[(k / 16) * 32 + (k % 16)] = hi;       // 32 f16 per (row, k-tile)
+      out[(k / 16) * 32 + 16 + (k % 16)] = lo;
+    }
   }
 }
 extern "C" int pmce_gemm_pack_split_f16(const float* W, int N, int K, int ldw, float* Wp, float* wscale, hipStream_t stream) {
   PMCE_REQUIRE(W && Wp && wscale, "gemm_pack_split: null pointer");
   PMCE_REQUIRE(N > 0 && K > 0 && K % 16 == 0 && ldw >= K, "gemm_pack_split: need N>0, K%%16==0, ldw>=K (N=%d K=%d ldw=%d)", N, K, ldw);
-  if (const hipError_t rc = hipMemsetAsync(wscale, 0, 4 * sizeof(float), stream); rc != hipSuccess) {
-    pmce_set_error("gemm_pack_split: hipMemsetAsync failed: %s", hipGetErrorString(rc));
-    return PMCE_ERR_LAUNCH;
-  }
-  const long long total = (long long)N * K;
-  const long long want = (total + 256 * 8 - 1) / (256 * 8);
-  const int blocks = (int)(want < 2048 ? want : 2048);
-  hipLaunchKernelGGL(split_absmax_kernel, dim3(blocks), dim3(256), 0, stream, W, N, K, ldw, reinterpret_cast<unsigned*>(wscale) + 2);
+  const int blocks = (N + 3) / 4 < 4096 ? (N + 3) / 4 : 4096;
   hipLaunchKernelGGL(split_pack_kernel, dim3(blocks), dim3(256), 0, stream, W, N, K, ldw, reinterpret_cast<_Float16*>(Wp), wscale);
   return pmce_check_launch("gemm_pack_split_f16");
 }

@@ -35,8 +35,8 @@ constexpr int WS_STAGE_FLOATS = (WS_BM + WS_BN) * 16;
 constexpr int WS_STAGE_BYTES = WS_STAGE_FLOATS * 4;
 constexpr int WS_PPL = (WS_BM + WS_BN) / 16 / WS_NLW;  // DMA pieces (16 rows x 64 B) per loader per k-tile: 7
 constexpr int WS_APL = WS_BM / 16 / WS_NLW;            // of which A's: 3
-constexpr int WS_SLICE_OFF = WS_NS * WS_STAGE_FLOATS;  // two bias slices of 256 floats (this tile's, the next one's)
-constexpr int WS_FLAG_OFF = WS_SLICE_OFF + 2 * 256;    // land[4] (16 words), prog[12] (16 words), then a 256-byte dump slot
+constexpr int WS_SLICE_OFF = WS_NS * WS_STAGE_FLOATS;  // two {bias, 2^-s} slice pairs of 256 floats each (this tile's, the next one's)
+constexpr int WS_FLAG_OFF = WS_SLICE_OFF + 4 * 256;    // land[4] (16 words), prog[12] (16 words), then a 256-byte dump slot
 constexpr int WS_LDS_BYTES = (WS_FLAG_OFF + 32 + 64) * 4;
 constexpr int WS_SPIN_LIMIT = 1 << 18;
 constexpr int WS_DEFAULT_OPT = 9;  // measured best: no dynamic priorities, loaders at normal priority (profiles/r03_a_*)
@@ -155,6 +155,7 @@ __global__ __launch_bounds__(1024) void gemm_split_ws_kernel(SplitParams p) {
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, 0xffffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b =  // bounded: lanes past bias[N-1] read zeros
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.N * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wscale), 0, p.N * 4, 0x00020000);
     // piece g = l + 4 q of a stage holds rows 16 g .. 16 g + 15 (A rows first): lane L -> row 16 g + (L >> 2), PHYSICAL chunk
     // L & 3, which holds logical chunk (L & 3) ^ ((row >> 2) & 3) = (L & 3) ^ ((L >> 4) & 3)
     const int drow = lane >> 2;
@@ -183,8 +184,9 @@ __global__ __launch_bounds__(1024) void gemm_split_ws_kernel(SplitParams p) {
         const long long c0 = WS_CLK();
         if (g >= (unsigned)WS_NS) ws_wait_all(prog_lane, g - WS_NS + 1, dead, fails);  // every compute wave holds the stage's previous k-tile
         const long long c1 = WS_CLK();
-        if (kt == 0 && l == 0) {  // the tile's bias slice rides in ahead of its first k-tile
-          if (p.bias) sdma16(rsrc_b, (unsigned)lane * 16u, nb * 4, lds0 + (WS_SLICE_OFF + par * 256) * 4);
+        if (kt == 0 && l == 0) {  // the tile's bias and 2^-s slices ride in ahead of its first k-tile
+          if (p.bias) sdma16(rsrc_b, (unsigned)lane * 16u, nb * 4, lds0 + (WS_SLICE_OFF + par * 512) * 4);
+          sdma16(rsrc_s, (unsigned)lane * 16u, nb * 4, lds0 + (WS_SLICE_OFF + par * 512 + 256) * 4);
           par ^= 1;
         }
         if constexpr ((DBG & 2) == 0) {
@@ -226,10 +228,10 @@ __global__ __launch_bounds__(1024) void gemm_split_ws_kernel(SplitParams p) {
   // their uses share a basic block (across blocks hipcc falls back to lgkmcnt(0)).
   const int n0 = lane & 31, hb = lane >> 5;
   const int wm = wave >> 2, wn = wave & 3;  // 3 x 4 waves of 64 x 64
-  const float w_up = p.wscale[0], w_down = p.wscale[1];
+  float w_down[2];  // 2^-s of this lane's column in the wave's two 32-column blocks
   const int swz = (n0 >> 2) & 3;
   const int a_row = (wm * 64 + n0) * 16, w_row = (WS_BM + wn * 64 + n0) * 16;  // floats inside a stage
-  const int ch = 4 * (hb ^ swz), cl = 4 * ((2 + hb) ^ swz);                    // hi / lo plane, k = 8 hb + [0,8)
+  const int ch = 4 * (hb ^ swz);  // the hi plane's chunk of k = 8 hb + [0,8); the lo plane's is ch ^ 8, i.e. byte address ^ 32
   const unsigned land_lane = land0 + 4 * (lane & 3);
   const unsigned my_prog = prog0 + 4 * wave;
   // The word every lane reads beside the fragments: land[lane & 3] - except lanes 4..6, which read the progress words of the three
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(1024) void gemm_split_ws_kernel(SplitParams p) {
       const long long c0 = WS_CLK();
       if constexpr ((DBG & 16) == 0) {  // all four loaders' pieces of this k-tile are in LDS
         if ((__builtin_amdgcn_ballot_w64((int)(peek - (g + 1)) < 0) & LAND_LANES) != 0ull) {  // (peek = 0 before the first k-tile)
-          ++polled;
+          polled += 1;
           ws_wait_all(land_lane, g + 1, dead, fails);
         }
         if constexpr ((OPT & 1) == 0) {
@@ -267,13 +269,13 @@ __global__ __launch_bounds__(1024) void gemm_split_ws_kernel(SplitParams p) {
         }
       }
       const long long c1 = WS_CLK();
-      const float* sA = lds + s * WS_STAGE_FLOATS;
       if (kt == 0) {  // the bias slice (scaled like W) is the accumulators' initial value
-        const float* sB = lds + WS_SLICE_OFF + par * 256 + wn * 64 + n0;
+        const float* sB = lds + WS_SLICE_OFF + par * 512 + wn * 64 + n0;
         par ^= 1;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const float bv = p.bias ? sB[j * 32] * w_up : 0.f;
+          w_down[j] = sB[256 + j * 32];
+          const float bv = p.bias ? sB[j * 32] * pow2_recip(w_down[j]) : 0.f;
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -361,6 +363,7 @@ __global__ __launch_bounds__(1024) void gemm_split_ws_kernel(SplitParams p) {
     float* const c_base = ws_uniform(p.C + (size_t)wm0 * p.ldc);
     const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(c_base, 0, 0xffffffff, 0x00020000);
     // (FULL = the wave's 64 rows all exist; otherwise - the matrix's last row tile only - every access is predicated on its row)
+    bool bad = false;  // this lane produced a non-finite value (an operand beyond the f16 range, or fp32 overflow)
     auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
       constexpr bool FULL = decltype(full_tag)::value;
       auto row_ok = [&](int i, int r) __attribute__((always_inline)) { return FULL || 32 * i + (r & 3) + 8 * (r >> 2) < rows_left; };
@@ -379,12 +382,13 @@ __global__ __launch_bounds__(1024) void gemm_split_ws_kernel(SplitParams p) {
           const unsigned so = ((unsigned)(i * 32) * p.ldc + (unsigned)(wn0 + j * 32)) * 4u;  // (a packed row takes the fp32 row's bytes)
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
-            f32x2 v = {acc[i][j][r] * w_down, acc[i][j][r + 1] * w_down};
+            f32x2 v = {acc[i][j][r] * w_down[j], acc[i][j][r + 1] * w_down[j]};
             if (ACT == 1) v = gelu_erf2(v);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
               const float x = e ? v.y : v.x;
               const _Float16 h = (_Float16)x;
+              bad = bad || nonfinite((float)h);  // also a finite x beyond f16's 65504: the next product could not read it
               const _Float16 lo = (_Float16)((x - (float)h) * 2048.0f);
               const unsigned w = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
               const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);  // lane ^ 1
@@ -421,10 +425,11 @@ __global__ __launch_bounds__(1024) void gemm_split_ws_kernel(SplitParams p) {
           const unsigned so = blk_off(b);
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
-            f32x2 v = {acc[i][j][r] * w_down, acc[i][j][r + 1] * w_down};
+            f32x2 v = {acc[i][j][r] * w_down[j], acc[i][j][r + 1] * w_down[j]};
             if (ACT == 1) v = gelu_erf2(v);
             if (RES) v += f32x2{rv[b & 1][r], rv[b & 1][r + 1]};
             const float vx = v.x, vy = v.y;
+            bad = bad || nonfinite(vx) || nonfinite(vy);
             if constexpr ((DBG & 256) != 0) if (b == 3 && r >= 14) continue;  // timing experiment: 62 stores per tile
             if constexpr ((DBG & 512) != 0) if (b == 3 && r >= 8) continue;   // timing experiment: 56 stores per tile
             if (row_ok(i, r)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vx), rsrc_c, voff[r], so, 2);  // aux 2 = nt
@@ -435,8 +440,10 @@ __global__ __launch_bounds__(1024) void gemm_split_ws_kernel(SplitParams p) {
     };
     if (full) epilogue(std::true_type{});
     else epilogue(std::false_type{});
+    report_nonfinite(p.oflow, bad);
     if constexpr ((DBG & 128) != 0) pt[3] += WS_CLK() - ce0;
   }
+  (void)polled;
   if (lane == 0) {
     WS_STAT(0, fails);
     WS_STAT(2, polled);

@@ -27,7 +27,7 @@ struct GruStepArgs {
   float* hout[2];         // + row*h_rs + unit
   long long gi_rs, h_rs;
   int B, H;
-  const float* wscale;    // SPLIT form: {2^s, 2^-s} of the packed W_hh (both directions share one scale)
+  const float* wscale;    // SPLIT form: [2 * 3H] 2^-s per row of the packed W_hh (direction-major, as packed: pmce_gemm_pack_split_f16)
 };
 
 typedef _Float16 gru_f16x8 __attribute__((ext_vector_type(8)));
@@ -204,7 +204,9 @@ __global__ __launch_bounds__(128 * NQ) void gru_step_kernel(GruStepArgs a) {
   // gate update on the D layout: unit = u0 + (lane & 31), batch row = m0 + rb*32 + (r&3) + 8*(r>>2) + 4*hb
   const float* __restrict__ bh = a.bhh[d];
   const float bhr = bh[u], bhz = bh[H + u], bhn = bh[2 * H + u];
-  const float w_down = SPLIT ? a.wscale[1] : 1.f;  // the packed W_hh carries 2^s
+  // the packed W_hh rows carry 2^s(row): rows u, H + u, 2 H + u of direction d
+  const float wd_r = SPLIT ? a.wscale[d * 3 * H + u] : 1.f, wd_z = SPLIT ? a.wscale[d * 3 * H + H + u] : 1.f,
+              wd_n = SPLIT ? a.wscale[d * 3 * H + 2 * H + u] : 1.f;
   float* __restrict__ ho = a.hout[d];
 #pragma unroll
   for (int q = 0; q < RW; ++q) {
@@ -217,9 +219,9 @@ __global__ __launch_bounds__(128 * NQ) void gru_step_kernel(GruStepArgs a) {
       an = sel ? acc[2][r] : an;
     }
     if (SPLIT) {
-      ar *= w_down;
-      az *= w_down;
-      an *= w_down;
+      ar *= wd_r;
+      az *= wd_z;
+      an *= wd_n;
     }
     const int r = RW * kq + q;
     const int m = m0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;

@@ -112,6 +112,10 @@ struct pmce_model {
   bool split_overlap = true;
   bool ffn_f16 = true;
   bool split_now = false;  // decision for the call in progress (set by check_ws, the first thing every entry point does)
+  // Sticky "a product of this model produced a non-finite value" word: 4 bytes of pinned host memory the device can write
+  // (hipHostMalloc, mapped), so that reading it costs no synchronisation.  Set by the split-f16 products' epilogues (an activation
+  // beyond f16's 65504 turns into inf / nan there, and so does fp32 overflow), checked by every entry point BEFORE it launches.
+  std::shared_ptr<unsigned> oflow;  // shared by handles cloned onto the same weights (pipeline lanes): one model, one flag
   // regressor (optional)
   const int* jr_indptr = nullptr;
   const int* jr_indices = nullptr;
@@ -447,9 +451,11 @@ int gru_layer(pmce_model* m, int layer, const float* gi_f, const float* gi_b, lo
   const bool split = m->split_now && sw.wp;
   const float* whh = split ? sw.wp : (layer == 0 ? m->w.whh0 : m->w.whh1);  // the packed rows keep the fp32 row stride
   const float* bhh = layer == 0 ? m->w.bhh0 : m->w.bhh1;
+  // (the packed rows' 2^-s: one per row, direction-major like the weight itself - a backward-only step starts at row 3 GH)
   auto step = [&](const float* gi0, const float* gi1, const float* w0, const float* w1, const float* b0, const float* b1,
                   const float* hp0, const float* hp1, float* ho0, float* ho1, int ndir) {
-    return split ? pmce_gru_step_split_f32(gi0, gi1, w0, w1, sw.scale, b0, b1, hp0, hp1, ho0, ho1, gi_rs, 2 * GH, B, GH, ndir, stream)
+    const float* scale = split ? sw.scale + (w0 == whh ? 0 : 3 * GH) : nullptr;
+    return split ? pmce_gru_step_split_f32(gi0, gi1, w0, w1, scale, b0, b1, hp0, hp1, ho0, ho1, gi_rs, 2 * GH, B, GH, ndir, stream)
                  : pmce_gru_step_f32(gi0, gi1, w0, w1, b0, b1, hp0, hp1, ho0, ho1, gi_rs, 2 * GH, B, GH, ndir, stream);
   };
   const long long YS = (long long)B * 2 * GH;
@@ -499,8 +505,11 @@ int gru_rest(pmce_model* m, int B, DecoderWs& w, hipStream_t stream) {
   // layer 1: only y[8] is consumed (CoevoDecoder.py:229,241-243) -> fwd needs t = 0..8, bwd t = 15..8.
   float* GI1f = w.GI1;
   float* GI1b = w.GI1 + (long long)9 * B * 3 * GH;
-  SplitW wih1_b = m->s_wih1;  // rows 3072.. of the packed weight (same row stride as the fp32 one), same scale
-  if (wih1_b.wp) wih1_b.wp += (long long)3 * GH * 2 * GH;
+  SplitW wih1_b = m->s_wih1;  // rows 3072.. of the packed weight (same row stride as the fp32 one) and of its per-row 2^-s
+  if (wih1_b.wp) {
+    wih1_b.wp += (long long)3 * GH * 2 * GH;
+    wih1_b.scale += 3 * GH;
+  }
   RUN(P_GEMM_GRU_IN, lgemm(m, w.Y0, m->w.wih1, m->s_wih1, m->w.bih1, nullptr, GI1f, 9 * B, 3 * GH, 2 * GH, 2 * GH,
                            3 * GH, 0, stream));
   RUN(P_GEMM_GRU_IN, lgemm(m, w.Y0 + (long long)8 * B * 2 * GH, m->w.wih1 + (long long)3 * GH * 2 * GH, wih1_b,
@@ -661,13 +670,14 @@ int ensure_side(pmce_model* m) {
 
 // ============================================================================================================
 namespace {
-// (Re)build the packed f16 planes of every lifter Linear weight in model-owned memory, or drop them (fp32 mode / no
-// lifter).  Runs on the null stream and waits: a load-time step, like the packing the host side does.
-int build_split_weights(pmce_model* m) {
+// (Re)build the packed f16 planes of every large weight in model-owned memory, or drop them (fp32 mode).  A load-time step, like
+// the packing the host side does: runs on `stream` - the stream the caller produced the fp32 weights on (a torch side stream is
+// non-blocking: the null stream would NOT be ordered behind it) - and waits for that stream only.
+int build_split_weights(pmce_model* m, hipStream_t stream) {
   if (m->split_adopted && m->split_gemm && m->split_arena) return PMCE_OK;  // another handle's planes of the same weights
   m->split_adopted = false;
   if (m->split_arena) {
-    (void)hipDeviceSynchronize();  // forwards in flight may still read the old planes
+    (void)hipDeviceSynchronize();  // forwards in flight (any stream, any lane) may still read the old planes; not capturable
     m->split_arena.reset();        // frees them unless another handle shares them
   }
   for (auto& kind : m->sblk)
@@ -699,7 +709,7 @@ int build_split_weights(pmce_model* m) {
   }
   if (items.empty()) return PMCE_OK;
   size_t floats = 0;
-  for (auto& it : items) floats += (((size_t)it.n * it.k + 63) & ~(size_t)63) + 64;
+  for (auto& it : items) floats += (((size_t)it.n * it.k + 63) & ~(size_t)63) + (((size_t)it.n + 63) & ~(size_t)63);  // planes + 2^-s per row
   float* arena = nullptr;
   const hipError_t rc = hipMalloc(reinterpret_cast<void**>(&arena), floats * sizeof(float));
   if (rc == hipSuccess) m->split_arena = std::shared_ptr<float>(arena, [](float* q) { (void)hipFree(q); });
@@ -712,15 +722,31 @@ int build_split_weights(pmce_model* m) {
   for (auto& it : items) {
     float* wp = p;
     float* sc = p + (((size_t)it.n * it.k + 63) & ~(size_t)63);
-    p = sc + 64;
-    PMCE_TRY(pmce_gemm_pack_split_f16(it.w, it.n, it.k, it.k, wp, sc, nullptr));
+    p = sc + (((size_t)it.n + 63) & ~(size_t)63);
+    PMCE_TRY(pmce_gemm_pack_split_f16(it.w, it.n, it.k, it.k, wp, sc, stream));
     it.dst->wp = wp;
     it.dst->scale = sc;
   }
-  if (hipStreamSynchronize(nullptr) != hipSuccess) {
+  if (hipStreamSynchronize(stream) != hipSuccess) {
     pmce_set_error("model_finalize: packing the split weights failed");
     return PMCE_ERR_LAUNCH;
   }
+  return PMCE_OK;
+}
+}  // namespace
+
+namespace {
+// the sticky overflow word: pinned host memory the device can write (made at finalize: creating a handle needs no GPU)
+int ensure_overflow_word(pmce_model* m) {
+  if (m->oflow) return PMCE_OK;
+  unsigned* w = nullptr;
+  if (hipHostMalloc(reinterpret_cast<void**>(&w), sizeof(unsigned), hipHostMallocMapped) != hipSuccess || !w) {
+    (void)hipGetLastError();
+    pmce_set_error("model_finalize: hipHostMalloc of the overflow word failed");
+    return PMCE_ERR_LAUNCH;
+  }
+  *w = 0u;
+  m->oflow = std::shared_ptr<unsigned>(w, [](unsigned* q) { (void)hipHostFree(q); });
   return PMCE_OK;
 }
 }  // namespace
@@ -792,7 +818,8 @@ int pmce_model_set_regressor_rows(pmce_model* m, int rows) {
   return PMCE_OK;
 }
 
-int pmce_model_finalize(pmce_model* m) {
+int pmce_model_finalize(pmce_model* m) { return pmce_model_finalize_on(m, nullptr); }
+int pmce_model_finalize_on(pmce_model* m, pmce_stream_t stream) {
   PMCE_REQUIRE(m, "model_finalize: null model");
   // a model may carry only the lifter (LiftTester path, lib/core/base.py:56,357) or only the decoder
   bool any_l = false, all_l = true, any_d = false, all_d = true;
@@ -818,16 +845,18 @@ int pmce_model_finalize(pmce_model* m) {
     auto it = m->ptr.find(sl.name);
     *sl.dst = it == m->ptr.end() ? nullptr : it->second;
   }
-  PMCE_TRY(build_split_weights(m));
+  PMCE_TRY(ensure_overflow_word(m));
+  PMCE_TRY(build_split_weights(m, stream));
   m->finalized = true;
   return PMCE_OK;
 }
 
-int pmce_model_set_gemm_mode(pmce_model* m, int split_f16) {
+int pmce_model_set_gemm_mode(pmce_model* m, int split_f16) { return pmce_model_set_gemm_mode_on(m, split_f16, nullptr); }
+int pmce_model_set_gemm_mode_on(pmce_model* m, int split_f16, pmce_stream_t stream) {
   PMCE_REQUIRE(m, "model_set_gemm_mode: null model");
   if (m->split_gemm != (split_f16 != 0)) {
     m->split_gemm = split_f16 != 0;
-    if (m->finalized) PMCE_TRY(build_split_weights(m));
+    if (m->finalized) PMCE_TRY(build_split_weights(m, stream));
   }
   return PMCE_OK;
 }
@@ -849,6 +878,15 @@ int pmce_model_share_split_weights(pmce_model* dst, const pmce_model* src) {
   dst->s_ada = src->s_ada; dst->s_final = src->s_final;
   dst->split_gemm = true;
   dst->split_adopted = true;
+  dst->oflow = src->oflow;  // lanes of one model report to one word
+  return PMCE_OK;
+}
+int pmce_model_overflowed(const pmce_model* m) {
+  return m && m->oflow && *reinterpret_cast<const volatile unsigned*>(m->oflow.get()) != 0u ? 1 : 0;
+}
+int pmce_model_clear_overflow(pmce_model* m) {
+  PMCE_REQUIRE(m && m->oflow, "model_clear_overflow: null model");
+  *reinterpret_cast<volatile unsigned*>(m->oflow.get()) = 0u;
   return PMCE_OK;
 }
 int pmce_model_set_split_min_batch(pmce_model* m, int clips) {
@@ -891,8 +929,20 @@ long long pmce_model_workspace_offset(const pmce_model* m, int batch, const char
   return (long long)reinterpret_cast<uintptr_t>(p);  // the carver ran on a null base: the pointer value IS the offset
 }
 
+namespace {
+struct SinkGuard {  // the launchers of this thread report to the model's flag only while one of its entry points runs
+  ~SinkGuard() { pmce_set_overflow_sink(nullptr); }
+};
+}  // namespace
+
 static int check_ws(pmce_model* m, int batch, void* ws, size_t ws_bytes) {
   PMCE_REQUIRE(m && m->finalized, "model not finalized (call pmce_model_finalize after registering all tensors)");
+  if (m->oflow && *reinterpret_cast<volatile unsigned*>(m->oflow.get()) != 0u) {
+    pmce_set_error("an earlier call on this model produced non-finite values in a product of the split-f16 form (an activation beyond "
+                   "the f16 range, |a| > 65504, or fp32 overflow): its outputs are invalid.  pmce_model_clear_overflow re-arms the "
+                   "model; pmce_model_set_gemm_mode(m, 0) computes on the fp32 matrix pipe, which has fp32's range");
+    return PMCE_ERR_OVERFLOW;
+  }
   PMCE_REQUIRE(batch > 0, "batch must be positive");
   PMCE_REQUIRE(ws && (reinterpret_cast<uintptr_t>(ws) & 255) == 0, "workspace must be non-null and 256-byte aligned");
   if (ws_bytes < pmce_model_workspace_bytes(m, batch)) {
@@ -900,12 +950,14 @@ static int check_ws(pmce_model* m, int batch, void* ws, size_t ws_bytes) {
     return PMCE_ERR_WORKSPACE;
   }
   m->split_now = m->split_gemm && batch >= m->split_min_batch;  // arithmetic (and with it the stream schedule) of this call
+  pmce_set_overflow_sink(m->oflow.get());  // (thread-local; the entry point clears it again through its SinkGuard)
   return PMCE_OK;
 }
 
 int pmce_lifter_forward(pmce_model* m, const float* pose2d, const float* img_feat, float* pose3d, int batch, void* ws,
                         size_t ws_bytes, pmce_stream_t stream) {
   PMCE_TRY(check_ws(m, batch, ws, ws_bytes));
+  SinkGuard sink_guard;
   PMCE_REQUIRE(m->has_lifter, "lifter_forward: lifter tensors not registered");
   PMCE_REQUIRE(pose2d && img_feat && pose3d, "lifter_forward: null pointer");
   Carver c(ws, ws_bytes);
@@ -917,6 +969,7 @@ int pmce_lifter_forward(pmce_model* m, const float* pose2d, const float* img_fea
 int pmce_decoder_forward(pmce_model* m, const float* joints, const float* img_feat, float* cam_pose, float* cam_mesh,
                          int batch, void* ws, size_t ws_bytes, pmce_stream_t stream) {
   PMCE_TRY(check_ws(m, batch, ws, ws_bytes));
+  SinkGuard sink_guard;
   PMCE_REQUIRE(m->has_decoder, "decoder_forward: decoder tensors not registered");
   PMCE_REQUIRE(joints && img_feat && cam_pose && cam_mesh, "decoder_forward: null pointer");
   Carver c(ws, ws_bytes);
@@ -936,6 +989,7 @@ int pmce_decoder_forward(pmce_model* m, const float* joints, const float* img_fe
 int pmce_coevo_block_forward(pmce_model* m, int k, const float* joints, const float* vt_in, const float* g, float* vt_out,
                              float* joint_out, int batch, void* ws, size_t ws_bytes, pmce_stream_t stream) {
   PMCE_TRY(check_ws(m, batch, ws, ws_bytes));
+  SinkGuard sink_guard;
   PMCE_REQUIRE(m->has_decoder, "coevo_block_forward: decoder tensors not registered");
   PMCE_REQUIRE(k >= 1 && k <= 3, "coevo_block_forward: k must be 1, 2 or 3");
   PMCE_REQUIRE(joints && vt_in && g && vt_out, "coevo_block_forward: null pointer");
@@ -980,6 +1034,7 @@ static int forward_impl(pmce_model* m, const float* pose2d, const float* img_fea
 int pmce_forward(pmce_model* m, const float* pose2d, const float* img_feat, float* cam_mesh, float* cam_pose,
                  float* pose3d, float* pred_pose, int batch, void* ws, size_t ws_bytes, pmce_stream_t stream) {
   PMCE_TRY(check_ws(m, batch, ws, ws_bytes));
+  SinkGuard sink_guard;
   PMCE_REQUIRE(m->has_lifter && m->has_decoder, "forward: needs both lifter and decoder tensors");
   PMCE_REQUIRE(pose2d && img_feat && cam_mesh && cam_pose && pose3d, "forward: null pointer");
   PMCE_REQUIRE(!pred_pose || (m->jr_indptr && m->jr_indices && m->jr_data && m->jr_rows > 0),
@@ -1004,6 +1059,7 @@ int pmce_stream_precompute(pmce_model* m, const float* pose2d_frames, const floa
   PMCE_REQUIRE(L > 0, "stream_precompute: L must be positive");
   const int bf = (L + T - 1) / T;  // the per-frame pass needs the workspace of ceil(L/16) clips
   PMCE_TRY(check_ws(m, bf, ws, ws_bytes));
+  SinkGuard sink_guard;
   PMCE_REQUIRE(m->has_lifter && m->has_decoder, "stream_precompute: needs both lifter and decoder tensors");
   PMCE_REQUIRE(pose2d_frames && feat_frames && x0 && gi0, "stream_precompute: null pointer");
   Carver c(ws, ws_bytes);
@@ -1052,6 +1108,7 @@ static int stream_forward_impl(pmce_model* m, const float* x0, const float* gi0,
 int pmce_stream_forward(pmce_model* m, const float* x0, const float* gi0, const int* win, int W, int L, float* cam_mesh,
                         float* cam_pose, float* pose3d, float* pred_pose, void* ws, size_t ws_bytes, pmce_stream_t stream) {
   PMCE_TRY(check_ws(m, W, ws, ws_bytes));
+  SinkGuard sink_guard;
   PMCE_REQUIRE(m->has_lifter && m->has_decoder, "stream_forward: needs both lifter and decoder tensors");
   PMCE_REQUIRE(x0 && gi0 && win && cam_mesh && cam_pose && pose3d && L > 0, "stream_forward: null pointer");
   PMCE_REQUIRE(!pred_pose || (m->jr_indptr && m->jr_indices && m->jr_data && m->jr_rows > 0),

@@ -36,12 +36,12 @@ def gemm_nt(A, W, bias=None, residual=None, act=0, out=None):
 
 
 def pack_split_f16(W):
-    """W[N,K] fp32 -> (Wp[N,K] storage of the f16 hi/lo planes, wscale[4]) for :func:`gemm_nt_split`."""
+    """W[N,K] fp32 -> (Wp[N,K] storage of the f16 hi/lo planes, wscale[N] = 2^-s per output row) for :func:`gemm_nt_split`."""
     lib = _lib.load()
     W = _c(W)
     N, K = W.shape
     Wp = torch.empty(N, K, device=W.device, dtype=torch.float32)
-    wscale = torch.empty(4, device=W.device, dtype=torch.float32)
+    wscale = torch.empty(N, device=W.device, dtype=torch.float32)
     _lib.check(lib.pmce_gemm_pack_split_f16(P(W), N, K, K, P(Wp), P(wscale), _st()), "gemm_pack_split_f16")
     return Wp, wscale
 

@@ -81,7 +81,9 @@ class HipEngine:
         self.regressor_rows = rows
 
     def finalize(self):
-        _lib.check(self.lib.pmce_model_finalize(self.handle), "pmce_model_finalize")
+        # on the CURRENT stream: the packed fp32 tensors registered above were produced on it, and the library's own packing of the
+        # f16 planes reads them (a torch side stream is non-blocking: the null stream is not ordered behind it)
+        _lib.check(self.lib.pmce_model_finalize_on(self.handle, _lib.current_stream()), "pmce_model_finalize")
 
     def clone_shared(self) -> "HipEngine":
         """A second handle on the SAME packed weights (no copy): its own workspace, side stream and events, so that two
@@ -123,13 +125,23 @@ class HipEngine:
         fp32 accumulate, fp32 accuracy); 'f32': on the fp32 matrix pipe."""
         if mode not in ("split_f16", "f32"):
             raise ValueError("gemm mode must be 'split_f16' or 'f32'")
-        _lib.check(self.lib.pmce_model_set_gemm_mode(self.handle, 1 if mode == "split_f16" else 0), "model_set_gemm_mode")
+        _lib.check(self.lib.pmce_model_set_gemm_mode_on(self.handle, 1 if mode == "split_f16" else 0, _lib.current_stream()),
+                   "model_set_gemm_mode")
 
     def gemm_mode(self) -> str:
         return "split_f16" if self.lib.pmce_model_gemm_mode(self.handle) else "f32"
 
     def set_split_min_batch(self, clips: int):
         _lib.check(self.lib.pmce_model_set_split_min_batch(self.handle, int(clips)), "model_set_split_min_batch")
+
+    def overflowed(self) -> bool:
+        """A product of the split-f16 form produced a non-finite value in a completed call (an activation beyond f16's 65504, or fp32
+        overflow): that call's outputs are invalid and every further call raises until :meth:`clear_overflow`.  Synchronise the
+        stream first for a definite answer about the last call."""
+        return bool(self.lib.pmce_model_overflowed(self.handle))
+
+    def clear_overflow(self):
+        _lib.check(self.lib.pmce_model_clear_overflow(self.handle), "model_clear_overflow")
 
     def set_concurrency(self, enable: bool):
         _lib.check(self.lib.pmce_model_set_concurrency(self.handle, 1 if enable else 0), "model_set_concurrency")
@@ -186,6 +198,18 @@ class HipModuleBase(nn.Module):
 
     def gemm_mode(self):
         return self._ensure_packed().gemm_mode()
+
+    def overflowed(self, synchronize: bool = True) -> bool:
+        """True if a call on this module ran out of the split-f16 form's range (|activation| > 65504 in a product operand, or fp32
+        overflow): the outputs of that call are invalid, and further forwards raise PmceError until :meth:`clear_overflow`.
+        ``set_gemm_mode('f32')`` has fp32's own range."""
+        eng = self._ensure_packed()
+        if synchronize:
+            torch.cuda.synchronize(eng.device)
+        return eng.overflowed()
+
+    def clear_overflow(self):
+        self._ensure_packed().clear_overflow()
 
     # any change of the parameters' storage invalidates the packed copy
     def _apply(self, fn, *a, **k):

@@ -574,3 +574,97 @@ def test_entry_points_in_one_process():
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     assert "smoke: max-abs vs oracle" in r.stdout
+
+
+def test_overflow_guard_of_the_split_mode():
+    """An image feature beyond f16's range (the raw features enter the GRU projection and imgfeat_embed unnormalised,
+    CoevoDecoder.py:216-229): the forward that saw it sets the model's sticky word, every later call fails with PMCE_ERR_OVERFLOW
+    BEFORE launching, clear_overflow re-arms, and the fp32 pipe computes the same input without complaint."""
+    from pmce_amd import _lib, synth
+    J, C, B = 17, 256, 4
+    model = get_model(J, C)
+    model.set_gemm_mode("split_f16", min_batch=1)
+    pose2d, img_feat = synth.make_inputs(B, J, 31)
+    p2, f = T(pose2d).to(dev()), T(img_feat).to(dev())
+    try:
+        good = [t.clone() for t in model(p2, f)]
+        assert not model.overflowed()
+        f_bad = f.clone()
+        f_bad[1, 5, 77] = 1.0e5
+        out = model(p2, f_bad)
+        assert model.overflowed()                                   # (synchronises)
+        assert not torch.isfinite(out[0][1]).all()                  # the clip that overflowed is visibly invalid ...
+        assert torch.equal(out[0][0], good[0][0]) and torch.equal(out[0][2:], good[0][2:])   # ... its neighbours are not touched
+        with pytest.raises(_lib.PmceError, match="non-finite"):
+            model(p2, f)
+        model.clear_overflow()
+        again = model(p2, f)
+        torch.cuda.synchronize()
+        assert not model.overflowed()
+        for a, b in zip(again, good):
+            assert torch.equal(a, b)
+        model.set_gemm_mode("f32")
+        out32 = model(p2, f_bad)
+        assert not model.overflowed() and all(torch.isfinite(t).all() for t in out32)
+    finally:
+        model.set_gemm_mode(None)
+        model.clear_overflow()
+
+
+def test_adversarial_weights_both_modes_vs_oracle():
+    """A checkpoint that is not well conditioned: every weight matrix of the lifter and the large decoder products multiplied
+    elementwise by a log-normal factor (sigma = 1), plus a 1e3 x outlier weight and a 1e3 x outlier ROW in three of them.  Both
+    arithmetic modes against the oracle (torch CPU fp32) on the same weights: the split-f16 form is held to the fp32 pipe's error."""
+    from oracle import pmce_oracle as O
+    from pmce_amd import assets, models, synth
+    J, C, B = 17, 256, 2
+    sd = {k: v.clone() for k, v in cached_state_dict(J, C).items()}
+    g = torch.Generator().manual_seed(3)
+    hit = 0
+    for k, v in sd.items():
+        if v.ndim == 2 and min(v.shape) >= 64 and ("pose_lifter" in k or "gru_cur" in k or "linear_cur" in k):
+            v *= torch.exp(torch.randn(v.shape, generator=g))
+            if k.endswith(("attn.qkv.weight", "mlp.fc1.weight", "weight_ih_l0")) and hit < 6:
+                v[v.shape[0] // 3, v.shape[1] // 5] *= 1e3
+                v[2 * v.shape[0] // 3] *= 1e3
+                hit += 1
+    assert hit >= 3
+    model = models.PMCE.get_model(J, C, 3)
+    model.load_state_dict(sd)
+    model.set_j_regressor(assets.load_j_regressor("h36m"))
+    model = model.to(dev())
+    pose2d, img_feat = synth.make_inputs(B, J, 5)
+    with torch.no_grad():
+        rm, rp, rl = O.pmce_forward(sd, T(pose2d), T(img_feat), model.vj_relation)
+        rm64, rp64, rl64 = O.pmce_forward(sd, T(pose2d), T(img_feat), model.vj_relation, dtype=torch.float64)
+    err = {}
+    for mode in ("split_f16", "f32"):
+        model.set_gemm_mode(mode, min_batch=1)
+        mesh, pose, pose3d = model(T(pose2d).to(dev()), T(img_feat).to(dev()))
+        assert not model.overflowed()
+        err[mode] = (maxabs(mesh, rm64), maxabs(pose, rp64), maxabs(pose3d, rl64))
+    err["oracle fp32"] = (maxabs(rm, rm64), maxabs(rp, rp64), maxabs(rl, rl64))
+    scale = (float(rm64.abs().max()), float(rp64.abs().max()), float(rl64.abs().max()))
+    print("adversarial checkpoint, error vs an fp64 oracle (mesh m, pose m, pose3d mm):", {k: tuple(f"{x:.2e}" for x in v) for k, v in err.items()},
+          "output scales", tuple(f"{x:.2e}" for x in scale))
+    for i in range(3):
+        assert err["split_f16"][i] <= 1.5 * max(err["f32"][i], err["oracle fp32"][i]) + 1e-7 * scale[i]
+
+
+def test_headline_shape_sampled_clips_vs_oracle():
+    """BASELINE configs[2] at north_star's width, directly: one B = 256, C = 512 forward in the default mode, 16 of its clips
+    against the oracle."""
+    from oracle import pmce_oracle as O
+    from pmce_amd import synth
+    J, C, B = 17, 512, 256
+    model = get_model(J, C)
+    sd = cached_state_dict(J, C)
+    pose2d, img_feat = synth.make_inputs(B, J, 2024)
+    mesh, pose, pose3d, pred = model.forward_with_joints(T(pose2d).to(dev()), T(img_feat).to(dev()))
+    assert not model.overflowed()
+    idx = list(range(0, B, 16))
+    with torch.no_grad():
+        rm, rp, rl = O.pmce_forward(sd, T(pose2d[idx]), T(img_feat[idx]), model.vj_relation)
+    e = (maxabs(mesh[idx], rm), maxabs(pose[idx], rp), maxabs(pose3d[idx], rl))
+    print("B=256, C=512, 16 sampled clips vs oracle: mesh %.2e m, pose %.2e m, pose3d %.2e mm" % e)
+    assert e[0] < TIGHT_M and e[1] < TIGHT_M and e[2] < TOL_MM

@@ -571,3 +571,62 @@ def test_lifter_block_fixture(golden):
     e = maxabs(x2.reshape(3, 17, 256), T(golden("modules_J17_C256.npz")["lifter_block_s1"]))
     print(f"lifter block vs reference fixture: {e:.2e}")
     assert e < 2e-5
+
+
+# ---- the split-f16 form on badly conditioned operands (round 3: per-row weight scales, range guard) ------------------------------
+
+def _adversarial(M, N, K, seed=5):
+    """A rows of magnitudes 1e-6 ... 3e4 (log-uniform), log-normal weights (sigma = 2) - plus ONE weight 1e4 x the largest and one
+    whole ROW of W 1e4 x the rest."""
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(M, K, generator=g) * torch.exp(torch.empty(M, 1).uniform_(np.log(1e-6), np.log(3e4), generator=g))
+    W = torch.randn(N, K, generator=g).sign() * torch.exp(2.0 * torch.randn(N, K, generator=g)) * K ** -0.5
+    W[N // 3, K // 5] = 1e4 * W.abs().max()      # an outlier weight inside a row
+    W[2 * N // 3] *= 1e4                          # an outlier row
+    b = torch.randn(N, generator=g)
+    return A.to(dev()), W.to(dev()), b.to(dev())
+
+
+@pytest.mark.parametrize("M,N,K,a_packed", [(4352, 512, 256, False), (4352, 512, 256, True), (20000, 1536, 512, True), (1000, 6144, 2048, False)])
+def test_gemm_split_adversarial_operands(M, N, K, a_packed):
+    """Per-OUTPUT-ROW weight scales: rows of W that are orders of magnitude apart, an outlier inside a row, activations over ten
+    decades - the error against an fp64 product stays at the fp32 pipe's, row by row (a per-tensor scale would lose the small
+    rows' lo planes to f16 sub-normals)."""
+    from pmce_amd import ops
+    A, W, b = _adversarial(M, N, K)
+    Wp, ws = ops.pack_split_f16(W)
+    out = ops.gemm_nt_split(ops.split_rows_f16(A) if a_packed else A, Wp, ws, b, None, 0, a_packed=a_packed)
+    out32 = ops.gemm_nt(A, W, b, None, 0)
+    assert torch.isfinite(out).all()
+    ref = A.double() @ W.double().t() + b.double()
+    # error per output element relative to the scale of its dot product, sum_k |a||w| (both pipes are held to the same yardstick)
+    scale = (A.double().abs() @ W.double().abs().t()) + b.double().abs() + 1e-300
+    e = ((out.double() - ref).abs() / scale).max().item()
+    e32 = ((out32.double() - ref).abs() / scale).max().item()
+    # and specifically on the SMALL rows of W next to the huge one
+    small = torch.ones(N, dtype=torch.bool, device=dev()); small[2 * N // 3] = False; small[N // 3] = False
+    es = ((out.double() - ref).abs() / scale)[:, small].max().item()
+    es32 = ((out32.double() - ref).abs() / scale)[:, small].max().item()
+    print(f"adversarial {M}x{N}x{K} packedA={a_packed}: max err / sum|a||w|: split {e:.2e} (fp32 pipe {e32:.2e}); on the small rows {es:.2e} ({es32:.2e})")
+    assert e <= 1.5 * e32 + 1e-9 and es <= 1.5 * es32 + 1e-9
+    assert e < 3e-7        # a few fp32 ulps of the dot product's scale
+
+
+def test_gemm_split_out_of_range_is_never_silently_finite():
+    """|a| > 65504 does not fit the f16 planes: the result is inf / nan in the affected rows, never a wrong finite value, and the
+    other rows are untouched."""
+    from pmce_amd import ops
+    M, N, K = 512, 256, 128
+    A = rnd("gemm.A", (M, K)).to(dev())
+    W = rnd("gemm.W", (N, K), scale=K ** -0.5).to(dev())
+    Wp, ws = ops.pack_split_f16(W)
+    clean = ops.gemm_nt_split(A, Wp, ws, None, None, 0)
+    A2 = A.clone()
+    A2[7, 3] = 7.0e4
+    A2[300, 100] = -1.0e9
+    for packed in (False, True):
+        out = ops.gemm_nt_split(ops.split_rows_f16(A2) if packed else A2, Wp, ws, None, None, 0, a_packed=packed)
+        bad_rows = (~torch.isfinite(out)).any(1).nonzero().flatten().tolist()
+        assert bad_rows == [7, 300], bad_rows
+        ok = torch.ones(M, dtype=torch.bool, device=dev()); ok[7] = False; ok[300] = False
+        assert torch.equal(out[ok], clean[ok])
