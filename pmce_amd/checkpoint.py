@@ -55,13 +55,39 @@ def validate_state_dict(sd):
     return kind, J, C, depth
 
 
+def _reference_checkpoint_globals():
+    """What a checkpoint written by the reference's training loop holds besides tensors and plain containers (main/train.py:57-64:
+    ``epoch``, ``model_state_dict``, ``optim_state_dict`` (Adam), ``scheduler_state_dict`` (MultiStepLR: a ``collections.Counter``
+    of milestones) and ``train_log`` / ``test_log`` lists whose entries are NUMPY SCALARS, ``np.power(...).mean()`` in
+    compute_both_err): the constructors of numpy scalars and dtypes, nothing that can run code."""
+    import collections
+    allowed = [collections.Counter, collections.OrderedDict, np.dtype, np.ndarray]
+    for modname in ("numpy._core.multiarray", "numpy.core.multiarray"):     # numpy 2.x / 1.x
+        try:
+            mod = __import__(modname, fromlist=["scalar"])
+        except Exception:  # noqa: BLE001
+            continue
+        for fn in ("scalar", "_reconstruct"):
+            if hasattr(mod, fn):
+                allowed.append(getattr(mod, fn))
+    for tname in ("float16", "float32", "float64", "int8", "int16", "int32", "int64", "uint8", "bool_"):
+        t = getattr(np, tname, None)
+        if t is not None:
+            allowed.append(t)
+            allowed.append(type(np.dtype(t)))      # numpy.dtypes.Float32DType ... (numpy >= 1.25 pickles the dtype's class)
+    return allowed
+
+
 def torch_load_checkpoint(path, map_location="cpu", allow_pickle=False):
-    """torch.load restricted to tensors and plain containers (``weights_only=True``): a checkpoint file cannot execute
-    code.  Reference checkpoints (``{'epoch', 'model_state_dict', 'optim_state_dict', ...}`` of tensors and numbers,
-    main/train.py:57-64) load this way; ``allow_pickle=True`` is the explicit opt-in to the unrestricted unpickler for
-    files that carry other Python objects."""
+    """torch.load that cannot execute code: ``weights_only=True`` with an allow-list of exactly the non-tensor objects the
+    reference's own checkpoints contain (numpy scalars in the error logs, the scheduler's ``Counter`` - see
+    :func:`_reference_checkpoint_globals`; without it a genuine ``best.pth.tar`` is rejected).  ``allow_pickle=True`` is the
+    explicit opt-in to the unrestricted unpickler for files that carry anything else."""
     try:
-        return torch.load(path, map_location=map_location, weights_only=True)
+        with torch.serialization.safe_globals(_reference_checkpoint_globals()):
+            return torch.load(path, map_location=map_location, weights_only=True)
+    except FileNotFoundError:
+        raise
     except Exception:  # noqa: BLE001
         if not allow_pickle:
             raise
@@ -69,12 +95,16 @@ def torch_load_checkpoint(path, map_location="cpu", allow_pickle=False):
 
 
 def load_reference_checkpoint(path, map_location="cpu", allow_pickle=False):
-    """-> (state_dict, kind, num_joint, embed_dim, depth); raises ValueError("No checkpoint exists!") like the reference's
-    load_checkpoint (lib/funcs_utils.py:122-128) when the file cannot be read."""
+    """-> (state_dict, kind, num_joint, embed_dim, depth).  A file that cannot be read raises ValueError whose message starts
+    with "No checkpoint exists!" like the reference's load_checkpoint (lib/funcs_utils.py:122-128) - followed by what actually
+    went wrong (missing file, or an object the restricted unpickler refuses: pass allow_pickle=True for such a file)."""
     try:
         obj = torch_load_checkpoint(path, map_location, allow_pickle)
     except Exception as e:  # noqa: BLE001 - same contract as the reference
-        raise ValueError("No checkpoint exists!\n", e)
+        hint = "" if isinstance(e, FileNotFoundError) or allow_pickle else \
+            "  (the file exists but holds objects outside the tensors / numpy scalars / Counter a reference checkpoint contains; " \
+            "allow_pickle=True loads it with the unrestricted unpickler)"
+        raise ValueError(f"No checkpoint exists!\n{type(e).__name__}: {e}{hint}") from e
     sd = packing.unwrap_checkpoint(obj)
     kind, J, C, depth = validate_state_dict(sd)
     return sd, kind, J, C, depth

@@ -23,6 +23,7 @@ cfg = SimpleNamespace(
         vertx_dim=64,                   # config.py (MODEL.vertx_dim)
         posenet_pretrained=False,
         posenet_path="",
+        posenet_allow_pickle=False,     # (not in the reference) unrestricted unpickler for GraphormerNet(pretrained=True)
     ),
 )
 

@@ -13,7 +13,7 @@ from ..runtime import HipEngine, HipModuleBase, _check_input, build_param_tree
 class GraphormerNet(HipModuleBase):
     """forward(x[B,16,J,2], img_feat[B,16,2048]) -> pose3d[B,J,3] in millimetres (PoseEstimation.py:95-115)."""
 
-    def __init__(self, num_frames=16, num_joints=17, embed_dim=256, depth=3, pretrained=False):
+    def __init__(self, num_frames=16, num_joints=17, embed_dim=256, depth=3, pretrained=False, allow_pickle=None):
         super().__init__()
         if num_frames != SEQLEN:
             raise ValueError("the path is specialised for 16-frame clips (cfg.DATASET.seqlen, config.py:48)")
@@ -22,7 +22,10 @@ class GraphormerNet(HipModuleBase):
         self.eval()
         if pretrained:   # PoseEstimation.py:71-74
             from ..checkpoint import torch_load_checkpoint
-            ckpt = torch_load_checkpoint(cfg.MODEL.posenet_path, map_location="cpu")   # tensors only: no code execution
+            # restricted unpickler: tensors + what the reference's training loop logs (numpy scalars, the scheduler's Counter);
+            # allow_pickle (argument, or cfg.MODEL.posenet_allow_pickle) opts into the unrestricted one for other files
+            ap = getattr(cfg.MODEL, "posenet_allow_pickle", False) if allow_pickle is None else allow_pickle
+            ckpt = torch_load_checkpoint(cfg.MODEL.posenet_path, map_location="cpu", allow_pickle=ap)
             self.load_state_dict(ckpt["model_state_dict"])
 
     def _build_engine(self, dev):
@@ -47,7 +50,7 @@ class GraphormerNet(HipModuleBase):
         return out
 
 
-def get_model(num_joint=17, embed_dim=256, depth=3, pretrained=False):
-    """Same signature as reference PoseEstimation.get_model (PoseEstimation.py:118-120)."""
+def get_model(num_joint=17, embed_dim=256, depth=3, pretrained=False, allow_pickle=None):
+    """Same signature as reference PoseEstimation.get_model (PoseEstimation.py:118-120) (+ allow_pickle, see GraphormerNet)."""
     return GraphormerNet(num_frames=cfg.DATASET.seqlen, num_joints=num_joint, embed_dim=embed_dim, depth=depth,
-                         pretrained=pretrained)
+                         pretrained=pretrained, allow_pickle=allow_pickle)

@@ -198,6 +198,47 @@ def test_checkpoint_tooling(tmp_path):
         checkpoint.load_reference_checkpoint(str(tmp_path / "nope.pth.tar"))
 
 
+def test_checkpoint_written_like_the_reference_training_loop(tmp_path):
+    """What main/train.py:57-64 really saves: the error logs hold NUMPY scalars (compute_both_err's np.power(...).mean()), the
+    optimizer state is Adam's, the scheduler's is a MultiStepLR's with its Counter of milestones.  The restricted unpickler
+    must take such a file (round 2's plain weights_only=True did not), refuse a file that carries anything executable, say
+    what went wrong, and leave the unrestricted unpickler as an explicit opt-in - also for GraphormerNet(pretrained=True)."""
+    from pmce_amd import checkpoint, models, synth
+    from pmce_amd.config import cfg
+    sd = cached_state_dict(17, 256)
+    lifter = {k[len("pose_lifter."):]: v for k, v in sd.items() if k.startswith("pose_lifter.")}
+    net = torch.nn.Linear(4, 4)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    net(torch.zeros(1, 4)).sum().backward()
+    opt.step()
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[2, 4], gamma=0.1)
+    logs = [np.float32(101.5), np.float64(88.25), np.power(np.ones(3, np.float32) * 2, 2).mean()]
+    p = tmp_path / "pose_best.pth.tar"
+    torch.save({"epoch": 7, "model_state_dict": lifter, "optim_state_dict": opt.state_dict(),
+                "scheduler_state_dict": sched.state_dict(), "train_log": logs, "test_log": list(logs)}, p)
+    sd2, kind, J, C, depth = checkpoint.load_reference_checkpoint(str(p))
+    assert (kind, J, C, depth) == ("lifter", 17, 256, 3) and all(torch.equal(sd2[k], lifter[k]) for k in lifter)
+    obj = checkpoint.torch_load_checkpoint(str(p))
+    assert obj["epoch"] == 7 and float(obj["test_log"][1]) == 88.25 and obj["scheduler_state_dict"]["milestones"][2] == 1
+    cfg.MODEL.posenet_path = str(p)
+    try:
+        m = models.PoseEstimation.get_model(17, 256, 3, pretrained=True)
+        assert torch.equal(m.state_dict()["norm_s.weight"], lifter["norm_s.weight"])
+    finally:
+        cfg.MODEL.posenet_path = ""
+
+    class Evil:      # something the allow-list does not know
+        def __reduce__(self):
+            return (print, ("code ran while unpickling",))
+    q = tmp_path / "evil.pth.tar"
+    torch.save({"model_state_dict": lifter, "extra": Evil()}, q)
+    with pytest.raises(ValueError) as e:
+        checkpoint.load_reference_checkpoint(str(q))
+    assert "No checkpoint exists" in str(e.value) and "allow_pickle=True" in str(e.value) and "UnpicklingError" in str(e.value)
+    sd3 = checkpoint.load_reference_checkpoint(str(q), allow_pickle=True)[0]
+    assert set(sd3) == set(lifter)
+
+
 def test_workload_flops_agree_with_oracle_count():
     from oracle import pmce_oracle as O
     from pmce_amd.workload import flops_per_clip
