@@ -19,6 +19,7 @@ stream), small-batch latency, and the oracle's CPU baseline on the host cores (r
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import socket
@@ -240,7 +241,7 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
     out = None
     for _ in range(max(warmup, 1)):  # packing / workspace allocation must not be inside the timed region
         out = step()
-    win_ms = []
+    win_ms, own_dt = [], []
     for _ in range(windows):
         torch.cuda.synchronize()
         sharding.barrier()
@@ -249,12 +250,15 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
         for _ in range(steps):
             out = step()
         torch.cuda.synchronize()
+        own_dt.append(time.perf_counter() - t0)      # this rank's own work (before it waits for the others)
         sharding.barrier()
         torch.cuda.synchronize()
         dt = sharding.reduce_max(time.perf_counter() - t0, dev)
         win_ms.append(dt / steps * 1e3)
     ms = statistics.median(win_ms)
     clips_per_s = B * world / (ms * 1e-3)
+    # every rank's OWN rate over the last window (its own clock, before the MAX): a straggler is visible here
+    per_rank = sharding.gather_rows(torch.tensor([[B / (own_dt[-1] / steps)]], dtype=torch.float64, device=dev)).flatten().tolist()
 
     # final metric reduction — the only collective of the path (RCCL over xGMI): per-rank partial sums
     if pipe is not None:
@@ -277,20 +281,29 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
                       "gemm_mode": gemm_mode,
                       "streams": 1 if (args.single_stream or (gemm_mode == "split_f16" and not _lib.split_overlap())) else 2 * depth,
                       "batches_enqueued_ahead": depth, "distinct_input_batches": NB},
-           "ref_equiv_tflops": round(fpc * clips_per_s / 1e12, 2), "outputs_finite": finite}
+           "ref_equiv_tflops": round(fpc * clips_per_s / 1e12, 2), "outputs_finite": finite,
+           "per_rank_clips_s": [round(x, 1) for x in per_rank],
+           "metric_reduction": {"collective": "all_reduce(SUM) of 3 fp64 partials per rank", "clips_counted": int(total[2].item()),
+                                "backend": (torch.distributed.get_backend() if world > 1 else None)}}
     if not full:
         return rec, model, pipe, inputs, sd
 
     # ---- per-kernel-class timing with HIP events on the launch stream (a few extra, untimed-for-value steps, one batch
     # at a time on one stream so that every launch is priced alone) ----
     run1 = lambda: model.forward_with_joints(*inputs[0])
+    clk = torch.zeros(2, dtype=torch.int64, device=dev)
+    lib = _lib.load()
+    if gemm_mode == "split_f16":       # the split kernel's workgroups report their residence in shader clocks and 100 MHz ticks
+        lib.pmce_gemm_split_set_clock_probe(ctypes.c_void_p(clk.data_ptr()))
     model.profile(True)
     nprof = 3
     for _ in range(nprof):
         run1()
     torch.cuda.synchronize()
+    lib.pmce_gemm_split_set_clock_probe(None)
     prof = model.profile_read()
     model.profile(False)
+    clk_ghz = float(clk[0].item()) / float(clk[1].item()) * 0.1 if int(clk[1].item()) > 0 else None
     if args.single_stream:
         model.set_concurrency(False)
     kernel_ms = {k_: round(v[0] / nprof, 4) for k_, v in prof.items() if v[1] > 0}
@@ -322,7 +335,14 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
             roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_F16_TFLOPS, 4), **common,
                         "arithmetic": "3 x v_mfma_f32_32x32x16_f16 per fp32 product (hi*hi + hi*lo + lo*hi), fp32 accumulate",
+                        "note": "achieved / frac count the f16 FLOPs the kernel ISSUES (3 x 2MNK); frac_algorithmic_2mnk is the same time "
+                                "against the algorithmic 2MNK of the fp32 products",
                         "fp32_equiv_tflops": round(work / secs / 1e12, 1),
+                        "frac_algorithmic_2mnk": round(work / secs / 1e12 / PEAK_F16_TFLOPS, 4),
+                        # MI355X runs this kernel power-limited: the shader clock its workgroups measured (s_memtime vs the 100 MHz
+                        # wall counter, in these very launches), and the issued rate against the matrix peak AT that clock
+                        "sustained_clock_ghz": round(clk_ghz, 3) if clk_ghz else None,
+                        "frac_of_peak_at_sustained_clock": round(ach / (PEAK_F16_TFLOPS * clk_ghz / 2.4), 4) if clk_ghz else None,
                         "hbm": {"algorithmic_bytes_per_launch": round(byt / dom_launches), "achieved_gbs": round(byt / secs / 1e9, 1),
                                 "peak_gbs": PEAK_HBM_GBS, "frac": round(byt / secs / 1e9 / PEAK_HBM_GBS, 4)}}
         elif kind == "flop":
@@ -422,17 +442,22 @@ def cpu_baseline_record(sd, vj_relation, J, C, seconds):
     # batch (a few seconds), then time a bounded sample of batch-64 forwards with the best one.
     p_cpu, f_cpu = (torch.from_numpy(a) for a in synth.make_inputs(64, J, seed=1))
     best_t, best_rate = 1, 0.0
+    cal = {}
     with torch.no_grad():
-        for nt in [t for t in (8, 16, 32, 64, 128) if t <= ncores] or [ncores]:
+        torch.set_num_threads(min(16, ncores))
+        t1 = time.perf_counter()
+        O.pmce_forward(sd, p_cpu[:4], f_cpu[:4], vj_relation)
+        cb = 64 if 4 / (time.perf_counter() - t1) > 4 else 16      # (a very slow host times batch-16 forwards instead)
+        for nt in [t for t in (8, 16, 32, 64, 128, 256) if t <= ncores] or [ncores]:   # calibrated on the batch that is timed
             torch.set_num_threads(nt)
             O.pmce_forward(sd, p_cpu[:2], f_cpu[:2], vj_relation)  # warm the pool
             t1 = time.perf_counter()
-            O.pmce_forward(sd, p_cpu[:8], f_cpu[:8], vj_relation)
-            rate = 8 / (time.perf_counter() - t1)
+            O.pmce_forward(sd, p_cpu[:cb], f_cpu[:cb], vj_relation)
+            rate = cb / (time.perf_counter() - t1)
+            cal[nt] = round(rate, 1)
             if rate > best_rate:
                 best_t, best_rate = nt, rate
         torch.set_num_threads(best_t)
-        cb = 64 if best_rate > 8 else 16
         n, t_cpu = 0, 0.0
         while t_cpu < seconds and n < 50:
             t1 = time.perf_counter()
@@ -447,8 +472,10 @@ def cpu_baseline_record(sd, vj_relation, J, C, seconds):
     return {"value": round(cb * n / t_cpu, 2), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
             "host_logical_cpus": ncores, "ms_per_clip": round(t_cpu / (cb * n) * 1e3, 3),
             "batch1_latency_ms": round(statistics.median(lat), 2),
+            "threads_calibration_clips_s": cal,
             "sample": f"{n} x batch-{cb} full forwards of oracle/pmce_oracle.py (torch CPU fp32, J={J}, C={C}), thread count "
-                      f"calibrated over 8..128 on batch-8 forwards; batch1_latency_ms = median of 5 single-clip forwards"}
+                      f"calibrated over 8..256 on batch-{cb} forwards (the batch that is timed); batch1_latency_ms = median of 5 "
+                      f"single-clip forwards"}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -565,7 +592,7 @@ def main():
     del model, pipe, inputs
     torch.cuda.empty_cache()
 
-    if solo and not args.no_cpu_baseline:      # host-only work last
+    if rank == 0 and not args.no_cpu_baseline:      # host-only work last; at N > 1 on rank 0 while the others wait at the final barrier
         cpu = cpu_baseline_record(sd, vj, J, C, args.cpu_seconds)
 
     if rank == 0:
@@ -582,10 +609,12 @@ def main():
             "kernel_ms_per_step": head["kernel_ms_per_step"], "launches_per_step": head["launches_per_step"],
             "kernel_ms_total_single_stream": head["kernel_ms_total_single_stream"],
             "ref_equiv_tflops": head["ref_equiv_tflops"], "outputs_finite": head["outputs_finite"],
+            "per_rank_clips_s": head["per_rank_clips_s"], "metric_reduction": head["metric_reduction"],
         }
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
+        sharding.barrier()        # (rank 0 timed the CPU baseline meanwhile)
         dist.destroy_process_group()
 
 

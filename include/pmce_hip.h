@@ -10,10 +10,18 @@
  *   - return 0 on success, a negative PMCE_ERR_* otherwise; never throw, never exit; the message of the last
  *     error of the calling thread is pmce_last_error_string();
  *   - every pointer is a DEVICE pointer to contiguous row-major fp32 (int32 where noted), 16-byte aligned;
- *   - the caller owns every buffer (weights, activations, workspace); the library allocates no device memory;
- *   - launches are asynchronous on the hipStream_t passed in; no hidden synchronisation;
- *   - no global mutable state except the thread-local error string, so one process per GPU or several
- *     streams per process are both fine.
+ *   - the caller owns every buffer: weights, activations, the workspace and - split_f16 mode - the arena that holds the f16
+ *     planes of the large weights (pmce_model_split_bytes / pmce_model_set_split_arena).  What a model handle allocates for
+ *     itself: 4 bytes of pinned host memory (the overflow word, pmce_model_overflowed), one internal HIP stream and a handful of
+ *     events (two-stream execution inside a forward); and, ONLY when no arena was handed over, the planes by hipMalloc;
+ *   - launches are asynchronous on the hipStream_t passed in.  The calls that synchronise: pmce_model_finalize[_on] and
+ *     pmce_model_set_gemm_mode[_on] (they wait for their own packing kernels on the stream given; a mode change that drops
+ *     existing planes first waits for the whole device - forwards in flight may read them - and is therefore not capturable),
+ *     pmce_model_profile_read (waits for the recorded events) and the diagnostics pmce_gemm_ws_timeouts / pmce_dbg_*;
+ *   - mutable state outside the handles: the thread-local error string and, while a model entry point runs, the thread-local
+ *     pointer to that model's overflow word - one process per GPU or several host threads with their own streams are both fine -
+ *     and the process-wide TUNING AIDS pmce_gemm_set_tuning, pmce_gemm_split_set_tuning / _set_skew / _set_ws (relaxed atomics
+ *     read at launch time: meant for benchmarks and tests, not to be flipped while forwards are being enqueued elsewhere).
  * Fixed structural constants of the path: T = 16 frames, F = 2048 image-feature channels, V = 431 coarse
  * vertices, 6890 mesh vertices, D = 64 decoder channels, GRU hidden 1024, 8 lifter heads.  J <= 32,
  * C in {256, 512}.
@@ -63,6 +71,13 @@ int pmce_model_set_regressor_rows(pmce_model* m, int rows);
  * stream, which is NOT ordered behind non-blocking streams (PyTorch's side streams). */
 int pmce_model_finalize(pmce_model* m);
 int pmce_model_finalize_on(pmce_model* m, pmce_stream_t stream);
+/* The f16 planes (as many bytes again as the fp32 weights they mirror: 0.6 GB at C = 512) live in memory the CALLER provides:
+ * pmce_model_split_bytes (after the last pmce_model_set_tensor; whatever the current mode; 0 for a handle that adopted another
+ * one's planes) says how much, pmce_model_set_split_arena hands it over (256-byte aligned device memory that must outlive the model
+ * and every handle sharing its planes) - before pmce_model_finalize[_on], and again before a pmce_model_set_gemm_mode[_on] that
+ * switches a finalized model to split_f16.  Without an arena the library falls back to hipMalloc / hipFree of its own. */
+size_t pmce_model_split_bytes(const pmce_model* m);
+int pmce_model_set_split_arena(pmce_model* m, void* arena, size_t bytes);
 /* Arithmetic of the path's 30 large products per forward (the pose lifter's Linear layers, the GRU input projections, the
  * packed AdaLN and final products): split_f16 != 0 (the default; env PMCE_SPLIT_F16=0 at create for the other) = the three-product f16 form of pmce_gemm_nt_split_f16 on weights the
  * model packs for itself at finalize, 0 = the fp32 matrix pipe.  Both meet fp32 accuracy (tests/test_gpu_ops.py measures
@@ -197,6 +212,10 @@ int pmce_gemm_split_set_ws(int on);
 /* Number of wavefronts of the wave-specialised kernel that gave up waiting on an in-kernel hand-off since the library was
  * loaded: 0 in a healthy process (every spin is bounded instead of hanging the device).  Synchronises the device. */
 int pmce_gemm_ws_timeouts(void);
+/* Measurement aid (bench.py): while set (null = off), every launch of the 4-wave split kernel adds, per workgroup, the shader
+ * clocks and the 100 MHz wall ticks its first wave was resident to device_two_words[0] / [1]: their ratio x 0.1 is the shader clock
+ * in GHz the chip sustained under the kernel (MI355X is power-limited there: 1.6 - 1.8 GHz, not the 2.4 GHz of the peak figures). */
+int pmce_gemm_split_set_clock_probe(unsigned long long* device_two_words);
 /* Tuning aid only: start delay of every CU's second workgroup in units of 4096 cycles (-1: half a tile of matrix time). */
 int pmce_gemm_split_set_skew(int units);
 /* Diagnostics (scripts/microbench/victims.py; not on the product path): self-checking bystander kernels and matrix-pipe

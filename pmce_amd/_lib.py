@@ -26,6 +26,8 @@ PROTOTYPES = {
     "pmce_model_set_regressor_rows": [C.c_void_p, _i],
     "pmce_model_finalize": [C.c_void_p],
     "pmce_model_finalize_on": [C.c_void_p, _s],
+    "pmce_model_split_bytes": [C.c_void_p],
+    "pmce_model_set_split_arena": [C.c_void_p, C.c_void_p, C.c_size_t],
     "pmce_model_set_gemm_mode_on": [C.c_void_p, _i, _s],
     "pmce_model_workspace_bytes": [C.c_void_p, _i],
     "pmce_model_workspace_offset": [C.c_void_p, _i, C.c_char_p],
@@ -59,6 +61,7 @@ PROTOTYPES = {
     "pmce_gemm_nt_split_f16_rowmap": [_f, _f, _f, _f, _f, _i, _i, _i, _l, _i, _l, _l, _s],
     "pmce_gemm_split_set_tuning": [_i],
     "pmce_gemm_split_set_ws": [_i],
+    "pmce_gemm_split_set_clock_probe": [C.c_void_p],
     "pmce_gemm_ws_timeouts": [],
     "pmce_dbg_victim": [_i, _f, _i, _i, _f, _s],
     "pmce_dbg_mfma_spin": [_i, _f, _i, _i, _s],
@@ -96,6 +99,7 @@ _RESTYPES = {
     "pmce_model_destroy": None,
     "pmce_model_tensor_name": C.c_char_p,
     "pmce_model_workspace_bytes": C.c_size_t,
+    "pmce_model_split_bytes": C.c_size_t,
     "pmce_model_workspace_offset": C.c_longlong,
 }
 

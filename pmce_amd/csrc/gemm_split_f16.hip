@@ -72,6 +72,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
     mb = (first_m + (bid % per_group) % gsz) * BM;
     nb = ((bid % per_group) / gsz) * BN;
   };
+  // clock probe (bench.py: the shader clock the chip sustains under this kernel; MI355X runs it power-limited far below 2.4 GHz)
+  const bool probe = p.clk != nullptr && tid == 0;
+  const long long pc0 = probe ? (long long)__builtin_readcyclecounter() : 0, pw0 = probe ? (long long)wall_clock64() : 0;
   const int my_tiles = (chunk_len - bx + gx - 1) / gx;
   const int nk = p.K / 16;
   const int total = my_tiles * nk;
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
                 const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);  // lane ^ 1
                 const unsigned outw = odd ? ((nbr >> 16) | (w & 0xffff0000u)) : ((w & 0xffffu) | (nbr << 16));
                 const int rr = ((r + e) & 3) + 8 * ((r + e) >> 2);
-                if (mrow + rr < p.M) __builtin_nontemporal_store(outw, reinterpret_cast<unsigned*>(Cp + (size_t)rr * (2 * p.ldc)));
+                if (mrow + rr < p.M && cb < p.N) __builtin_nontemporal_store(outw, reinterpret_cast<unsigned*>(Cp + (size_t)rr * (2 * p.ldc)));  // (N % 32 == 0: a 32-column block is all in or all out)
               }
             }
           }
@@ -343,11 +346,20 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
       if (li < chunk_len) tile_coords(chunk_start + li, m_base, n_base);
     }
   }
+  if (probe) {
+    atomicAdd(&p.clk[0], (unsigned long long)((long long)__builtin_readcyclecounter() - pc0));
+    atomicAdd(&p.clk[1], (unsigned long long)((long long)wall_clock64() - pw0));
+  }
 }
 
 // ---- launch ---------------------------------------------------------------------------------------------------------------
 static std::atomic<int> g_split_tile{pmce_env_int("PMCE_SPLIT_TILE", -1)};
 static std::atomic<int> g_split_skew{pmce_env_int("PMCE_SPLIT_SKEW", -1)};
+static std::atomic<unsigned long long*> g_split_clk{nullptr};
+extern "C" int pmce_gemm_split_set_clock_probe(unsigned long long* device_two_words) {
+  g_split_clk.store(device_two_words, std::memory_order_relaxed);
+  return PMCE_OK;
+}
 extern "C" int pmce_gemm_split_set_skew(int units) {
   g_split_skew.store(units, std::memory_order_relaxed);
   return PMCE_OK;
@@ -433,6 +445,7 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
   p.M = M; p.N = N; p.K = K; p.lda = (unsigned)lda; p.ldc = (unsigned)ldc;
   p.c_div = c_div; p.c_lo = c_lo; p.c_hi = c_hi;
   p.oflow = pmce_overflow_sink();
+  p.clk = g_split_clk.load(std::memory_order_relaxed);
   {  // half a tile of matrix time: nk iterations x 3*TM*TN instructions x 32 cycles (TM*TN = 8 or 4), / 2, in 4096-cycle units
     const int knob = g_split_skew.load(std::memory_order_relaxed);
     p.skew = knob >= 0 ? knob : (K / 16) * 12 * 32 / 4096 + 1;

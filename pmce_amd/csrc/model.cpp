@@ -97,7 +97,10 @@ struct pmce_model {
   bool fused_ca = true;    // CrossAttentionBlock of the vertex stream as one launch (PMCE_VERTEX_FUSED=0 at create: two)
   // the large products on the f16 matrix pipe (three-product split, fp32 accuracy) instead of the fp32 one
   bool split_gemm = true;  // pmce_model_set_gemm_mode / PMCE_SPLIT_F16=0 at create
-  std::shared_ptr<float> split_arena;  // hipMalloc'ed: every packed weight + its scale; shared by handles cloned onto the same weights
+  std::shared_ptr<float> split_arena;  // every packed weight + its per-row 2^-s; shared by handles cloned onto the same weights.
+                                       // Caller memory (pmce_model_set_split_arena: no-op deleter) or, without one, hipMalloc'ed.
+  float* caller_arena = nullptr;       // set by pmce_model_set_split_arena, consumed by the next (re)build of the planes
+  size_t caller_arena_bytes = 0;
   bool split_adopted = false;          // the planes came from another handle (pmce_model_share_split_weights): finalize keeps them
   LifterBlockSplit sblk[2][8];
   SplitW s_ie, s_wih0, s_wih1, s_whh0, s_whh1, s_ada, s_final;
@@ -673,6 +676,20 @@ namespace {
 // (Re)build the packed f16 planes of every large weight in model-owned memory, or drop them (fp32 mode).  A load-time step, like
 // the packing the host side does: runs on `stream` - the stream the caller produced the fp32 weights on (a torch side stream is
 // non-blocking: the null stream would NOT be ordered behind it) - and waits for that stream only.
+struct SplitItem { const float* w; int n, k; SplitW* dst; };
+size_t split_item_floats(int n, int k) { return (((size_t)n * k + 63) & ~(size_t)63) + (((size_t)n + 63) & ~(size_t)63); }  // planes + 2^-s per row
+// bytes of the planes of a model with / without lifter and decoder
+size_t split_bytes_for(int C, int depth, bool lifter, bool decoder) {
+  size_t f = 0;
+  if (lifter) {
+    f += split_item_floats(C, F);
+    f += 2 * (size_t)depth * (split_item_floats(3 * C, C) + split_item_floats(C, C) + split_item_floats(2 * C, C) + split_item_floats(C, 2 * C));
+  }
+  if (decoder)
+    f += split_item_floats(6 * GH, F) + split_item_floats(6 * GH, 2 * GH) + 2 * split_item_floats(6 * GH, GH) +
+         split_item_floats(N_ADA * 128, 2 * GH) + split_item_floats(NVF * 3, FINAL_K);
+  return f * sizeof(float);
+}
 int build_split_weights(pmce_model* m, hipStream_t stream) {
   if (m->split_adopted && m->split_gemm && m->split_arena) return PMCE_OK;  // another handle's planes of the same weights
   m->split_adopted = false;
@@ -685,8 +702,7 @@ int build_split_weights(pmce_model* m, hipStream_t stream) {
   m->s_ie = m->s_wih0 = m->s_wih1 = m->s_whh0 = m->s_whh1 = m->s_ada = m->s_final = SplitW{};
   if (!m->split_gemm) return PMCE_OK;
   const int C = m->C;
-  struct Item { const float* w; int n, k; SplitW* dst; };
-  std::vector<Item> items;
+  std::vector<SplitItem> items;
   if (m->has_lifter) {
     items.push_back({m->w.ie_w, C, F, &m->s_ie});
     for (int kind = 0; kind < 2; ++kind)
@@ -709,20 +725,30 @@ int build_split_weights(pmce_model* m, hipStream_t stream) {
   }
   if (items.empty()) return PMCE_OK;
   size_t floats = 0;
-  for (auto& it : items) floats += (((size_t)it.n * it.k + 63) & ~(size_t)63) + (((size_t)it.n + 63) & ~(size_t)63);  // planes + 2^-s per row
-  float* arena = nullptr;
-  const hipError_t rc = hipMalloc(reinterpret_cast<void**>(&arena), floats * sizeof(float));
-  if (rc == hipSuccess) m->split_arena = std::shared_ptr<float>(arena, [](float* q) { (void)hipFree(q); });
-  if (rc != hipSuccess) {
-    pmce_set_error("model_finalize: hipMalloc(%zu bytes) for the split weights failed: %s", floats * sizeof(float),
-                   hipGetErrorString(rc));
-    return PMCE_ERR_LAUNCH;
+  for (auto& it : items) floats += split_item_floats(it.n, it.k);
+  if (m->caller_arena) {  // the caller's memory (its allocator, its lifetime): pmce_model_set_split_arena
+    if (m->caller_arena_bytes < floats * sizeof(float)) {
+      pmce_set_error("model_finalize: the split arena holds %zu bytes, the planes need %zu (pmce_model_split_bytes)", m->caller_arena_bytes,
+                     floats * sizeof(float));
+      return PMCE_ERR_WORKSPACE;
+    }
+    m->split_arena = std::shared_ptr<float>(m->caller_arena, [](float*) {});
+    m->caller_arena = nullptr;
+    m->caller_arena_bytes = 0;
+  } else {
+    float* arena = nullptr;
+    const hipError_t rc = hipMalloc(reinterpret_cast<void**>(&arena), floats * sizeof(float));
+    if (rc != hipSuccess) {
+      pmce_set_error("model_finalize: hipMalloc(%zu bytes) for the split weights failed: %s", floats * sizeof(float), hipGetErrorString(rc));
+      return PMCE_ERR_LAUNCH;
+    }
+    m->split_arena = std::shared_ptr<float>(arena, [](float* q) { (void)hipFree(q); });
   }
   float* p = m->split_arena.get();
   for (auto& it : items) {
     float* wp = p;
     float* sc = p + (((size_t)it.n * it.k + 63) & ~(size_t)63);
-    p = sc + (((size_t)it.n + 63) & ~(size_t)63);
+    p = wp + split_item_floats(it.n, it.k);
     PMCE_TRY(pmce_gemm_pack_split_f16(it.w, it.n, it.k, it.k, wp, sc, stream));
     it.dst->wp = wp;
     it.dst->scale = sc;
@@ -818,6 +844,20 @@ int pmce_model_set_regressor_rows(pmce_model* m, int rows) {
   return PMCE_OK;
 }
 
+size_t pmce_model_split_bytes(const pmce_model* m) {
+  if (!m || (m->split_adopted && m->split_arena)) return 0;
+  bool lifter = false, decoder = false;
+  for (auto& s : m->names)
+    if (m->ptr.count(s)) (s.rfind("lifter.", 0) == 0 ? lifter : decoder) = true;
+  return split_bytes_for(m->C, m->depth, lifter, decoder);
+}
+int pmce_model_set_split_arena(pmce_model* m, void* arena, size_t bytes) {
+  PMCE_REQUIRE(m, "model_set_split_arena: null model");
+  PMCE_REQUIRE(arena == nullptr || (reinterpret_cast<uintptr_t>(arena) & 255) == 0, "model_set_split_arena: the arena must be 256-byte aligned");
+  m->caller_arena = static_cast<float*>(arena);
+  m->caller_arena_bytes = arena ? bytes : 0;
+  return PMCE_OK;
+}
 int pmce_model_finalize(pmce_model* m) { return pmce_model_finalize_on(m, nullptr); }
 int pmce_model_finalize_on(pmce_model* m, pmce_stream_t stream) {
   PMCE_REQUIRE(m, "model_finalize: null model");

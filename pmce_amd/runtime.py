@@ -53,6 +53,8 @@ class HipEngine:
         self.device = None
         self.regressor_rows = 0
         self.split_min_batch = None
+        self.split_arena = None      # torch memory holding the f16 planes (kept alive here; lanes keep the owner's)
+        self._finalized = False
 
     def __del__(self):
         try:
@@ -80,10 +82,20 @@ class HipEngine:
         _lib.check(self.lib.pmce_model_set_regressor_rows(self.handle, rows), "set_regressor_rows")
         self.regressor_rows = rows
 
+    def _give_split_arena(self):
+        """The f16 planes of the split mode live in memory of PyTorch's allocator (the library allocates none of its own)."""
+        n = int(self.lib.pmce_model_split_bytes(self.handle))
+        if n and self.device is not None:
+            self.split_arena = torch.empty(n, dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.pmce_model_set_split_arena(self.handle, C.c_void_p(self.split_arena.data_ptr()), n), "model_set_split_arena")
+
     def finalize(self):
+        if self.gemm_mode() == "split_f16":
+            self._give_split_arena()
         # on the CURRENT stream: the packed fp32 tensors registered above were produced on it, and the library's own packing of the
         # f16 planes reads them (a torch side stream is non-blocking: the null stream is not ordered behind it)
         _lib.check(self.lib.pmce_model_finalize_on(self.handle, _lib.current_stream()), "pmce_model_finalize")
+        self._finalized = True
 
     def clone_shared(self) -> "HipEngine":
         """A second handle on the SAME packed weights (no copy): its own workspace, side stream and events, so that two
@@ -98,6 +110,7 @@ class HipEngine:
         if self.regressor_rows:
             _lib.check(other.lib.pmce_model_set_regressor_rows(other.handle, self.regressor_rows), "set_regressor_rows")
             other.regressor_rows = self.regressor_rows
+        other.split_arena = self.split_arena      # the planes it adopts live in this engine's arena
         other.finalize()
         return other
 
@@ -125,8 +138,12 @@ class HipEngine:
         fp32 accumulate, fp32 accuracy); 'f32': on the fp32 matrix pipe."""
         if mode not in ("split_f16", "f32"):
             raise ValueError("gemm mode must be 'split_f16' or 'f32'")
+        if mode == "split_f16" and self.gemm_mode() != "split_f16" and self._finalized:
+            self._give_split_arena()      # a finalized fp32-mode model is about to pack its planes
         _lib.check(self.lib.pmce_model_set_gemm_mode_on(self.handle, 1 if mode == "split_f16" else 0, _lib.current_stream()),
                    "model_set_gemm_mode")
+        if mode == "f32":
+            self.split_arena = None       # (the library waited for the device before it let go of the planes)
 
     def gemm_mode(self) -> str:
         return "split_f16" if self.lib.pmce_model_gemm_mode(self.handle) else "f32"

@@ -668,3 +668,24 @@ def test_headline_shape_sampled_clips_vs_oracle():
     e = (maxabs(mesh[idx], rm), maxabs(pose[idx], rp), maxabs(pose3d[idx], rl))
     print("B=256, C=512, 16 sampled clips vs oracle: mesh %.2e m, pose %.2e m, pose3d %.2e mm" % e)
     assert e[0] < TIGHT_M and e[1] < TIGHT_M and e[2] < TOL_MM
+
+
+@pytest.mark.parametrize("depth", [1, 2, 4])
+def test_other_depths_vs_oracle(depth):
+    """get_model(num_joint, embed_dim, depth) takes any depth (reference PoseEstimation.py:31-45, cfg.MODEL.hpe_dep): the library
+    accepts 1..8; depths other than the shipped 3 against the oracle (which builds the same number of blocks from the same keys)."""
+    from oracle import pmce_oracle as O
+    from pmce_amd import assets, models, synth
+    J, C, B = 17, 256, 2
+    sd = synth.make_state_dict(synth.pmce_spec(J, C, depth), seed=321)
+    model = models.PMCE.get_model(J, C, depth)
+    model.load_state_dict(sd)
+    model.set_j_regressor(assets.load_j_regressor("h36m"))
+    model = model.to(dev())
+    pose2d, img_feat = synth.make_inputs(B, J, 8)
+    mesh, pose, pose3d = model(T(pose2d).to(dev()), T(img_feat).to(dev()))
+    with torch.no_grad():
+        rm, rp, rl = O.pmce_forward(sd, T(pose2d), T(img_feat), model.vj_relation, depth=depth)
+    e = (maxabs(mesh, rm), maxabs(pose, rp), maxabs(pose3d, rl))
+    print(f"depth {depth} vs oracle: mesh %.2e m, pose %.2e m, pose3d %.2e mm" % e)
+    assert e[0] < TIGHT_M and e[1] < TIGHT_M and e[2] < TOL_MM

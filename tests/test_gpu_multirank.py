@@ -75,11 +75,29 @@ def test_bench_two_ranks_on_this_box():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--windows", "2", "--batch",
-                        "32", "--embed-dim", "256"], cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+                        "32", "--embed-dim", "256", "--cpu-seconds", "2"], cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = lines[0]
     print({k: d[k] for k in ("value", "n_gpus", "ms_per_step", "outputs_finite")})
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 64 and d["outputs_finite"] and d["value"] > 0
-    assert d["roofline"] is not None and d["cpu_baseline"] is None
+    assert d["roofline"] is not None and d["cpu_baseline"]["value"] > 0           # rank 0 times the CPU baseline at N > 1 as well
+    assert len(d["per_rank_clips_s"]) == 2 and all(v > 0 for v in d["per_rank_clips_s"])
+    assert d["metric_reduction"]["clips_counted"] == 64 and d["metric_reduction"]["backend"] == "gloo"
+
+
+def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():
+    """The first box with two devices exercises RCCL with more than one rank: `python bench.py --gpus 2` exactly as the round
+    driver launches it (backend nccl, one rank per GPU).  On a one-GPU box RCCL refuses two ranks on one device - skipped."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs (RCCL refuses two ranks on one device)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "PMCE_BENCH_SHARE_GPU", "PMCE_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--windows", "2", "--cpu-seconds", "2"],
+                       cwd=REPO, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    print({k: d[k] for k in ("value", "n_gpus", "ms_per_step", "per_rank_clips_s", "metric_reduction")})
+    assert d["n_gpus"] == 2 and d["metric_reduction"]["backend"] == "nccl" and d["metric_reduction"]["clips_counted"] == 512
+    assert d["outputs_finite"] and min(d["per_rank_clips_s"]) > 0.5 * max(d["per_rank_clips_s"])
