@@ -226,13 +226,21 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
         // every lane still stores one dword per element: even lanes {hi(n), hi(n+1)}, odd lanes {lo(n-1), lo(n)}.
         const bool odd = lane & 1;
         const int colf = (n0 >> 4) * 32 + (odd ? 16 + ((n0 - 1) & 15) : (n0 & 15));  // f16 index inside the 32-column group
+        // Buffer-form stores: 16 lane offsets (row r of a 32x32 block + this lane's f16 pair) serve every block; the block's position
+        // is added to the lane offset (NOT passed as the scalar offset: the range check that drops the rows beyond M covers the
+        // lane offset only), and the descriptor ends after row M - 1.
+        const unsigned rows_left = (unsigned)min(p.M - m_base, BM);
+        const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(p.C + (size_t)m_base * p.ldc, 0, rows_left * (unsigned)p.ldc * 4u, 0x00020000);
+        unsigned voff[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) voff[r] = (unsigned)(4 * hb + (r & 3) + 8 * (r >> 2)) * (unsigned)p.ldc * 4u + (unsigned)colf * 2u;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int cb = n_base + wn * WN + j * 32;
+          if (cb >= p.N) continue;  // (N % 32 == 0: a 32-column block is all in or all out)
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
-            const int mrow = m_base + wm * WM + i * 32 + 4 * hb;
-            _Float16* __restrict__ Cp = reinterpret_cast<_Float16*>(p.C) + (size_t)mrow * (2 * p.ldc) + 2 * cb + colf;
+            const unsigned so = ((unsigned)(wm * WM + i * 32) * (unsigned)p.ldc + (unsigned)cb) * 4u;  // wave-uniform
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
               f32x2 v = {acc[i][j][r] * w_down[j], acc[i][j][r + 1] * w_down[j]};
@@ -246,8 +254,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
                 const unsigned w = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
                 const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);  // lane ^ 1
                 const unsigned outw = odd ? ((nbr >> 16) | (w & 0xffff0000u)) : ((w & 0xffffu) | (nbr << 16));
-                const int rr = ((r + e) & 3) + 8 * ((r + e) >> 2);
-                if (mrow + rr < p.M && cb < p.N) __builtin_nontemporal_store(outw, reinterpret_cast<unsigned*>(Cp + (size_t)rr * (2 * p.ldc)));  // (N % 32 == 0: a 32-column block is all in or all out)
+                __builtin_amdgcn_raw_buffer_store_b32(outw, rsrc_c, voff[r + e] + so, 0, 2);
               }
             }
           }

@@ -97,6 +97,10 @@ class PinnedFeeder:
         self._used = [False] * slots
         # the first DMA out of a fresh pinned buffer costs ~10 ms (page registration on first use): pay it here, not in the
         # first batches
+        # The device buffers come from the CURRENT stream's pool: the allocator may hand out blocks whose previous owner's kernels
+        # are still queued on that stream (freed tensors are reusable at once by the same stream).  The copy stream is ordered
+        # behind everything queued there so far, or a late kernel of a dead tensor would write into a batch already copied in.
+        self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.copy_stream):
             for h, d in zip(self.host, self.dev):
                 for k in h:

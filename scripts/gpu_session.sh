@@ -1,15 +1,15 @@
 #!/bin/bash
-# Round-2 GPU session script: bash scripts/gpu_r02.sh [tests] [bench] [sweep] [prof] [pmc] (any subset, in this order).
-# Everything lands under gpurun_out/r02/.
+# GPU session script: bash scripts/gpu_session.sh [tests] [bench] [sweep] [prof] [pmc] (any subset, in this order).
+# Everything lands under gpurun_out/r03/.
 set -u
-mkdir -p gpurun_out/r02
-O=gpurun_out/r02
+mkdir -p gpurun_out/r03
+O=gpurun_out/r03
 export TMPDIR=/tmp PMCE_SYNTHETIC_BASE_DATA=1
 python -c "import pmce_amd.build as b; print(b.build())" > $O/build.log 2>&1 || { cat $O/build.log; exit 1; }
 for what in "$@"; do
 case $what in
 tests)
-  timeout 1500 python -m pytest tests -m gpu -q -s -p no:cacheprovider -x > $O/pytest_gpu.log 2>&1
+  timeout 1500 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $O/pytest_gpu.log 2>&1
   echo "pytest exit: $?" | tee -a $O/pytest_gpu.log
   grep -E "passed|failed|error" $O/pytest_gpu.log | tail -5
   ;;

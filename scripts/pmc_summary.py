@@ -1,4 +1,4 @@
-"""FETCH_SIZE / WRITE_SIZE rocprofv3 passes (scripts/gpu_r02.sh pmc) -> per-kernel HBM traffic per launch (KiB), the file
+"""FETCH_SIZE / WRITE_SIZE rocprofv3 passes (scripts/gpu_session.sh pmc) -> per-kernel HBM traffic per launch (KiB), the file
 bench.py reads for `roofline.traffic`.  usage: pmc_summary.py <dir with FETCH_SIZE/ and WRITE_SIZE/> <out.json>"""
 import collections
 import csv
