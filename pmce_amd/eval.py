@@ -7,7 +7,10 @@
   ``gt_joints_mm`` / ``keep_global`` it is ``Human36M.evaluate`` (data/Human36M/dataset.py:715-848): annotated ground-truth
   joints, camera-4 samples only.
 
-Kernels: csrc/metrics.hip through the C ABI.  torch is used for allocation and the final few-float reductions only.
+Kernels: csrc/metrics.hip through the C ABI.  torch is used for allocation and the final few-float reductions only.  Those
+reductions (fp64 sums, cat / stack) may run while pipeline lanes are computing the next batches: torch kernels of exactly these
+kinds are checked bit-correct beside forwards of both product modes on every run of the GPU suite
+(tests/test_gpu_bystander.py).
 """
 from __future__ import annotations
 

@@ -204,9 +204,11 @@ class HipModuleBase(nn.Module):
         on the same CU (scripts/microbench/victims.py).  The library is therefore built without any packed-fp32 instruction
         (build.py; checked on the device code by tests/test_host_logic.py), which makes its own kernels safe next to each other:
         both modes use the two-stream / two-batches-in-flight execution, and overlapped runs are bitwise equal to serial ones
-        (tests/test_gpu_e2e.py::test_overlapped_split_mode_equals_serial).  OTHER GPU work of the process that contains
-        packed-fp32 arithmetic (e.g. elementwise torch kernels on another stream) must not run concurrently with a forward in
-        'split_f16' mode; 'f32' mode has no such restriction.  PMCE_SPLIT_OVERLAP=0 restores the strictly serial schedule."""
+        (tests/test_gpu_e2e.py::test_overlapped_split_mode_equals_serial).  OTHER GPU work of the process: what the suite measures
+        on every run (tests/test_gpu_bystander.py) is that torch's elementwise / normalisation / reduction kernels and
+        compiler-generated packed fp32 stay bit-correct beside forwards in both modes; the affected form is hand-written
+        v_pk_fma_f32 with op_sel operands - code like that should not run concurrently with a forward in 'split_f16' mode
+        ('f32' mode has no such restriction; PMCE_SPLIT_OVERLAP=0 restores the strictly serial schedule)."""
         if mode not in (None, "split_f16", "f32"):
             raise ValueError("gemm mode must be 'split_f16', 'f32' or None")
         self._gemm_mode = mode
