@@ -58,6 +58,8 @@ PROTOTYPES = {
     "pmce_gemm_nt_split_f16_ex": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _l, _l, _i, _i, _i, _s],
     "pmce_ln_chain_ex_f32": [_f, _l, _i, _f, _f, _fl, _f, _i, _i, _f, _f, _f, _fl, _f, _i, _s],
     "pmce_seq_attention_ex_f32": [_f, _f, _i, _i, _i, _i, _l, _l, _l, _i, _s],
+    "pmce_seq_attention_split_supported": [_i, _i],
+    "pmce_seq_attention_split_f16": [_f, _f, _i, _i, _i, _i, _l, _l, _l, _s],
     "pmce_gemm_nt_split_f16_rowmap": [_f, _f, _f, _f, _f, _i, _i, _i, _l, _i, _l, _l, _s],
     "pmce_gemm_split_set_tuning": [_i],
     "pmce_gemm_split_set_ws": [_i],

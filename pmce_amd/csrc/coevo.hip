@@ -341,7 +341,10 @@ __device__ __forceinline__ void weight_scale(const float* __restrict__ src, int 
   down = mx > 0.f ? ldexpf(1.f, e - 15) : 1.f;
 }
 // slots [8s, 8s+8) of an activation -> the (hi, lo*2^11) B fragments of k-step s
-__device__ __forceinline__ void split_slots8(const float* x, tl_f16x8& hi, tl_f16x8& lo) {
+__device__ __forceinline__ void split_slots8(const float* x_, tl_f16x8& hi, tl_f16x8& lo) {
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = pinned(x_[e]);  // one fp32 value for both planes (common.hpp)
 #pragma unroll
   for (int e = 0; e < 8; ++e) hi[e] = (_Float16)x[e];
 #pragma unroll

@@ -153,8 +153,18 @@ __device__ __forceinline__ void stage_weight(float* __restrict__ dst, const floa
 // (gemm_split_f16.hip): per 16-wide k-tile 16 f16 "hi" then 16 f16 "lo * 2^11".  `row` is the row's start (the packed row takes
 // the bytes of the fp32 row).
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store4_split_f16(float* __restrict__ row, int c, const f32x4& v) {
+// A COMPUTED value that is about to be split into its (hi, lo) f16 planes goes through this first.  Under -ffp-contract=fast hipcc
+// folds the arithmetic that produced v into each conversion on its own: hi = v_fma_mixlo_f16(a, b) (ONE rounding, of the exact
+// product) in one place and v_cvt_f16_f32 of the fp32-rounded a*b in another.  When rne32(a*b) is an f16 tie the two disagree by
+// an ulp, and a lo computed against the one is stored next to the other: an element off by 2^-10 relative, about one in 10^5
+// (found by the matrix-pipe attention's test).  Pinned, v is ONE fp32 value for both planes.
+__device__ __forceinline__ float pinned(float v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ void store4_split_f16(float* __restrict__ row, int c, const f32x4& v_) {
   f16x4 hi, lo;
+  const f32x4 v = {pinned(v_[0]), pinned(v_[1]), pinned(v_[2]), pinned(v_[3])};
 #pragma unroll
   for (int e = 0; e < 4; ++e) hi[e] = (_Float16)v[e];
 #pragma unroll

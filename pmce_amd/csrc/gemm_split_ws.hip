@@ -386,7 +386,7 @@ __global__ __launch_bounds__(1024) void gemm_split_ws_kernel(SplitParams p) {
             if (ACT == 1) v = gelu_erf2(v);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-              const float x = e ? v.y : v.x;
+              const float x = pinned(e ? v.y : v.x);
               const _Float16 h = (_Float16)x;
               bad = bad || nonfinite((float)h);  // also a finite x beyond f16's 65504: the next product could not read it
               const _Float16 lo = (_Float16)((x - (float)h) * 2048.0f);

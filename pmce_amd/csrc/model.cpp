@@ -114,6 +114,7 @@ struct pmce_model {
   // other.  PMCE_SPLIT_OVERLAP=0 at create restores the strictly serial schedule of the split mode (diagnostic).
   bool split_overlap = true;
   bool ffn_f16 = true;
+  bool attn_f16 = true;  // the lifter's attention on the f16 matrix pipe in split mode (PMCE_ATTN_F16=0: the vector-pipe kernel, an A/B knob)
   bool split_now = false;  // decision for the call in progress (set by check_ws, the first thing every entry point does)
   // Sticky "a product of this model produced a non-finite value" word: 4 bytes of pinned host memory the device can write
   // (hipHostMalloc, mapped), so that reading it costs no synchronisation.  Set by the split-f16 products' epilogues (an activation
@@ -370,12 +371,18 @@ int lifter_block_body(pmce_model* m, int kind, int i, long long M, int nframes, 
   const int J = m->J, C = m->C;
   const LifterBlockW& bw = m->w.blk[kind][i];
   const LifterBlockSplit& sw = m->sblk[kind][i];
+  // split mode: q, k, v leave the product pre-split and the attention runs on the f16 matrix pipe too (seq_attention_mfma.hip)
+  const int N_seq = kind == 0 ? J : T;
+  const bool mfma_attn = m->split_now && sw.qkv.wp && m->attn_f16 && pmce_seq_attention_split_supported(N_seq, C);
   RUN(P_GEMM_LIFTER, lgemm(m, w.XN, bw.qkv_w, sw.qkv, bw.qkv_b, nullptr, w.QKV,
-                          (int)M, 3 * C, C, C, 3 * C, 0, stream, pk(m)));
-  if (kind == 0)  // sequences = frames, tokens j contiguous                        (PoseEstimation.py:78,101)
-    RUN(P_SEQ_ATTN, pmce_seq_attention_ex_f32(w.QKV, w.AO, nframes, J, C, 0, J, 0, 1, pk(m), stream));
-  else  // sequences = (b,j), tokens t at stride J                                  (PoseEstimation.py:87,104)
-    RUN(P_SEQ_ATTN, pmce_seq_attention_ex_f32(w.QKV, w.AO, B * J, T, C, J, 1, (long long)T * J, J, pk(m), stream));
+                          (int)M, 3 * C, C, C, 3 * C, 0, stream, pk(m), mfma_attn ? 1 : 0));
+  if (kind == 0) {  // sequences = frames, tokens j contiguous                      (PoseEstimation.py:78,101)
+    if (mfma_attn) RUN(P_SEQ_ATTN, pmce_seq_attention_split_f16(w.QKV, w.AO, nframes, J, C, 0, J, 0, 1, stream));
+    else RUN(P_SEQ_ATTN, pmce_seq_attention_ex_f32(w.QKV, w.AO, nframes, J, C, 0, J, 0, 1, pk(m), stream));
+  } else {  // sequences = (b,j), tokens t at stride J                              (PoseEstimation.py:87,104)
+    if (mfma_attn) RUN(P_SEQ_ATTN, pmce_seq_attention_split_f16(w.QKV, w.AO, B * J, T, C, J, 1, (long long)T * J, J, stream));
+    else RUN(P_SEQ_ATTN, pmce_seq_attention_ex_f32(w.QKV, w.AO, B * J, T, C, J, 1, (long long)T * J, J, pk(m), stream));
+  }
   RUN(P_GEMM_LIFTER, lgemm(m, w.AO, bw.proj_w, sw.proj, bw.proj_b, w.X, w.X, (int)M, C,
                           C, C, C, 0, stream, pk(m)));
   RUN(P_LN, pmce_ln_chain_ex_f32(w.X, M, C, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, bw.norm2_w,
@@ -793,6 +800,7 @@ int pmce_model_create(int num_joint, int embed_dim, int depth, pmce_model** out)
   m->split_gemm = pmce_env_int("PMCE_SPLIT_F16", 1) != 0;
   m->split_min_batch = pmce_env_int("PMCE_SPLIT_MIN_BATCH", 1);
   m->ffn_f16 = pmce_env_int("PMCE_FFN_F16", 1) != 0;
+  m->attn_f16 = pmce_env_int("PMCE_ATTN_F16", 1) != 0;
   m->split_overlap = pmce_env_int("PMCE_SPLIT_OVERLAP", 1) != 0;
   build_names(m);
   *out = m;

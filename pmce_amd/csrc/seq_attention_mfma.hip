@@ -1,0 +1,257 @@
+// Short-sequence multi-head attention of the pose lifter (timm Attention == reference PoseEstimation.py:78-104 via
+// vision_transformer.Attention; the in-tree copy of the same arithmetic is CoevoDecoder.py:118-131) on the f16 MATRIX pipe, for
+// the split-f16 product mode: q, k, v arrive PRE-SPLIT from the qkv product's epilogue - every fp32 row as
+// [3C/16][16 f16 hi | 16 f16 lo*2^11] in its own bytes - and the result leaves in the same form, as the A operand of `proj`.
+//
+// Why a second attention kernel.  seq_attention_pair_kernel (lifter.hip) does the 2 x N x N x HD multiply-adds of a head on the
+// vector pipe, one query pair per lane: at C = 512 it spends 4,352 v_fma per lane and sequence with 72 of 128 lanes active, holds
+// the whole q / k / v of a sequence in registers on its way to LDS (256 VGPRs, 6-20 spilled), and its phases (fetch, spread,
+// pass 1, softmax, pass 2, store) run one after the other in each of the 4 workgroups a CU holds: 186 / 170 us per launch at
+// B = 256 against 113 us of HBM time for the 713 MB it moves (6.3 TB/s achievable).  Here the arithmetic is ~24 matrix
+// instructions per head and product pair, the operands never pass through registers on their way in (LDS-DMA), and a ring of
+// units keeps two units' worth of bytes in flight per CU while a third is being computed - the kernel is meant to sit on the
+// HBM roofline, not on the vector pipe.
+//
+// Arithmetic.  With x = xh + xl*2^-11 (xh = rne16(x), xl = rne16((x - xh) * 2^11)):
+//     q.k = sum qh*kh + 2^-11 * sum (qh*kl + ql*kh)          (dropped: ql*kl, 2^-22 relative)
+// the two sums in separate fp32 accumulators of v_mfma_f32_32x32x16_f16.  Computed TRANSPOSED, S^T = K Q^T (rows = keys, columns =
+// queries): a lane then holds 16 of the 32 keys of ONE query, the softmax over keys is in-lane plus one exchange with lane ^ 32,
+// and P^T in the accumulators already IS the B operand (k = keys, n = queries) of out^T = V^T P^T - in the register order
+// key(s, hb, e) = 16 s + 4 hb + (e & 3) + 8 (e >> 2), which the A operand (V^T, gathered from the row-major V with 16-bit LDS
+// reads) simply follows.  P is split like every other operand (p in [0, 1]: ph = rne16(p), pl = rne16((p - ph) * 2^11)), the
+// softmax is the exact two-pass form on the hardware 2^x with log2-scaled scores, normalisation by 1 / sum once at the end.
+// Keys >= N (a sequence is 16 frames or 17 / 19 joints; the matrix tile is 32 x 32) read a clamped row and get a score of -inf.
+//
+// Work split.  A unit = one sequence x one 1 KB column chunk of q, k and v (4 heads at HD = 64, all 8 at HD = 32): 3 N DMA
+// instructions of 64 lanes x 16 B, rows at a stride of 1040 B in LDS (65 sixteen-byte slots: the 16 rows a ds_read_b128 service
+// group touches fall on 16 different slots).  Four waves, each owning the heads in its 256 B of the chunk; persistent
+// workgroups, one per CU, over units blockIdx.x + k * gridDim.x; ring of 3 units (2 for N = 19).  One barrier per unit: wait for
+// the unit's DMAs (counted s_waitcnt: vmcnt counts this wave's DMAs and result stores in issue order), barrier, issue the DMAs of
+// unit k + NS - 1 into the slot read in iteration k - 1, compute.  The result goes through the unit's own (dead) Q rows - each wave
+// only ever touches its own 256 B of them - and leaves as full 256-byte row segments.
+#include "gemm_split_common.hpp"
+
+namespace {
+
+template <int HD, int N>
+struct AttnCfg {
+  static constexpr int C = 8 * HD;
+  static constexpr int UPS = C * 4 / 1024;       // units (1 KB column chunks) per sequence
+  static constexpr int HPW = 1024 / (HD * 4) / 4;  // heads per wave
+  static constexpr int RS = 1040;                // LDS row stride in bytes
+  static constexpr int UNIT = 3 * N * RS;        // one ring slot: Q rows, K rows, V rows
+  static constexpr int NS = 3 * UNIT <= 160 * 1024 ? 3 : 2;
+  static constexpr int DPW = (3 * N + 3) / 4;    // DMA instructions per wave and unit (the last ones may repeat a row)
+  static constexpr int ST = (N + 3) / 4;         // result store instructions per wave and unit
+  static constexpr int LDS_BYTES = NS * UNIT;
+  static constexpr int KSTEPS = HD / 16, DBLK = HD / 32, PSTEPS = N > 16 ? 2 : 1;
+};
+
+template <int HD, int N>
+__global__ __launch_bounds__(256, 1) void seq_attention_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out, int nseq,
+                                                                   int seq_div, long long seq_lo, long long seq_hi,
+                                                                   long long tok_stride, unsigned* oflow) {
+  using Cfg = AttnCfg<HD, N>;
+  constexpr int C = Cfg::C, UPS = Cfg::UPS, HPW = Cfg::HPW, RS = Cfg::RS, UNIT = Cfg::UNIT, NS = Cfg::NS, DPW = Cfg::DPW, ST = Cfg::ST;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hb = lane >> 5;
+  const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem;
+  const int total = nseq * UPS;
+  const int nmine = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const unsigned tok_bytes = (unsigned)tok_stride * (unsigned)(3 * C * 4);  // (a sequence spans < 4 GiB: checked by the launcher)
+
+  auto unit_coords = [&](int k, long long& tokbase, int& g) {
+    const int u = (int)blockIdx.x + k * (int)gridDim.x;
+    const int seq = u / UPS;
+    g = u - seq * UPS;
+    tokbase = (long long)(seq % seq_div) * seq_lo + (long long)(seq / seq_div) * seq_hi;
+  };
+  auto issue = [&](int k, int slot) {
+    long long tb;
+    int g;
+    unit_coords(k, tb, g);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qkv) + tb * (3 * C), 0, 0xffffffff, 0x00020000);
+    const unsigned slot_base = lds0 + (unsigned)slot * UNIT;
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+      const int i = min(wave + 4 * j, 3 * N - 1);  // (a repeated instruction rewrites the same row with the same bytes)
+      const int a = i / N, r = i - a * N;
+      sdma16(rsrc, (unsigned)lane * 16u, (int)((unsigned)r * tok_bytes + (unsigned)(a * C * 4 + g * 1024)), slot_base + (unsigned)((a * N + r) * RS));
+    }
+  };
+
+  int issued = 0, i_slot = 0;
+#pragma unroll
+  for (int q = 0; q < NS - 1; ++q)
+    if (issued < nmine) {
+      issue(issued, i_slot);
+      ++issued;
+      i_slot = i_slot + 1 == NS ? 0 : i_slot + 1;
+    }
+
+  // hd^-0.5 * log2(e): scores in log2 units, softmax on the hardware 2^x
+  constexpr float scale = (HD == 32 ? 0.17677669529663688110f : 0.125f) * 1.44269504088896340736f;
+  constexpr float two_m11 = 0.00048828125f;
+  const int rowc = min(l31, N - 1);  // this lane's key row (A operand of K Q^T) and query row (B operand), clamped into the sequence
+  bool bad = false;
+  int slot = 0;
+  for (int it = 0; it < nmine; ++it) {
+    // unit `it` has landed when nothing older than the (NS - 2) younger units' DMAs and the last (NS - 1) units' stores is
+    // outstanding; in the first iterations and in the tail fewer operations follow it, so wait for everything
+    if (issued - it - 1 == NS - 2 && it >= NS - 1) wait_vm<(NS - 2) * DPW + (NS - 1) * ST>();
+    else wait_vm<0>();
+    __syncthreads();
+    if (issued < nmine) {
+      issue(issued, i_slot);
+      ++issued;
+      i_slot = i_slot + 1 == NS ? 0 : i_slot + 1;
+    }
+    unsigned char* const U = smem + slot * UNIT;
+#pragma unroll
+    for (int h = 0; h < HPW; ++h) {
+      const int hoff = (wave * HPW + h) * (HD * 4);  // this head's bytes inside a row of the unit
+      // ---- S^T = K Q^T ----
+      f32x16 s_main, s_cross;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_main[r] = s_cross[r] = 0.f;
+      const unsigned char* pq = U + (0 * N + rowc) * RS + hoff + hb * 16;
+      const unsigned char* pk = U + (1 * N + rowc) * RS + hoff + hb * 16;
+#pragma unroll
+      for (int ks = 0; ks < Cfg::KSTEPS; ++ks) {
+        const f16x8 kh = *reinterpret_cast<const f16x8*>(pk + ks * 64), kl = *reinterpret_cast<const f16x8*>(pk + ks * 64 + 32);
+        const f16x8 qh = *reinterpret_cast<const f16x8*>(pq + ks * 64), ql = *reinterpret_cast<const f16x8*>(pq + ks * 64 + 32);
+        s_main = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh, s_main, 0, 0, 0);
+        s_cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql, s_cross, 0, 0, 0);
+        s_cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh, s_cross, 0, 0, 0);
+      }
+      // ---- softmax over the keys of this lane's query: register r is key 4 hb + (r & 3) + 8 (r >> 2) ----
+      float p[16];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 4 * hb + (r & 3) + 8 * (r >> 2);
+        const float sv = fmaf(s_cross[r], two_m11, s_main[r]) * scale;
+        p[r] = (r < 8 || N > 16) ? (key < N ? sv : -INFINITY) : -INFINITY;  // (N <= 16: registers 8..15 are keys >= 16)
+        mx = fmaxf(mx, p[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        p[r] = __builtin_amdgcn_exp2f(p[r] - mx);
+        sum += p[r];
+      }
+      sum += __shfl_xor(sum, 32);
+      const float inv = 1.0f / sum;
+      // ---- out^T = V^T P^T, one 32-channel block at a time ----
+#pragma unroll
+      for (int blk = 0; blk < Cfg::DBLK; ++blk) {
+        f32x16 o_main, o_cross;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_main[r] = o_cross[r] = 0.f;
+        // f16 index of channel 32 blk + l31 inside the row's planes: group (2 blk + (l31 >> 4)) of 32 halves, hi at (l31 & 15), lo 16 further
+        const _Float16* pv = reinterpret_cast<const _Float16*>(U + 2 * N * RS + hoff) + (2 * blk + (l31 >> 4)) * 32 + (l31 & 15);
+#pragma unroll
+        for (int s = 0; s < Cfg::PSTEPS; ++s) {
+          f16x8 ph, pl, vh, vl;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float pv32 = pinned(p[8 * s + e]);
+            ph[e] = (_Float16)pv32;
+            pl[e] = (_Float16)((pv32 - (float)ph[e]) * 2048.0f);
+          }
+          // keys 16.. exist only up to N - 1 (and only in the hb = 0 half): the other slots carry p = 0 and may hold any finite v
+          constexpr int NE = 8;
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            const int key = 16 * s + (e & 3) + 8 * (e >> 2);  // + 4 hb
+            if (s == 0 || key < N) {
+              const _Float16* pr = pv + (size_t)min(key + 4 * hb, N - 1) * (RS / 2);
+              vh[e] = pr[0];
+              vl[e] = pr[16];
+            } else {
+              vh[e] = vh[0];
+              vl[e] = vl[0];
+            }
+          }
+          o_main = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o_main, 0, 0, 0);
+          o_cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o_cross, 0, 0, 0);
+          o_cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o_cross, 0, 0, 0);
+        }
+        // register r is channel 32 blk + 4 hb + (r & 3) + 8 (r >> 2) of query l31: four consecutive channels per r >> 2, written
+        // pre-split into this head's bytes of the (dead) Q row
+        if (l31 < N) {
+          unsigned char* po = U + l31 * RS + hoff;
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            f16x4 oh, ol;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float v = pinned(fmaf(o_cross[4 * rq + e], two_m11, o_main[4 * rq + e]) * inv);
+              bad = bad || nonfinite(v);
+              oh[e] = (_Float16)v;
+              ol[e] = (_Float16)((v - (float)oh[e]) * 2048.0f);
+            }
+            const int g16 = 2 * blk + (rq >> 1), idx = 8 * (rq & 1) + 4 * hb;
+            *reinterpret_cast<f16x4*>(po + g16 * 64 + idx * 2) = oh;
+            *reinterpret_cast<f16x4*>(po + g16 * 64 + 32 + idx * 2) = ol;
+          }
+        }
+      }
+    }
+    // ---- this wave's 256 B of every result row: LDS (written by other lanes of the wave) -> global, full segments ----
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+      long long tb;
+      int g;
+      unit_coords(it, tb, g);
+#pragma unroll
+      for (int i = 0; i < ST; ++i) {
+        const int row = 4 * i + (lane >> 4), piece = lane & 15;
+        if (row < N) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(U + row * RS + wave * 256 + piece * 16);
+          *reinterpret_cast<f32x4*>(out + (tb + row * tok_stride) * C + g * 256 + wave * 64 + piece * 4) = t;
+        }
+      }
+    }
+    slot = slot + 1 == NS ? 0 : slot + 1;
+  }
+  report_nonfinite(oflow, bad);
+}
+
+template <int HD, int N>
+int launch(const float* qkv, float* out, int nseq, int seq_div, long long seq_lo, long long seq_hi, long long tok_stride, hipStream_t stream) {
+  using Cfg = AttnCfg<HD, N>;
+  static std::atomic<unsigned long long> done{0};
+  PMCE_TRY(pmce_opt_in_lds(reinterpret_cast<const void*>(&seq_attention_mfma_kernel<HD, N>), Cfg::LDS_BYTES, done, "seq_attention_split_f16"));
+  const int units = nseq * Cfg::UPS;
+  const int grid = units < 256 ? units : 256;
+  hipLaunchKernelGGL((seq_attention_mfma_kernel<HD, N>), dim3(grid), dim3(256), Cfg::LDS_BYTES, stream, qkv, out, nseq, seq_div, seq_lo, seq_hi,
+                     tok_stride, pmce_overflow_sink());
+  return pmce_check_launch("seq_attention_split_f16");
+}
+
+}  // namespace
+
+extern "C" int pmce_seq_attention_split_supported(int N, int C) { return (C == 256 || C == 512) && (N == 16 || N == 17 || N == 19) ? 1 : 0; }
+
+extern "C" int pmce_seq_attention_split_f16(const float* qkv, float* out, int nseq, int N, int C, int seq_div, long long seq_lo,
+                                            long long seq_hi, long long tok_stride, hipStream_t stream) {
+  PMCE_REQUIRE(qkv && out && nseq > 0, "seq_attention_split_f16: bad arguments");
+  if (seq_div <= 0) seq_div = 0x7fffffff;  // (as pmce_seq_attention_f32: sequence s starts at token s * seq_lo)
+  PMCE_REQUIRE(pmce_seq_attention_split_supported(N, C), "seq_attention_split_f16: C must be 256 or 512 and N 16, 17 or 19 (got N=%d C=%d)", N, C);
+  PMCE_REQUIRE(tok_stride > 0 && (long long)N * tok_stride * 3 * C * 4 < (1ll << 32), "seq_attention_split_f16: a sequence spans 4 GiB or more");
+#define PMCE_ATTN_CASE(HD_, N_) \
+  if (C == 8 * HD_ && N == N_) return launch<HD_, N_>(qkv, out, nseq, seq_div, seq_lo, seq_hi, tok_stride, stream)
+  PMCE_ATTN_CASE(64, 16);
+  PMCE_ATTN_CASE(64, 17);
+  PMCE_ATTN_CASE(64, 19);
+  PMCE_ATTN_CASE(32, 16);
+  PMCE_ATTN_CASE(32, 17);
+  PMCE_ATTN_CASE(32, 19);
+#undef PMCE_ATTN_CASE
+  return PMCE_OK;
+}

@@ -90,6 +90,24 @@ def seq_attention(qkv, nseq, N, Cc, seq_div, seq_lo, seq_hi, tok_stride, out_spl
     return out
 
 
+def seq_attention_split(qkv_planes, nseq, N, Cc, seq_div, seq_lo, seq_hi, tok_stride):
+    """The matrix-pipe attention of the split-f16 mode: pre-split q, k, v in, pre-split result out (see :func:`split_rows_f16`,
+    :func:`unsplit_rows_f16`)."""
+    lib = _lib.load()
+    qkv_planes = _c(qkv_planes)
+    out = torch.empty(qkv_planes.shape[0], Cc, device=qkv_planes.device, dtype=torch.float32)
+    _lib.check(lib.pmce_seq_attention_split_f16(P(qkv_planes), P(out), nseq, N, Cc, seq_div, seq_lo, seq_hi, tok_stride, _st()),
+               "seq_attention_split_f16")
+    return out
+
+
+def unsplit_rows_f16(Ap):
+    """The fp32 values a packed (hi | lo*2^11) f16 buffer stands for (float64, exact): inverse of :func:`split_rows_f16`."""
+    M, K = Ap.shape
+    h = Ap.contiguous().view(torch.float16).view(M, K // 16, 2, 16).double()
+    return (h[:, :, 0] + h[:, :, 1] / 2048.0).reshape(M, K)
+
+
 def vertex_init_gather(joints, vj_relation):
     lib = _lib.load()
     joints = _c(joints)

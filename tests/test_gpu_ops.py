@@ -288,6 +288,41 @@ def test_seq_attention(C, J):
     assert torch.equal(pt.view(torch.int32), ops.split_rows_f16(out_t).view(torch.int32))
 
 
+@pytest.mark.parametrize("C,J,B", [(512, 17, 2), (256, 17, 2), (512, 19, 1), (256, 19, 3), (512, 17, 37)])
+def test_seq_attention_split_f16(C, J, B):
+    """The matrix-pipe attention of the split-f16 mode (pre-split q, k, v in, pre-split result out) against the fp64 attention of
+    the SAME operands (what the planes stand for), next to the vector-pipe kernel's error on them; spatial and temporal layout;
+    larger scores than a model produces (|q.k| up to ~40) so that the softmax is peaked; bitwise repeatable."""
+    from pmce_amd import ops
+    Tn, H = 16, 8
+    hd = C // H
+    M = B * Tn * J
+    qkv = (rnd("attn.qkv", (M, 3 * C)) * 1.7).to(dev())
+    planes = ops.split_rows_f16(qkv)
+    exact = ops.unsplit_rows_f16(planes)                                       # float64 [M, 3C]: the values the planes hold
+    assert (exact - qkv.double()).abs().max().item() < 1e-5
+
+    def ref(seq_first):
+        x = exact.reshape(B, Tn, J, 3, H, hd)
+        x = x if seq_first == "s" else x.permute(0, 2, 1, 3, 4, 5)
+        q, k, v = x[..., 0, :, :], x[..., 1, :, :], x[..., 2, :, :]
+        q, k, v = (z.permute(0, 1, 3, 2, 4) for z in (q, k, v))
+        a = ((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(-1) @ v
+        a = a.permute(0, 1, 3, 2, 4).reshape(*a.shape[:2], a.shape[3], C)
+        return (a if seq_first == "s" else a.permute(0, 2, 1, 3)).reshape(M, C)
+
+    for name, args in (("spatial", (B * Tn, J, C, 0, J, 0, 1)), ("temporal", (B * J, Tn, C, J, 1, Tn * J, J))):
+        want = ref(name[0])
+        got_p = ops.seq_attention_split(planes, *args)
+        got = ops.unsplit_rows_f16(got_p)
+        vec = ops.seq_attention(exact.float(), *args)                              # the vector-pipe kernel on the same values
+        e, ev = (got - want).abs().max().item(), (vec.double() - want).abs().max().item()
+        print(f"seq_attention_split_f16 C={C} J={J} B={B} {name}: {e:.2e} (vector-pipe kernel {ev:.2e}), |out| max {want.abs().max().item():.2f}")
+        assert e < 5e-6
+        again = ops.seq_attention_split(planes, *args)
+        assert torch.equal(again.view(torch.int32), got_p.view(torch.int32))
+
+
 def test_vertex_init_gather_bit_exact(golden):
     from pmce_amd import ops
     z = golden("e2e_J17_C256_B2.npz")
