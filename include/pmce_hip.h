@@ -240,13 +240,13 @@ int pmce_ln_chain_ex_f32(const float* x, long long rows, int C, const float* w1,
                          int out2_split, pmce_stream_t stream);
 int pmce_seq_attention_ex_f32(const float* qkv, float* out, int nseq, int N, int C, int seq_div, long long seq_lo,
                               long long seq_hi, long long tok_stride, int out_split, pmce_stream_t stream);
-/* The same attention (timm Attention of PoseEstimation.py:78-104) on the f16 matrix pipe in the three-product form: q, k, v READ
- * pre-split (the qkv product run with c_packed = 1: [row][3C/16][16 hi | 16 lo*2^11] f16 in the bytes of the fp32 row), the result
- * WRITTEN pre-split as the A operand of proj.  Sequence / token addressing as pmce_seq_attention_f32.  C = 256 or 512 (8 heads),
+/* The same attention (timm Attention of PoseEstimation.py:78-104) on the f16 matrix pipe in the three-product form: q, k, v read
+ * as fp32 (split into f16 (hi, lo) planes inside the kernel), the result WRITTEN pre-split ([row][C/16][16 hi | 16 lo*2^11] f16 in
+ * the bytes of the fp32 row) as the A operand of proj.  Sequence / token addressing as pmce_seq_attention_f32.  C = 256 or 512 (8 heads),
  * N = 16, 17 or 19 (pmce_seq_attention_split_supported tells); anything else returns PMCE_ERR_ARG - callers keep fp32 qkv and
  * pmce_seq_attention_ex_f32 there.  A non-finite result sets the calling thread's overflow sink like the products do. */
 int pmce_seq_attention_split_supported(int N, int C);
-int pmce_seq_attention_split_f16(const float* qkv_planes, float* out_planes, int nseq, int N, int C, int seq_div, long long seq_lo,
+int pmce_seq_attention_split_f16(const float* qkv, float* out_planes, int nseq, int N, int C, int seq_div, long long seq_lo,
                                  long long seq_hi, long long tok_stride, pmce_stream_t stream);
 int pmce_ln_chain_f32(const float* x, long long rows, int C, const float* w1, const float* b1, float eps1,
                       const float* add, int add_div, int add_mod, float* out1, const float* w2, const float* b2,

@@ -395,8 +395,7 @@ static int launch_cfg(SplitParams& p, int act, bool apack, bool opack, hipStream
   if (g > 256 * per_cu) g = 256 * per_cu;
   g = (g + 7) & ~7;
   const bool res = p.R != nullptr;
-  if (opack)  // packed in, packed out: fc1 of the lifter (GELU), qkv (the matrix-pipe attention reads pre-split q, k, v)
-    return act == 1 ? launch_one<TM, TN, 1, false, true, true>(p, g, stream) : launch_one<TM, TN, 0, false, true, true>(p, g, stream);
+  if (opack) return launch_one<TM, TN, 1, false, true, true>(p, g, stream);  // fc1 of the lifter: GELU, packed in, packed out
   if (apack) {
     if (act == 1) return res ? launch_one<TM, TN, 1, true, true>(p, g, stream) : launch_one<TM, TN, 1, false, true>(p, g, stream);
     return res ? launch_one<TM, TN, 0, true, true>(p, g, stream) : launch_one<TM, TN, 0, false, true>(p, g, stream);
@@ -446,8 +445,8 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
                "gemm_split: an operand spans 4 GiB or more (split the batch)");
   PMCE_REQUIRE(ldc < (1ll << 21), "gemm_split: ldc=%lld (the tile epilogue addresses a 256-row window of C / R with 32-bit byte offsets)", ldc);
   PMCE_REQUIRE(c_div == 0 || R == nullptr, "gemm_split: a C row map cannot be combined with a residual");
-  PMCE_REQUIRE(!c_packed || (a_packed && R == nullptr && c_div == 0 && N % 32 == 0 && ldc == N),
-               "gemm_split: a packed result needs a packed A, no residual, no row map, N %% 32 == 0 and ldc == N");
+  PMCE_REQUIRE(!c_packed || (a_packed && act == 1 && R == nullptr && c_div == 0 && N % 32 == 0 && ldc == N),
+               "gemm_split: a packed result is supported for the packed-A + GELU form with N %% 32 == 0 and ldc == N");
   SplitParams p;
   p.A = A; p.W = Wp; p.wscale = wscale; p.bias = bias; p.R = R; p.C = C;
   p.M = M; p.N = N; p.K = K; p.lda = (unsigned)lda; p.ldc = (unsigned)ldc;
@@ -460,7 +459,7 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
   }
   {
     const int forced = g_split_tile.load(std::memory_order_relaxed);
-    if ((forced == 3 || (forced < 0 && g_split_ws.load(std::memory_order_relaxed) != 0)) && !(c_packed && act == 0) && pmce_gemm_split_ws_wants(M, N, K, a_packed, c_div)) {
+    if ((forced == 3 || (forced < 0 && g_split_ws.load(std::memory_order_relaxed) != 0)) && pmce_gemm_split_ws_wants(M, N, K, a_packed, c_div)) {
       PMCE_TRY(pmce_gemm_split_ws_launch(p, act, c_packed, stream));
       return pmce_check_launch("gemm_nt_split_f16 (ws)");
     }

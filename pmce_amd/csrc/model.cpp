@@ -371,11 +371,11 @@ int lifter_block_body(pmce_model* m, int kind, int i, long long M, int nframes, 
   const int J = m->J, C = m->C;
   const LifterBlockW& bw = m->w.blk[kind][i];
   const LifterBlockSplit& sw = m->sblk[kind][i];
-  // split mode: q, k, v leave the product pre-split and the attention runs on the f16 matrix pipe too (seq_attention_mfma.hip)
+  // split mode: the attention runs on the f16 matrix pipe too (seq_attention_mfma.hip; reads the fp32 q, k, v, writes AO pre-split)
   const int N_seq = kind == 0 ? J : T;
-  const bool mfma_attn = m->split_now && sw.qkv.wp && m->attn_f16 && pmce_seq_attention_split_supported(N_seq, C);
+  const bool mfma_attn = m->split_now && m->attn_f16 && pmce_seq_attention_split_supported(N_seq, C);
   RUN(P_GEMM_LIFTER, lgemm(m, w.XN, bw.qkv_w, sw.qkv, bw.qkv_b, nullptr, w.QKV,
-                          (int)M, 3 * C, C, C, 3 * C, 0, stream, pk(m), mfma_attn ? 1 : 0));
+                          (int)M, 3 * C, C, C, 3 * C, 0, stream, pk(m)));
   if (kind == 0) {  // sequences = frames, tokens j contiguous                      (PoseEstimation.py:78,101)
     if (mfma_attn) RUN(P_SEQ_ATTN, pmce_seq_attention_split_f16(w.QKV, w.AO, nframes, J, C, 0, J, 0, 1, stream));
     else RUN(P_SEQ_ATTN, pmce_seq_attention_ex_f32(w.QKV, w.AO, nframes, J, C, 0, J, 0, 1, pk(m), stream));

@@ -1,16 +1,16 @@
 // Short-sequence multi-head attention of the pose lifter (timm Attention == reference PoseEstimation.py:78-104 via
 // vision_transformer.Attention; the in-tree copy of the same arithmetic is CoevoDecoder.py:118-131) on the f16 MATRIX pipe, for
-// the split-f16 product mode: q, k, v arrive PRE-SPLIT from the qkv product's epilogue - every fp32 row as
-// [3C/16][16 f16 hi | 16 f16 lo*2^11] in its own bytes - and the result leaves in the same form, as the A operand of `proj`.
+// the split-f16 product mode: q, k, v arrive as the fp32 rows the qkv product wrote, are split into (hi, lo) f16 planes on the way
+// to the matrix pipe, and the result leaves pre-split - [16 f16 hi | 16 f16 lo*2^11] per 16 channels, in the bytes of the fp32
+// values - as the A operand of `proj`.
 //
 // Why a second attention kernel.  seq_attention_pair_kernel (lifter.hip) does the 2 x N x N x HD multiply-adds of a head on the
 // vector pipe, one query pair per lane: at C = 512 it spends 4,352 v_fma per lane and sequence with 72 of 128 lanes active, holds
 // the whole q / k / v of a sequence in registers on its way to LDS (256 VGPRs, 6-20 spilled), and its phases (fetch, spread,
-// pass 1, softmax, pass 2, store) run one after the other in each of the 4 workgroups a CU holds: 186 / 170 us per launch at
-// B = 256 against 113 us of HBM time for the 713 MB it moves (6.3 TB/s achievable).  Here the arithmetic is ~24 matrix
-// instructions per head and product pair, the operands never pass through registers on their way in (LDS-DMA), and a ring of
-// units keeps two units' worth of bytes in flight per CU while a third is being computed - the kernel is meant to sit on the
-// HBM roofline, not on the vector pipe.
+// pass 1, softmax, pass 2, store) run one after the other in each of the 4 workgroups a CU holds: 175-186 / 150-170 us per launch
+// at B = 256 against 91-113 us of HBM time for the 571-713 MB it moves (6.3 TB/s achievable).  Here the arithmetic is 24 matrix
+// instructions per head, K and V go global -> LDS without passing through registers (LDS-DMA), and the bytes in flight do not
+// depend on how many registers a wave can spare.
 //
 // Arithmetic.  With x = xh + xl*2^-11 (xh = rne16(x), xl = rne16((x - xh) * 2^11)):
 //     q.k = sum qh*kh + 2^-11 * sum (qh*kl + ql*kh)          (dropped: ql*kl, 2^-22 relative)
@@ -18,17 +18,26 @@
 // queries): a lane then holds 16 of the 32 keys of ONE query, the softmax over keys is in-lane plus one exchange with lane ^ 32,
 // and P^T in the accumulators already IS the B operand (k = keys, n = queries) of out^T = V^T P^T - in the register order
 // key(s, hb, e) = 16 s + 4 hb + (e & 3) + 8 (e >> 2), which the A operand (V^T, gathered from the row-major V with 16-bit LDS
-// reads) simply follows.  P is split like every other operand (p in [0, 1]: ph = rne16(p), pl = rne16((p - ph) * 2^11)), the
-// softmax is the exact two-pass form on the hardware 2^x with log2-scaled scores, normalisation by 1 / sum once at the end.
-// Keys >= N (a sequence is 16 frames or 17 / 19 joints; the matrix tile is 32 x 32) read a clamped row and get a score of -inf.
+// reads) simply follows.  P is split like every other operand (p in [0, 1]), the softmax is the exact two-pass form on the hardware
+// 2^x with log2-scaled scores, normalisation by 1 / sum once at the end.  Keys >= N (a sequence is 16 frames or 17 / 19 joints;
+// the matrix tile is 32 x 32) read a clamped row and get a score of -inf.
 //
-// Work split.  A unit = one sequence x one 1 KB column chunk of q, k and v (4 heads at HD = 64, all 8 at HD = 32): 3 N DMA
-// instructions of 64 lanes x 16 B, rows at a stride of 1040 B in LDS (65 sixteen-byte slots: the 16 rows a ds_read_b128 service
-// group touches fall on 16 different slots).  Four waves, each owning the heads in its 256 B of the chunk; persistent
-// workgroups, one per CU, over units blockIdx.x + k * gridDim.x; ring of 3 units (2 for N = 19).  One barrier per unit: wait for
-// the unit's DMAs (counted s_waitcnt: vmcnt counts this wave's DMAs and result stores in issue order), barrier, issue the DMAs of
-// unit k + NS - 1 into the slot read in iteration k - 1, compute.  The result goes through the unit's own (dead) Q rows - each wave
-// only ever touches its own 256 B of them - and leaves as full 256-byte row segments.
+// Work split.  A unit = one sequence x one 1 KB column chunk (4 heads at HD = 64, all 8 at HD = 32).  Four waves, each owning the
+// heads in its 256 B of the chunk:
+//   * K and V rows of the unit: 2 N DMA instructions of 64 lanes x 16 B into a ring of two slots, rows at a stride of 1040 B (65
+//     sixteen-byte slots: the 16 rows a ds_read_b128 service group touches fall on 16 different ones).  Each wave converts ITS
+//     strip of every row in place, fp32 -> [16 hi | 16 lo*2^11] per 16 channels (a quad of lanes reads the 64 bytes of a group in
+//     one instruction and writes them back afterwards; all reads of the strip are issued before the first value is used);
+//   * Q is the B operand - lane (query, k-half) needs 8 consecutive channels of its own row - so it goes global -> registers
+//     directly (32 B per lane and k-step, every fetched line fully used by the wave) and is split in registers; the loads of the
+//     NEXT unit are issued before this unit's arithmetic;
+//   * the result is staged through the wave's own strip of the (dead) K rows and leaves as full 256-byte row segments.
+// One barrier per unit: wait for the unit's DMAs (counted s_waitcnt: vmcnt counts a wave's loads, DMAs and stores in issue order),
+// barrier, issue the next unit's Q loads and DMAs into the other slot, compute.  Persistent workgroups, TWO per CU (71-79 KB of
+// LDS each): with one wave per SIMD nothing hides the dependent chain scores -> softmax -> P V -> split -> store of a unit;
+// with two, one workgroup's chain runs under the other's.  (Measured on the way: q, k, v pre-split by the qkv product's epilogue
+// and all three through LDS, one workgroup per CU with a ring of three: 117 / 110 us per launch at C = 512, but +37 us on each
+// qkv product, which runs at the chip's power limit; the same kernel splitting all three strips in LDS: 149 / 131 us.)
 #include "gemm_split_common.hpp"
 
 namespace {
@@ -36,23 +45,24 @@ namespace {
 template <int HD, int N>
 struct AttnCfg {
   static constexpr int C = 8 * HD;
-  static constexpr int UPS = C * 4 / 1024;       // units (1 KB column chunks) per sequence
+  static constexpr int UPS = C * 4 / 1024;         // units (1 KB column chunks) per sequence
   static constexpr int HPW = 1024 / (HD * 4) / 4;  // heads per wave
-  static constexpr int RS = 1040;                // LDS row stride in bytes
-  static constexpr int UNIT = 3 * N * RS;        // one ring slot: Q rows, K rows, V rows
-  static constexpr int NS = 3 * UNIT <= 160 * 1024 ? 3 : 2;
-  static constexpr int DPW = (3 * N + 3) / 4;    // DMA instructions per wave and unit (the last ones may repeat a row)
-  static constexpr int ST = (N + 3) / 4;         // result store instructions per wave and unit
+  static constexpr int RS = 1040;                  // LDS row stride in bytes
+  static constexpr int UNIT = 2 * N * RS;          // one ring slot: K rows, V rows
+  static constexpr int NS = 2;
+  static constexpr int DPW = (2 * N + 3) / 4;      // DMA instructions per wave and unit (the last ones may repeat a row)
+  static constexpr int ST = (N + 3) / 4;           // result store instructions per wave and unit
   static constexpr int LDS_BYTES = NS * UNIT;
   static constexpr int KSTEPS = HD / 16, DBLK = HD / 32, PSTEPS = N > 16 ? 2 : 1;
+  static constexpr int QL = 2 * KSTEPS * HPW;      // 16-byte Q loads per lane and unit
 };
 
 template <int HD, int N>
-__global__ __launch_bounds__(256, 1) void seq_attention_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out, int nseq,
+__global__ __launch_bounds__(256, 2) void seq_attention_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out, int nseq,
                                                                    int seq_div, long long seq_lo, long long seq_hi,
                                                                    long long tok_stride, unsigned* oflow) {
   using Cfg = AttnCfg<HD, N>;
-  constexpr int C = Cfg::C, UPS = Cfg::UPS, HPW = Cfg::HPW, RS = Cfg::RS, UNIT = Cfg::UNIT, NS = Cfg::NS, DPW = Cfg::DPW, ST = Cfg::ST;
+  constexpr int C = Cfg::C, UPS = Cfg::UPS, HPW = Cfg::HPW, RS = Cfg::RS, UNIT = Cfg::UNIT, DPW = Cfg::DPW, ST = Cfg::ST, QL = Cfg::QL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hb = lane >> 5;
@@ -60,6 +70,7 @@ __global__ __launch_bounds__(256, 1) void seq_attention_mfma_kernel(const float*
   const int total = nseq * UPS;
   const int nmine = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const unsigned tok_bytes = (unsigned)tok_stride * (unsigned)(3 * C * 4);  // (a sequence spans < 4 GiB: checked by the launcher)
+  const int rowc = min(l31, N - 1);  // this lane's key row (A operand of K Q^T) and query row (B operand), clamped into the sequence
 
   auto unit_coords = [&](int k, long long& tokbase, int& g) {
     const int u = (int)blockIdx.x + k * (int)gridDim.x;
@@ -67,6 +78,7 @@ __global__ __launch_bounds__(256, 1) void seq_attention_mfma_kernel(const float*
     g = u - seq * UPS;
     tokbase = (long long)(seq % seq_div) * seq_lo + (long long)(seq / seq_div) * seq_hi;
   };
+  // K and V rows of unit k -> ring slot (arrays 1 and 2 of the row: byte offsets C*4 and 2*C*4)
   auto issue = [&](int k, int slot) {
     long long tb;
     int g;
@@ -75,55 +87,118 @@ __global__ __launch_bounds__(256, 1) void seq_attention_mfma_kernel(const float*
     const unsigned slot_base = lds0 + (unsigned)slot * UNIT;
 #pragma unroll
     for (int j = 0; j < DPW; ++j) {
-      const int i = min(wave + 4 * j, 3 * N - 1);  // (a repeated instruction rewrites the same row with the same bytes)
+      const int i = min(wave + 4 * j, 2 * N - 1);  // (a repeated instruction rewrites the same row with the same bytes)
       const int a = i / N, r = i - a * N;
-      sdma16(rsrc, (unsigned)lane * 16u, (int)((unsigned)r * tok_bytes + (unsigned)(a * C * 4 + g * 1024)), slot_base + (unsigned)((a * N + r) * RS));
+      sdma16(rsrc, (unsigned)lane * 16u, (int)((unsigned)r * tok_bytes + (unsigned)((a + 1) * C * 4 + g * 1024)), slot_base + (unsigned)(i * RS));
     }
   };
-
-  int issued = 0, i_slot = 0;
+  // this lane's part of Q of unit k: row rowc, per head and k-step the 8 channels 16 ks + 8 hb + [0, 8)
+  auto load_q = [&](int k, f32x4 (&q)[QL]) {
+    long long tb;
+    int g;
+    unit_coords(k, tb, g);
+    const float* row = qkv + (tb + (long long)rowc * tok_stride) * (3 * C) + g * 256 + wave * 64 + hb * 8;
 #pragma unroll
-  for (int q = 0; q < NS - 1; ++q)
-    if (issued < nmine) {
-      issue(issued, i_slot);
-      ++issued;
-      i_slot = i_slot + 1 == NS ? 0 : i_slot + 1;
+    for (int i = 0; i < QL / 2; ++i) {  // i = head-in-wave * KSTEPS + ks: consecutive 16-channel groups of the wave's 64 floats
+      q[2 * i] = *reinterpret_cast<const f32x4*>(row + i * 16);
+      q[2 * i + 1] = *reinterpret_cast<const f32x4*>(row + i * 16 + 4);
     }
+  };
 
   // hd^-0.5 * log2(e): scores in log2 units, softmax on the hardware 2^x
   constexpr float scale = (HD == 32 ? 0.17677669529663688110f : 0.125f) * 1.44269504088896340736f;
   constexpr float two_m11 = 0.00048828125f;
-  const int rowc = min(l31, N - 1);  // this lane's key row (A operand of K Q^T) and query row (B operand), clamped into the sequence
   bool bad = false;
+  f32x4 qraw[QL];
+  if (nmine > 0) {
+    load_q(0, qraw);
+    issue(0, 0);
+  }
   int slot = 0;
   for (int it = 0; it < nmine; ++it) {
-    // unit `it` has landed when nothing older than the (NS - 2) younger units' DMAs and the last (NS - 1) units' stores is
-    // outstanding; in the first iterations and in the tail fewer operations follow it, so wait for everything
-    if (issued - it - 1 == NS - 2 && it >= NS - 1) wait_vm<(NS - 2) * DPW + (NS - 1) * ST>();
+    // the DMAs of unit `it` were followed by the stores of unit it - 1 only (the Q loads of `it` went out before them)
+    if (it > 0) wait_vm<ST>();
     else wait_vm<0>();
-    __syncthreads();
-    if (issued < nmine) {
-      issue(issued, i_slot);
-      ++issued;
-      i_slot = i_slot + 1 == NS ? 0 : i_slot + 1;
+    __syncthreads();  // every wave's rows of unit `it` are in LDS; every wave is done with the other slot
+    f16x8 qh[QL / 2], ql[QL / 2];
+#pragma unroll
+    for (int i = 0; i < QL / 2; ++i) split8(qraw[2 * i], qraw[2 * i + 1], qh[i], ql[i]);
+    if (it + 1 < nmine) {
+      load_q(it + 1, qraw);
+      issue(it + 1, slot ^ 1);
     }
     unsigned char* const U = smem + slot * UNIT;
+    {
+      // this wave's 256-byte strip of every K and V row, fp32 -> planes in place; every read is issued before the first value is
+      // used; the rows past 2 N - 1 of the last instruction are clamped (their lanes write the same bytes a second time)
+      constexpr int NI = (2 * N + 3) / 4;
+      unsigned char* grp[NI];
+      f32x4 x[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        grp[i] = U + min(4 * i + (lane >> 4), 2 * N - 1) * RS + wave * 256 + ((lane & 15) >> 2) * 64;
+        x[i] = *reinterpret_cast<const f32x4*>(grp[i] + (lane & 3) * 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        f16x4 xh, xl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[e] = (_Float16)x[i][e];
+          xl[e] = (_Float16)((x[i][e] - (float)xh[e]) * 2048.0f);
+        }
+        *reinterpret_cast<f16x4*>(grp[i] + (lane & 3) * 8) = xh;
+        *reinterpret_cast<f16x4*>(grp[i] + 32 + (lane & 3) * 8) = xl;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int h = 0; h < HPW; ++h) {
       const int hoff = (wave * HPW + h) * (HD * 4);  // this head's bytes inside a row of the unit
+      // Every LDS read of the head - the K fragments and the gathered V^T fragments - is issued here, ahead of the dependent
+      // chain (scores -> softmax -> P V).
+      const unsigned char* pk = U + rowc * RS + hoff + hb * 16;
+      f16x8 kh[Cfg::KSTEPS], kl[Cfg::KSTEPS];
+#pragma unroll
+      for (int ks = 0; ks < Cfg::KSTEPS; ++ks) {
+        kh[ks] = *reinterpret_cast<const f16x8*>(pk + ks * 64);
+        kl[ks] = *reinterpret_cast<const f16x8*>(pk + ks * 64 + 32);
+      }
+      f16x8 vh[Cfg::DBLK][Cfg::PSTEPS], vl[Cfg::DBLK][Cfg::PSTEPS];
+#pragma unroll
+      for (int blk = 0; blk < Cfg::DBLK; ++blk) {
+        // f16 index of channel 32 blk + l31 inside the row's planes: group (2 blk + (l31 >> 4)) of 32 halves, hi at (l31 & 15), lo 16 further
+        const _Float16* pv = reinterpret_cast<const _Float16*>(U + N * RS + hoff) + (2 * blk + (l31 >> 4)) * 32 + (l31 & 15);
+#pragma unroll
+        for (int s = 0; s < Cfg::PSTEPS; ++s) {
+          // keys 16.. exist only up to N - 1 (and only in the hb = 0 half): the other slots carry p = 0 and may hold any finite v
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int key = 16 * s + (e & 3) + 8 * (e >> 2);  // + 4 hb
+            if (s == 0 || key < N) {
+              const _Float16* pr = pv + (size_t)min(key + 4 * hb, N - 1) * (RS / 2);
+              vh[blk][s][e] = pr[0];
+              vl[blk][s][e] = pr[16];
+            } else {
+              vh[blk][s][e] = vh[blk][s][0];
+              vl[blk][s][e] = vl[blk][s][0];
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
       // ---- S^T = K Q^T ----
       f32x16 s_main, s_cross;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s_main[r] = s_cross[r] = 0.f;
-      const unsigned char* pq = U + (0 * N + rowc) * RS + hoff + hb * 16;
-      const unsigned char* pk = U + (1 * N + rowc) * RS + hoff + hb * 16;
 #pragma unroll
       for (int ks = 0; ks < Cfg::KSTEPS; ++ks) {
-        const f16x8 kh = *reinterpret_cast<const f16x8*>(pk + ks * 64), kl = *reinterpret_cast<const f16x8*>(pk + ks * 64 + 32);
-        const f16x8 qh = *reinterpret_cast<const f16x8*>(pq + ks * 64), ql = *reinterpret_cast<const f16x8*>(pq + ks * 64 + 32);
-        s_main = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh, s_main, 0, 0, 0);
-        s_cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql, s_cross, 0, 0, 0);
-        s_cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh, s_cross, 0, 0, 0);
+        s_main = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[ks], qh[h * Cfg::KSTEPS + ks], s_main, 0, 0, 0);
+        s_cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[ks], ql[h * Cfg::KSTEPS + ks], s_cross, 0, 0, 0);
+        s_cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[ks], qh[h * Cfg::KSTEPS + ks], s_cross, 0, 0, 0);
       }
       // ---- softmax over the keys of this lane's query: register r is key 4 hb + (r & 3) + 8 (r >> 2) ----
       float p[16];
@@ -150,37 +225,21 @@ __global__ __launch_bounds__(256, 1) void seq_attention_mfma_kernel(const float*
         f32x16 o_main, o_cross;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o_main[r] = o_cross[r] = 0.f;
-        // f16 index of channel 32 blk + l31 inside the row's planes: group (2 blk + (l31 >> 4)) of 32 halves, hi at (l31 & 15), lo 16 further
-        const _Float16* pv = reinterpret_cast<const _Float16*>(U + 2 * N * RS + hoff) + (2 * blk + (l31 >> 4)) * 32 + (l31 & 15);
 #pragma unroll
         for (int s = 0; s < Cfg::PSTEPS; ++s) {
-          f16x8 ph, pl, vh, vl;
+          f16x8 ph, pl;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float pv32 = pinned(p[8 * s + e]);
             ph[e] = (_Float16)pv32;
             pl[e] = (_Float16)((pv32 - (float)ph[e]) * 2048.0f);
           }
-          // keys 16.. exist only up to N - 1 (and only in the hb = 0 half): the other slots carry p = 0 and may hold any finite v
-          constexpr int NE = 8;
-#pragma unroll
-          for (int e = 0; e < NE; ++e) {
-            const int key = 16 * s + (e & 3) + 8 * (e >> 2);  // + 4 hb
-            if (s == 0 || key < N) {
-              const _Float16* pr = pv + (size_t)min(key + 4 * hb, N - 1) * (RS / 2);
-              vh[e] = pr[0];
-              vl[e] = pr[16];
-            } else {
-              vh[e] = vh[0];
-              vl[e] = vl[0];
-            }
-          }
-          o_main = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o_main, 0, 0, 0);
-          o_cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o_cross, 0, 0, 0);
-          o_cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o_cross, 0, 0, 0);
+          o_main = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[blk][s], ph, o_main, 0, 0, 0);
+          o_cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[blk][s], pl, o_cross, 0, 0, 0);
+          o_cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[blk][s], ph, o_cross, 0, 0, 0);
         }
         // register r is channel 32 blk + 4 hb + (r & 3) + 8 (r >> 2) of query l31: four consecutive channels per r >> 2, written
-        // pre-split into this head's bytes of the (dead) Q row
+        // pre-split into this head's bytes of the (dead) K row of that query
         if (l31 < N) {
           unsigned char* po = U + l31 * RS + hoff;
 #pragma unroll
@@ -217,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void seq_attention_mfma_kernel(const float*
         }
       }
     }
-    slot = slot + 1 == NS ? 0 : slot + 1;
+    slot ^= 1;
   }
   report_nonfinite(oflow, bad);
 }
@@ -228,7 +287,7 @@ int launch(const float* qkv, float* out, int nseq, int seq_div, long long seq_lo
   static std::atomic<unsigned long long> done{0};
   PMCE_TRY(pmce_opt_in_lds(reinterpret_cast<const void*>(&seq_attention_mfma_kernel<HD, N>), Cfg::LDS_BYTES, done, "seq_attention_split_f16"));
   const int units = nseq * Cfg::UPS;
-  const int grid = units < 256 ? units : 256;
+  const int grid = units < 512 ? units : 512;
   hipLaunchKernelGGL((seq_attention_mfma_kernel<HD, N>), dim3(grid), dim3(256), Cfg::LDS_BYTES, stream, qkv, out, nseq, seq_div, seq_lo, seq_hi,
                      tok_stride, pmce_overflow_sink());
   return pmce_check_launch("seq_attention_split_f16");

@@ -90,13 +90,12 @@ def seq_attention(qkv, nseq, N, Cc, seq_div, seq_lo, seq_hi, tok_stride, out_spl
     return out
 
 
-def seq_attention_split(qkv_planes, nseq, N, Cc, seq_div, seq_lo, seq_hi, tok_stride):
-    """The matrix-pipe attention of the split-f16 mode: pre-split q, k, v in, pre-split result out (see :func:`split_rows_f16`,
-    :func:`unsplit_rows_f16`)."""
+def seq_attention_split(qkv, nseq, N, Cc, seq_div, seq_lo, seq_hi, tok_stride):
+    """The matrix-pipe attention of the split-f16 mode: fp32 q, k, v in, pre-split result out (see :func:`unsplit_rows_f16`)."""
     lib = _lib.load()
-    qkv_planes = _c(qkv_planes)
-    out = torch.empty(qkv_planes.shape[0], Cc, device=qkv_planes.device, dtype=torch.float32)
-    _lib.check(lib.pmce_seq_attention_split_f16(P(qkv_planes), P(out), nseq, N, Cc, seq_div, seq_lo, seq_hi, tok_stride, _st()),
+    qkv = _c(qkv)
+    out = torch.empty(qkv.shape[0], Cc, device=qkv.device, dtype=torch.float32)
+    _lib.check(lib.pmce_seq_attention_split_f16(P(qkv), P(out), nseq, N, Cc, seq_div, seq_lo, seq_hi, tok_stride, _st()),
                "seq_attention_split_f16")
     return out
 

@@ -29,7 +29,6 @@ for C in (512, 256):
     M = B * T * J
     g = torch.Generator(device="cpu").manual_seed(5)
     qkvs = [torch.randn(M, 3 * C, generator=g).to(dev) for _ in range(3)]     # rotate buffers: 3 x 428 MB > the 256 MB cache
-    planes = [ops.split_rows_f16(q) for q in qkvs]
     mbytes = M * 4 * C * 4 / 1e6
     for name, args in (("spatial ", (B * T, J, C, 0, J, 0, 1)), ("temporal", (B * J, T, C, J, 1, T * J, J))):
         i = [0]
@@ -40,7 +39,7 @@ for C in (512, 256):
 
         def mat():
             i[0] += 1
-            ops.seq_attention_split(planes[i[0] % 3], *args)
+            ops.seq_attention_split(qkvs[i[0] % 3], *args)
 
         tv, tm = timeit(vec), timeit(mat)
         print(f"C={C} B={B} {name}: vector pipe {tv:7.1f} us ({mbytes / tv:5.2f} TB/s)   matrix pipe {tm:7.1f} us ({mbytes / tm:5.2f} TB/s)   [{mbytes:.0f} MB per launch]", flush=True)

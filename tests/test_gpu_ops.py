@@ -290,8 +290,8 @@ def test_seq_attention(C, J):
 
 @pytest.mark.parametrize("C,J,B", [(512, 17, 2), (256, 17, 2), (512, 19, 1), (256, 19, 3), (512, 17, 37)])
 def test_seq_attention_split_f16(C, J, B):
-    """The matrix-pipe attention of the split-f16 mode (pre-split q, k, v in, pre-split result out) against the fp64 attention of
-    the SAME operands (what the planes stand for), next to the vector-pipe kernel's error on them; spatial and temporal layout;
+    """The matrix-pipe attention of the split-f16 mode (fp32 q, k, v in, pre-split result out) against the fp64 attention of
+    the operands it computes with (the 22-bit planes of q, k, v), next to the vector-pipe kernel's error on them; spatial and temporal layout;
     larger scores than a model produces (|q.k| up to ~40) so that the softmax is peaked; bitwise repeatable."""
     from pmce_amd import ops
     Tn, H = 16, 8
@@ -313,13 +313,13 @@ def test_seq_attention_split_f16(C, J, B):
 
     for name, args in (("spatial", (B * Tn, J, C, 0, J, 0, 1)), ("temporal", (B * J, Tn, C, J, 1, Tn * J, J))):
         want = ref(name[0])
-        got_p = ops.seq_attention_split(planes, *args)
+        got_p = ops.seq_attention_split(qkv, *args)
         got = ops.unsplit_rows_f16(got_p)
         vec = ops.seq_attention(exact.float(), *args)                              # the vector-pipe kernel on the same values
         e, ev = (got - want).abs().max().item(), (vec.double() - want).abs().max().item()
         print(f"seq_attention_split_f16 C={C} J={J} B={B} {name}: {e:.2e} (vector-pipe kernel {ev:.2e}), |out| max {want.abs().max().item():.2f}")
         assert e < 5e-6
-        again = ops.seq_attention_split(planes, *args)
+        again = ops.seq_attention_split(qkv, *args)
         assert torch.equal(again.view(torch.int32), got_p.view(torch.int32))
 
 
