@@ -189,13 +189,59 @@ def north_star_record(kernel_ms, launches, B, J, f16_ffn=False):
     cyc_per_tile = (64 + 16 * ((J + 7) // 8)) * 64 + ffn_cycles
     t_hbm = byt / (PEAK_HBM_GBS * 1e9) * 1e3
     t_mfma = tiles * cyc_per_tile / N_SIMD / (CLOCK_GHZ * 1e9) * 1e3
-    floor = max(t_hbm, t_mfma)
+    # vector-pipe floor: the kernel's measured vector instruction count (SQ_INSTS_VALU of the committed PMC pass, per clip), 4
+    # cycles each, spread perfectly over the SIMDs - the AdaLN, softmax, exact-erf GELU and operand splitting the kernel cannot
+    # avoid in its present form.  A wave issues vector and matrix instructions one after the other, and at 1.75 waves per SIMD
+    # little overlaps them: `serial_floor_ms` = matrix + vector time is the realistic floor, max(...) the optimistic one.
+    t_valu = None
+    pmc = _pmc_counters()
+    key = "void vertex_ca_mlp_kernel<true>" if f16_ffn else "void vertex_ca_mlp_kernel<false>"
+    if name == "vertex_ca_mlp" and pmc and key in pmc and pmc[key].get("SQ_INSTS_VALU") and pmc[key].get("SQ_WAVES"):
+        per_clip = pmc[key]["SQ_INSTS_VALU"] / (pmc[key]["SQ_WAVES"] / 7.0)      # 7 waves per clip (14 wave tiles, 2 per wave)
+        t_valu = per_clip * B * 4 / N_SIMD / (CLOCK_GHZ * 1e9) * 1e3
+    floor = max(t_hbm, t_mfma, t_valu or 0.0)
     ach = byt / (ms * 1e-3) / 1e9
-    return {"kernel": name, "bound": "hbm" if t_hbm >= t_mfma else "mfma", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
-            "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "bytes_per_clip_dir_block": 229376,
-            "avg_launch_ms": round(ms, 5), "hbm_floor_ms": round(t_hbm, 5), "mfma_floor_ms": round(t_mfma, 5),
-            "frac_of_floor": round(floor / ms, 4),
-            "ffn_arithmetic": "3 x f16 MFMA per fp32 product" if (f16_ffn and name == "vertex_ca_mlp") else "fp32 MFMA"}
+    rec = {"kernel": name, "bound": "hbm" if t_hbm >= max(t_mfma, t_valu or 0.0) else ("mfma" if t_mfma >= (t_valu or 0.0) else "valu"),
+           "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
+           "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "bytes_per_clip_dir_block": 229376,
+           "avg_launch_ms": round(ms, 5), "hbm_floor_ms": round(t_hbm, 5), "mfma_floor_ms": round(t_mfma, 5),
+           "frac_of_floor": round(floor / ms, 4),
+           "ffn_arithmetic": "3 x f16 MFMA per fp32 product" if (f16_ffn and name == "vertex_ca_mlp") else "fp32 MFMA"}
+    if t_valu is not None:
+        rec.update({"valu_floor_ms": round(t_valu, 5), "serial_floor_ms": round(t_mfma + t_valu, 5),
+                    "frac_of_serial_floor": round((t_mfma + t_valu) / ms, 4),
+                    "valu_source": "profiles/pmc_counters_per_kernel.json (SQ_INSTS_VALU per launch at B = 256, scaled per clip)"})
+    return rec
+
+
+_PMC_COUNTERS = None
+
+
+def _pmc_counters():
+    global _PMC_COUNTERS
+    if _PMC_COUNTERS is None:
+        fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_counters_per_kernel.json")
+        try:
+            _PMC_COUNTERS = json.load(open(fn))
+        except (OSError, ValueError):
+            _PMC_COUNTERS = {}
+    return _PMC_COUNTERS
+
+
+def attention_record(kernel_ms, launches, B, J, C, split):
+    """The lifter's attention - the HBM-bound kernel of the path - against the HBM roofline: it reads q, k, v (3C floats per
+    token) and writes C floats per token, once each; `traffic` is what the PMC pass counted per launch."""
+    if "seq_attention" not in kernel_ms or not launches.get("seq_attention"):
+        return None
+    ms = kernel_ms["seq_attention"] / launches["seq_attention"]
+    byt = B * 16 * J * 4 * C * 4.0
+    ach = byt / (ms * 1e-3) / 1e9
+    kern = "seq_attention_mfma_kernel" if split else ("seq_attention_pair_kernel" if C == 512 else "seq_attention_kernel")
+    tr, src = pmc_traffic_per_launch(kern, C)
+    return {"kernel": kern, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(ach / PEAK_HBM_GBS, 4), "frac_of_achievable_6300": round(ach / 6300.0, 4), "avg_launch_ms": round(ms, 5),
+            "launches_per_step": launches["seq_attention"], "algorithmic_bytes_per_launch": int(byt), "traffic": tr,
+            "traffic_source": src}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -354,6 +400,7 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
             roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(ach / PEAK_HBM_GBS, 4), **common}
     rec.update({"roofline": roofline, "roofline_cross_attention": north_star_record(kernel_ms, launches, B, J, f16_ffn=(gemm_mode == "split_f16")),
+                "roofline_attention": attention_record(kernel_ms, launches, B, J, C, gemm_mode == "split_f16" and J in (17, 19)),
                 "kernel_ms_per_step": kernel_ms, "launches_per_step": launches,
                 "kernel_ms_total_single_stream": round(sum(kernel_ms.values()), 4), "gemm_mode": gemm_mode})
     return rec, model, pipe, inputs, sd
@@ -517,7 +564,7 @@ def main():
     # C = 256), and a child that runs while its parent holds a HIP context sees ~6 % slower kernels in its profiling pass.
     variant = variant_f32 = None
     C, B, J = args.embed_dim, args.batch, args.joints
-    keep = ("value", "unit", "ms_per_step", "windows", "config", "roofline", "roofline_cross_attention", "cpu_baseline",
+    keep = ("value", "unit", "ms_per_step", "windows", "config", "roofline", "roofline_cross_attention", "roofline_attention", "cpu_baseline",
             "kernel_ms_per_step", "launches_per_step", "kernel_ms_total_single_stream", "ref_equiv_tflops", "outputs_finite")
 
     def child_record(extra, cpu_ok):
@@ -604,6 +651,7 @@ def main():
                       if head.get("gemm_mode") == "split_f16" else "f32"),
             "data": "synthetic",
             "config": head["config"], "roofline": head["roofline"], "roofline_cross_attention": head["roofline_cross_attention"],
+            "roofline_attention": head.get("roofline_attention"),
             "cpu_baseline": cpu, "windows": head["windows"], "host_fed": host_fed, "latency": latency,
             f"variant_c{256 if C == 512 else 512}": variant, "variant_f32_pipe": variant_f32,
             "kernel_ms_per_step": head["kernel_ms_per_step"], "launches_per_step": head["launches_per_step"],

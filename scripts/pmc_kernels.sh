@@ -15,7 +15,7 @@ pat = re.compile(os.environ["PAT"])
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob("gpurun_out/kpmc/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        name = row["Kernel_Name"].split("(")[0]
+        name = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
         if not pat.search(name): continue
         a = agg[name[:70]][row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
 import json

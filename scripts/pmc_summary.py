@@ -14,7 +14,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") != c:
                 continue
-            name = row["Kernel_Name"].split("(")[0][:60]
+            name = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:60]
             agg[name][0] += float(row["Counter_Value"])
             agg[name][1] += 1
     out[c] = {k: (v[0] / v[1], v[1]) for k, v in agg.items()}

@@ -9,6 +9,7 @@ def rec(tag, d):
     print(f"[{tag}] {d['value']} clips/s  {d['ms_per_step']} ms/step  windows {d.get('windows', {}).get('ms_per_step')}")
     print("   roofline:", {k: v for k, v in (d.get("roofline") or {}).items() if k not in ("classes", "traffic_source")})
     print("   north-star:", d.get("roofline_cross_attention"))
+    print("   attention :", d.get("roofline_attention"))
     print("   kernels (ms/step):", {k: v for k, v in (d.get("kernel_ms_per_step") or {}).items() if v > 0.04},
           "sum", d.get("kernel_ms_total_single_stream"))
     print("   cpu:", d.get("cpu_baseline"))
