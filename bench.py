@@ -504,6 +504,8 @@ def cpu_baseline_record(sd, vj_relation, J, C, seconds):
             cal[nt] = round(rate, 1)
             if rate > best_rate:
                 best_t, best_rate = nt, rate
+            elif rate < 0.6 * best_rate:     # past the knee: more threads only oversubscribe (256 threads: 0.3 clips/s, minutes per forward)
+                break
         torch.set_num_threads(best_t)
         n, t_cpu = 0, 0.0
         while t_cpu < seconds and n < 50:
@@ -521,7 +523,7 @@ def cpu_baseline_record(sd, vj_relation, J, C, seconds):
             "batch1_latency_ms": round(statistics.median(lat), 2),
             "threads_calibration_clips_s": cal,
             "sample": f"{n} x batch-{cb} full forwards of oracle/pmce_oracle.py (torch CPU fp32, J={J}, C={C}), thread count "
-                      f"calibrated over 8..256 on batch-{cb} forwards (the batch that is timed); batch1_latency_ms = median of 5 "
+                      f"calibrated over 8, 16, 32, ... on batch-{cb} forwards (the batch that is timed) until the rate falls below 0.6 of the best; batch1_latency_ms = median of 5 "
                       f"single-clip forwards"}
 
 
