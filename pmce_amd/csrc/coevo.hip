@@ -730,7 +730,7 @@ __global__ __launch_bounds__(256) void adaln_qkv_kernel(const float* __restrict_
                                                         int gb_stride, int inst, const float* __restrict__ Wqkv,
                                                         const float* __restrict__ bqkv, float* __restrict__ qkv, int B) {
   __shared__ __attribute__((aligned(16))) float sW[192 * LDW64];
-  __shared__ __attribute__((aligned(16))) float sT[4 * 32 * 36];  // per-wave output transpose tile
+  __shared__ __attribute__((aligned(16))) float sT[4 * 32 * 32];  // per-wave output transpose tile: [token][8 chunks of 4 channels], chunk ^ (token & 7)
   __shared__ float sB[192];
   const int tid = threadIdx.x;
   stage_weight<64>(sW, Wqkv, 192, tid, 256);
@@ -758,7 +758,10 @@ __global__ __launch_bounds__(256) void adaln_qkv_kernel(const float* __restrict_
     // and 32-channel group) instead of 32 bytes in each of 32 rows: the accumulator layout's direct stores cost 24 of this
     // kernel's 59 us.  The 192 output channels are produced in two halves of three 32-channel tiles (48 instead of 96
     // accumulator registers: room for the prefetched tile without spilling).
-    float* tb = sT + wave * (32 * 36);
+    // (rows of 128 B with the 16-byte chunk XOR-ed by the row: the 8 consecutive lanes of a ds_write_b128 service group - 8 tokens,
+    // one chunk - hit 8 different bank quads, and the four non-contiguous 16-lane groups of the ds_read_b128 - 4 rows, half a row each -
+    // cover the 256-byte bank row exactly once; the padded 36-float rows this replaces cost 331,776 conflict cycles per launch)
+    float* tb = sT + wave * (32 * 32);
     const long long tok0 = (long long)b * NV + tile * 32;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -777,12 +780,12 @@ __global__ __launch_bounds__(256) void adaln_qkv_kernel(const float* __restrict_
           t.y = acc[nt][4 * g + 1];
           t.z = acc[nt][4 * g + 2];
           t.w = acc[nt][4 * g + 3];
-          *reinterpret_cast<f32x4*>(tb + n0 * 36 + 8 * g + 4 * hb) = t;
+          *reinterpret_cast<f32x4*>(tb + n0 * 32 + 4 * ((2 * g + hb) ^ (n0 & 7))) = t;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int tk = 8 * i + (lane >> 3);
-          const f32x4 t = *reinterpret_cast<const f32x4*>(tb + tk * 36 + 4 * (lane & 7));
+          const f32x4 t = *reinterpret_cast<const f32x4*>(tb + tk * 32 + 4 * ((lane & 7) ^ (tk & 7)));
           if (tile * 32 + tk < NV)
             *reinterpret_cast<f32x4*>(qkv + (tok0 + tk) * 192 + (3 * half + nt) * 32 + 4 * (lane & 7)) = t;
         }

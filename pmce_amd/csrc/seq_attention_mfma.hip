@@ -148,8 +148,12 @@ __global__ __launch_bounds__(256, 2) void seq_attention_mfma_kernel(const float*
           xh[e] = (_Float16)x[i][e];
           xl[e] = (_Float16)((x[i][e] - (float)xh[e]) * 2048.0f);
         }
-        *reinterpret_cast<f16x4*>(grp[i] + (lane & 3) * 8) = xh;
-        *reinterpret_cast<f16x4*>(grp[i] + 32 + (lane & 3) * 8) = xl;
+        // 16 consecutive lanes (a ds_write_b64 service group) hold one row's four groups: groups 0, 1 write hi first and groups 2, 3
+        // lo first, so that the 16 eight-byte stores of an instruction fall on 16 different bank pairs (hi and lo areas of groups g
+        // and g + 2 are 128 B apart - the same banks for a store)
+        const bool lo_first = (lane & 8) != 0;
+        *reinterpret_cast<f16x4*>(grp[i] + (lo_first ? 32 : 0) + (lane & 3) * 8) = lo_first ? xl : xh;
+        *reinterpret_cast<f16x4*>(grp[i] + (lo_first ? 0 : 32) + (lane & 3) * 8) = lo_first ? xh : xl;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

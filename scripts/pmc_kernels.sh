@@ -3,10 +3,13 @@
 set -u
 pat=${1:-vertex_ca}
 export TMPDIR=/tmp
+rm -rf gpurun_out/kpmc
 mkdir -p gpurun_out/kpmc
 i=0
+# PMCE_PMC_ONLY=3 runs only the third group (LDS counters)
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM"; do
   i=$((i+1))
+  if [[ -n "${PMCE_PMC_ONLY:-}" && "$i" != "$PMCE_PMC_ONLY" ]]; then continue; fi
   (cd /tmp && timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OLDPWD/gpurun_out/kpmc/g$i -o pmc -- python $OLDPWD/bench.py --embed-dim ${PMCE_PMC_C:-512} --steps 1 --warmup 1 --windows 1 --no-cpu-baseline --no-latency --no-host-fed --no-variant --single-stream > $OLDPWD/gpurun_out/kpmc/g$i.log 2>&1)
 done
 PAT="$pat" python - <<'PY'
