@@ -73,6 +73,10 @@ def test_argument_validation_without_gpu(lib):
     assert rc == -1 and "K%32" in _lib.last_error()
     rc = lib.pmce_seq_attention_f32(1, 1, 4, 40, 256, 0, 1, 0, 1, None)
     assert rc == -1 and "1..32" in _lib.last_error()
+    assert lib.pmce_seq_attention_split_supported(17, 512) == 1 and lib.pmce_seq_attention_split_supported(16, 256) == 1
+    assert lib.pmce_seq_attention_split_supported(24, 512) == 0 and lib.pmce_seq_attention_split_supported(17, 384) == 0
+    rc = lib.pmce_seq_attention_split_f16(16, 16, 4, 24, 512, 0, 24, 0, 1, None)
+    assert rc == -1 and "16, 17 or 19" in _lib.last_error()
     import ctypes as C
     h = C.c_void_p()
     assert lib.pmce_model_create(17, 300, 3, C.byref(h)) == -1
