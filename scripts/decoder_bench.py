@@ -36,17 +36,14 @@ def main():
         dec(joints, feats)
     torch.cuda.synchronize()
     prof = eng.profile_read(); eng.profile(False); eng.set_concurrency(True)
-    # the north-star kernel: since round 2 the whole CrossAttentionBlock (cross-attention + FFN) is one launch
-    kname = "vertex_ca_mlp" if prof.get("vertex_ca_mlp", (0, 0))[1] > 0 else "vertex_ca"
-    ca_ms = prof[kname][0] / prof[kname][1]
-    mfma_per_tile = 64 + 16 * ((J + 7) // 8) + (512 if kname == "vertex_ca_mlp" else 0)
-    mfma_floor_ms = B * 14 * mfma_per_tile * 64 / 1024 / 2.4e9 * 1e3
-    hbm_floor_ms = 229376.0 * B / 8e12 * 1e3
+    # the north-star kernel against its floors: bench.py's model of it (HBM bytes, matrix instructions of the product mode in use,
+    # vector-pipe floor from the committed PMC instruction count)
+    import bench
+    kernel_ms = {k: v[0] / 3 for k, v in prof.items() if v[1] > 0}
+    launches = {k: v[1] // 3 for k, v in prof.items() if v[1] > 0}
     out = {"config": f"CoEvoDecoder-only forward, batch={B}, J=17", "clips_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4),
-           "cross_attention": {"kernel": kname, "avg_launch_ms": round(ca_ms, 5), "bytes_per_clip_dir_block": 229376,
-                               "achieved_GBps": round(229376 * B / (ca_ms * 1e-3) / 1e9, 1), "peak_GBps": 8000,
-                               "mfma_floor_ms": round(mfma_floor_ms, 5), "hbm_floor_ms": round(hbm_floor_ms, 5),
-                               "frac_of_floor": round(max(mfma_floor_ms, hbm_floor_ms) / ca_ms, 4)},
+           "gemm_mode": eng.gemm_mode(),
+           "cross_attention": bench.north_star_record(kernel_ms, launches, B, J, f16_ffn=(eng.gemm_mode() == "split_f16")),
            "kernel_ms_per_step": {k: round(v[0] / 3, 4) for k, v in prof.items() if v[1] > 0 and v[0] / 3 > 0.01},
            "outputs_finite": bool(torch.isfinite(mesh).all().item() and torch.isfinite(pose).all().item())}
     print(json.dumps(out))
