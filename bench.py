@@ -35,6 +35,9 @@ PEAK_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 MFMA 
 PEAK_F16_TFLOPS = 2500.0    # same guide: dense f16/bf16 MFMA peak (v_mfma_f32_32x32x16_f16)
 PEAK_HBM_GBS = 8000.0       # HBM3E peak (same guide; ~6.3 TB/s is what a streaming copy reaches)
 CLOCK_GHZ = 2.4
+# what v_mfma_f32_32x32x16_f16 sustains from REGISTER operands holding random f16 bit patterns, pipe 98-100 % occupied, at the
+# 1.42-1.54 GHz the chip then holds (scripts/microbench/mfma_peak.hip, profiles/r03_d_mfma_peak_register_operands.txt; zeros: 2,357)
+MEASURED_F16_CEILING_TFLOPS = 1582.0
 N_SIMD = 1024               # 256 CUs x 4 SIMDs; one v_mfma_f32_32x32x2_f32 occupies a SIMD's matrix pipe for 64 cycles
 
 
@@ -381,6 +384,8 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
             roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_F16_TFLOPS, 4), **common,
                         "arithmetic": "3 x v_mfma_f32_32x32x16_f16 per fp32 product (hi*hi + hi*lo + lo*hi), fp32 accumulate",
+                        "measured_pipe_ceiling_tflops": MEASURED_F16_CEILING_TFLOPS,
+                        "frac_of_measured_pipe_ceiling": round(ach / MEASURED_F16_CEILING_TFLOPS, 4),
                         "note": "achieved / frac count the f16 FLOPs the kernel ISSUES (3 x 2MNK); frac_algorithmic_2mnk is the same time "
                                 "against the algorithmic 2MNK of the fp32 products",
                         "fp32_equiv_tflops": round(work / secs / 1e12, 1),
