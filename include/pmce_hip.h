@@ -211,6 +211,9 @@ int pmce_split_rows_f16(const float* A, long long M, int K, long long lda, float
 int pmce_gemm_split_set_tuning(int tile);
 /* Tuning aid only: 0 keeps the automatic choice away from the wave-specialised kernel (PMCE_SPLIT_WS=0 at load does the same). */
 int pmce_gemm_split_set_ws(int on);
+/* Tuning aid (process-wide; env PMCE_SPLIT_M16 at load): the products with a pre-split A on v_mfma_f32_16x16x32_f16 instead of
+ * 32x32x16 (csrc/gemm_split_m16.hip) - the same three-product arithmetic, a different summation order inside a k-tile. */
+int pmce_gemm_split_set_m16(int on);
 /* Number of wavefronts of the wave-specialised kernel that gave up waiting on an in-kernel hand-off since the library was
  * loaded: 0 in a healthy process (every spin is bounded instead of hanging the device).  Synchronises the device. */
 int pmce_gemm_ws_timeouts(void);

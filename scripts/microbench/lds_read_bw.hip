@@ -87,6 +87,73 @@ __global__ __launch_bounds__(256 * WAVES_PER_SIMD) void pipelined_kernel(float* 
     atomicAdd(&clk[1], (unsigned long long)(wall_clock64() - w0));
   }
 }
+// The same loop with the other full-rate f16 shape, v_mfma_f32_16x16x32_f16: the same 12 fragment reads, 48 instructions of 16 cycles
+// instead of 24 of 32 (32 accumulator tiles of 4 registers).  mfma_peak.hip: from registers, on random data, this shape sustains
+// 1.76 PFLOP/s at 1.72 GHz where 32x32x16 sustains 1.53 at 1.48.
+template <int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256 * WAVES_PER_SIMD) void pipelined16_kernel(float* __restrict__ sink, unsigned long long* clk, int iters) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 32 * 1024; i += blockDim.x) lds[i] = (float)(i & 1023) * 0.001f;
+  __syncthreads();
+  const long long c0 = clock64(), w0 = wall_clock64();
+  const int n0 = lane & 31, hb = lane >> 5, swz = (n0 >> 2) & 3;
+  const int wbase = (wave & 3) * 1024;
+  f32x4 acc[32];
+  for (int a = 0; a < 32; ++a) for (int r = 0; r < 4; ++r) acc[a][r] = 0.f;
+  auto rd = [&](int it, f16x8 (&f)[12]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const int off = n0 * 16 + 4 * ((2 * ((j >> 2) & 1) + hb) ^ swz) + (j & 3) * 512 + (j >> 3) * 2048;
+      f[j] = *reinterpret_cast<const f16x8*>(lds + ((wbase + off + (it & 7) * 4096) & (32 * 1024 - 1)));
+    }
+  };
+  auto mm = [&](f16x8 (&f)[12]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < 48; ++m) acc[m & 31] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[m % 12], f[(m + 5) % 12], acc[m & 31], 0, 0, 0);
+  };
+  f16x8 fa[12], fb[12];
+  rd(0, fa);
+  for (int it = 0; it < iters; it += 2) {
+    rd(it + 1, fb);
+    mm(fa);
+    rd(it + 2, fa);
+    mm(fb);
+  }
+  float k = 0.f;
+  for (int a = 0; a < 32; ++a) k += acc[a][0];
+  if (k == 123.456f) sink[tid] = k;
+  if (tid == 0) {
+    atomicAdd(&clk[0], (unsigned long long)(clock64() - c0));
+    atomicAdd(&clk[1], (unsigned long long)(wall_clock64() - w0));
+  }
+}
+template <int WAVES_PER_SIMD>
+static void run_pipelined16(float* sink) {
+  const int iters = 20000;
+  auto k = pipelined16_kernel<WAVES_PER_SIMD>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  unsigned long long* clk;
+  CK(hipMalloc(&clk, 16));
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  hipLaunchKernelGGL(k, dim3(256), dim3(256 * WAVES_PER_SIMD), 128 * 1024, 0, sink, clk, 100);
+  CK(hipDeviceSynchronize());
+  CK(hipMemset(clk, 0, 16));
+  CK(hipEventRecord(a));
+  hipLaunchKernelGGL(k, dim3(256), dim3(256 * WAVES_PER_SIMD), 128 * 1024, 0, sink, clk, iters);
+  CK(hipEventRecord(b));
+  CK(hipEventSynchronize(b));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, a, b));
+  unsigned long long h[2];
+  CK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
+  const double ghz = (double)h[0] / (double)h[1] * 0.1;
+  const double ns = ms * 1e6 / iters;
+  printf("pipelined, 16x16x32 shape, %d wave(s)/SIMD: %7.1f ns per k-tile of 48 mfma per wave = %5.1f %% of the matrix peak at 2.4 GHz; shader clock %.2f GHz -> %5.1f %% at that clock\n",
+         WAVES_PER_SIMD, ns, 100.0 * WAVES_PER_SIMD * 48 * 16 / 2.4 / ns, ghz, 100.0 * WAVES_PER_SIMD * 48 * 16 / ghz / ns);
+}
+
 template <int WAVES_PER_SIMD>
 static void run_pipelined(float* sink) {
   const int iters = 20000;
@@ -134,15 +201,18 @@ static void run(const char* what, int waves, float* sink) {
          ns_per_iter, bytes / (ms * 1e6), bytes / (ms * 1e6) / 2.4, MFMAS ? 100.0 * (waves / 4.0) * MFMAS * 32 / 2.4 / ns_per_iter : 0.0);
 }
 
-int main() {
+int main(int argc, char** argv) {
   float* sink;
   CK(hipMalloc(&sink, 1 << 20));
+  const bool only_pipelined = argc > 1;
+  if (!only_pipelined)
   for (int waves : {4, 8, 12, 16}) {
     run<0, 8, 0>("fragment pattern (swizzled)", waves, sink);
     run<0, 16, 0>("fragment pattern (swizzled)", waves, sink);
     run<1, 8, 0>("lane-linear", waves, sink);
     run<2, 8, 0>("fragment pattern, no swizzle", waves, sink);
   }
+  if (!only_pipelined)
   for (int waves : {4, 8, 12}) {
     run<0, 8, 12>("fragment pattern + matrix instructions", waves, sink);
     run<0, 12, 24>("fragment pattern + matrix instructions", waves, sink);
@@ -150,5 +220,7 @@ int main() {
   }
   run_pipelined<1>(sink);
   run_pipelined<2>(sink);
+  run_pipelined16<1>(sink);
+  run_pipelined16<2>(sink);
   return 0;
 }

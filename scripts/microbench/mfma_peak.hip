@@ -43,6 +43,37 @@ __global__ __launch_bounds__(256 * WPS) void spin(const unsigned* __restrict__ s
   if (k == 123.456f) sink[tid] = k;
 }
 
+// the other full-rate f16 shape: 16x16x32 (8,192 multiply-adds in 16 cycles; 4 accumulator registers per chain)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int WPS>
+__global__ __launch_bounds__(256 * WPS) void spin16(const unsigned* __restrict__ seed, float* __restrict__ sink, unsigned long long* clk, int iters) {
+  const int tid = threadIdx.x;
+  f16x8 a[4], b[4];
+  for (int i = 0; i < 4; ++i) {
+    unsigned w[4], v[4];
+    for (int k = 0; k < 4; ++k) {
+      w[k] = seed[(blockIdx.x * 1024 + tid) * 32 + i * 8 + k];
+      v[k] = seed[(blockIdx.x * 1024 + tid) * 32 + i * 8 + 4 + k];
+    }
+    a[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<uint4*>(w));
+    b[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<uint4*>(v));
+  }
+  f32x4 acc[16];
+  for (int j = 0; j < 16; ++j) for (int r = 0; r < 4; ++r) acc[j][r] = 0.f;
+  const long long c0 = clock64(), w0 = wall_clock64();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j & 3], b[(j >> 2) & 3], acc[j], 0, 0, 0);
+  }
+  if (tid == 0) {
+    atomicAdd(&clk[0], (unsigned long long)(clock64() - c0));
+    atomicAdd(&clk[1], (unsigned long long)(wall_clock64() - w0));
+  }
+  float k = 0.f;
+  for (int j = 0; j < 16; ++j) k += acc[j][0] + acc[j][3];
+  if (k == 123.456f) sink[tid] = k;
+}
+
 int main() {
   const int iters = 40000;
   unsigned* seed;
@@ -86,7 +117,28 @@ int main() {
       const double ghz = (double)c[0] / (double)c[1] * 0.1;
       const double flops = 2.0 * 32 * 32 * 16 * 8.0 * iters * 1024.0 * wps;   // per launch
       const double tf = flops / (ms * 1e-3) / 1e12;
-      printf("%-18s %d wave(s)/SIMD: %7.1f TFLOP/s = %.3f of 2500; shader clock %.2f GHz -> %.3f of the rate at that clock\n",
+      printf("32x32x16 %-18s %d wave(s)/SIMD: %7.1f TFLOP/s = %.3f of 2500; shader clock %.2f GHz -> %.3f of the rate at that clock\n",
+             data == 0 ? "zero operands" : data == 1 ? "constant 1.0" : "random f16", wps, tf, tf / 2500.0, ghz, tf / (2500.0 * ghz / 2.4));
+    }
+    for (int wps : {1, 2}) {
+      auto launch = [&](int n) {
+        if (wps == 1) hipLaunchKernelGGL(spin16<1>, dim3(256), dim3(256), 0, 0, seed, sink, clk, n);
+        else hipLaunchKernelGGL(spin16<2>, dim3(256), dim3(512), 0, 0, seed, sink, clk, n);
+      };
+      launch(200);
+      CK(hipDeviceSynchronize());
+      CK(hipMemset(clk, 0, 16));
+      CK(hipEventRecord(e0));
+      launch(iters);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      unsigned long long c[2];
+      CK(hipMemcpy(c, clk, 16, hipMemcpyDeviceToHost));
+      const double ghz = (double)c[0] / (double)c[1] * 0.1;
+      const double tf = 2.0 * 16 * 16 * 32 * 16.0 * iters * 1024.0 * wps / (ms * 1e-3) / 1e12;
+      printf("16x16x32 %-18s %d wave(s)/SIMD: %7.1f TFLOP/s = %.3f of 2500; shader clock %.2f GHz -> %.3f of the rate at that clock\n",
              data == 0 ? "zero operands" : data == 1 ? "constant 1.0" : "random f16", wps, tf, tf / 2500.0, ghz, tf / (2500.0 * ghz / 2.4));
     }
   }

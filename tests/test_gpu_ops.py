@@ -289,6 +289,39 @@ def test_seq_attention(C, J):
     assert torch.equal(pt.view(torch.int32), ops.split_rows_f16(out_t).view(torch.int32))
 
 
+@pytest.mark.parametrize("M,N,K,act,res,cpk", [(4352, 1536, 512, 0, False, False), (5003, 512, 512, 0, True, False), (1000, 1024, 512, 1, False, True),
+                                               (4352, 256, 1024, 0, True, False), (777, 160, 128, 1, False, False), (40000, 768, 256, 0, False, False)])
+def test_gemm_split_16x16x32_shape(M, N, K, act, res, cpk):
+    """The opt-in kernel on v_mfma_f32_16x16x32_f16 (gemm_split_m16.hip: products concatenated along the instruction's K, W rows
+    permuted into LDS so that a lane owns adjacent columns): every element against an fp64 product next to the default kernel's
+    error on the same operands; edge tiles in M and N, residual, GELU, pre-split result; bitwise repeatable."""
+    from pmce_amd import _lib, ops
+    lib = _lib.load()
+    A = rnd("gemm.A", (M, K)).to(dev())
+    W = rnd("gemm.W", (N, K), scale=K ** -0.5).to(dev())
+    b = rnd("gemm.b", (N,)).to(dev())
+    R = rnd("gemm.R", (M, N)).to(dev()) if res else None
+    Wp, ws = ops.pack_split_f16(W)
+    Ap = ops.split_rows_f16(A)
+    ref = A.double() @ W.double().t() + b.double()
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    if res:
+        ref = ref + R.double()
+    base = ops.gemm_nt_split(Ap, Wp, ws, b, R, act, a_packed=True, c_packed=cpk)
+    lib.pmce_gemm_split_set_m16(2)
+    try:
+        out = ops.gemm_nt_split(Ap, Wp, ws, b, R, act, a_packed=True, c_packed=cpk)
+        again = ops.gemm_nt_split(Ap, Wp, ws, b, R, act, a_packed=True, c_packed=cpk)
+    finally:
+        lib.pmce_gemm_split_set_m16(0)
+    val = (lambda t: ops.unsplit_rows_f16(t) if cpk else t.double())
+    e, e0 = (val(out) - ref).abs().max().item(), (val(base) - ref).abs().max().item()
+    print(f"gemm 16x16x32 {M}x{N}x{K} act={act} res={res} packed_out={cpk}: {e:.2e} (32x32x16 kernel {e0:.2e})")
+    assert torch.equal(out.view(torch.int32), again.view(torch.int32))
+    assert e < 2e-5 and e <= 1.5 * e0 + 1e-7
+
+
 @pytest.mark.parametrize("C,J,B", [(512, 17, 2), (256, 17, 2), (512, 19, 1), (256, 19, 3), (512, 17, 37)])
 def test_seq_attention_split_f16(C, J, B):
     """The matrix-pipe attention of the split-f16 mode (fp32 q, k, v in, pre-split result out) against the fp64 attention of

@@ -50,7 +50,7 @@ def test_f16_matrix_kernels_contain_no_packed_fp32(lib, tmp_path):
             f16_files.add(src)
         bad = sorted(set(re.findall(r"v_pk_(?:fma|mul|add)_f32", asm)))
         assert not bad, f"{src}: packed-fp32 instructions {bad} in a library whose kernels issue f16 matrix instructions"
-    assert f16_files == {"gemm_split_f16.hip", "gemm_split_ws.hip", "seq_attention_mfma.hip", "gru.hip", "coevo.hip"}
+    assert f16_files == {"gemm_split_f16.hip", "gemm_split_ws.hip", "gemm_split_m16.hip", "seq_attention_mfma.hip", "gru.hip", "coevo.hip"}
 
 
 def test_library_exports_every_declared_symbol(lib):
@@ -343,7 +343,7 @@ def test_hot_kernels_do_not_spill(lib, tmp_path):
         pytest.skip("llvm-objdump / llvm-readelf not available")
     allowed = ("gemm_split_ws_kernel", "seq_attention_pair_kernel", "sample_errors_kernel")   # (metrics: a private array by design)
     seen = 0
-    for src in ("gemm_split_f16.hip", "gemm_f32.hip", "seq_attention_mfma.hip", "lifter.hip", "gru.hip", "coevo.hip"):
+    for src in ("gemm_split_f16.hip", "gemm_split_m16.hip", "gemm_f32.hip", "seq_attention_mfma.hip", "lifter.hip", "gru.hip", "coevo.hip"):
         obj = osp.join(B.CSRC, "build", osp.splitext(src)[0] + ".o")
         if not osp.exists(obj):
             pytest.skip(f"{obj} not present (library built elsewhere)")
