@@ -46,7 +46,7 @@ def test_f16_matrix_kernels_contain_no_packed_fp32(lib, tmp_path):
         dev = [f for f in os.listdir(tmp_path) if f.startswith(osp.basename(obj) + ".") and "amdgcn" in f]
         assert dev, f"no device code object extracted from {obj}"
         asm = subprocess.run([objdump, "-d", str(tmp_path / dev[0])], check=True, capture_output=True, text=True).stdout
-        if "v_mfma_f32_32x32x16_f16" in asm:
+        if "v_mfma_f32_32x32x16_f16" in asm or "v_mfma_f32_16x16x32_f16" in asm:
             f16_files.add(src)
         bad = sorted(set(re.findall(r"v_pk_(?:fma|mul|add)_f32", asm)))
         assert not bad, f"{src}: packed-fp32 instructions {bad} in a library whose kernels issue f16 matrix instructions"
