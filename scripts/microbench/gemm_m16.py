@@ -40,7 +40,7 @@ for name, N, K, act, res, cpk in shapes:
     Ap = ops.split_rows_f16(A)
     outs, times = {}, {}
     for mode in (0, 1):
-        lib.pmce_gemm_split_set_m16(mode)
+        lib.pmce_gemm_split_set_m16(2 * mode)    # 2 = wherever the kernel applies (1 = only where it measured faster)
         run = lambda: ops.gemm_nt_split(Ap, Wp, ws, b, R, act, a_packed=True, c_packed=cpk)
         outs[mode] = run()
         times[mode] = timeit(run)
