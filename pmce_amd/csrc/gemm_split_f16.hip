@@ -477,7 +477,7 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
   // lower energy per multiply-add buys clock; the narrow and the residual products are bound elsewhere and its extra LDS reads cost),
   // 2 = wherever it applies (A/B)
   const int m16 = g_split_m16.load(std::memory_order_relaxed);
-  if (m16 != 0 && pmce_gemm_split_m16_wants(K, a_packed, c_div) && (m16 >= 2 || (R == nullptr && !c_packed && N >= 1024 && M >= 16384))) {
+  if (m16 != 0 && pmce_gemm_split_m16_wants(K, a_packed, c_div) && (m16 >= 2 || (R == nullptr && N >= 1024 && M >= 16384))) {
     PMCE_TRY(pmce_gemm_split_m16_launch(p, act, c_packed, pick_split_tile(M, N), stream));
     return pmce_check_launch("gemm_nt_split_f16 (16x16x32)");
   }

@@ -19,6 +19,9 @@
 // k-tile for the g >= 2 lanes) against 12 - the price of not holding two k-tiles in LDS.
 // The 16-byte chunks of a stage row are XOR-swizzled with (-(row >> 2)) & 3 here (DMA side and read side): with 16 rows x 2
 // k-groups per half wave the service groups of ds_read_b128 need that permutation to fall on 16 different slots.
+// (Unlike the default kernel, whose k order is the same for every tile shape, the 64 x 64 wave tile adds a pair's I3 one k-tile later
+// than the 64 x 128 one: results of this kernel may differ in the last bit between batch sizes that select different tiles - one
+// more reason it is an opt-in.)
 // Accumulators: 16x16 blocks, lane l holds rows 4 (l >> 4) + r of ONE column; the W rows are permuted on their way into LDS so that
 // the two blocks of a 32-column group give a lane the ADJACENT columns 2 (l & 15) and + 1: the epilogue moves 8 bytes per lane,
 // 128 contiguous bytes per 16 lanes (with plain 16-column blocks it moved 64-byte half lines and the residual products lost 40 %).
@@ -152,6 +155,23 @@ __global__ __launch_bounds__(256, 2) void gemm_split_m16_kernel(SplitParams p) {
   float w_down[CB];  // 2^-s of this lane's column in each 16-column block
   f32x4m acc[RB][CB];
   f16x8 a3[RB], b3[CB];  // I3 operands: g < 2 lanes hold the even k-tile's, g >= 2 lanes the odd one's
+  // DEFER (the 64 x 64 wave tile, which has the registers for it): a pair's I3 is issued at the START of the next pair's even
+  // k-tile, where it depends on no fresh LDS read and runs under that k-tile's fragment reads; issued behind the odd k-tile's reads
+  // it leaves the pipe idle for an LDS round trip per pair (PMC: 16.5 % more kernel cycles than the 32x32x16 kernel for the same
+  // matrix-busy cycles).  One code path for every pair: a tile's first pair issues the "previous" I3 on ZERO operands (a3 / b3 are
+  // cleared after every tile: 32 extra instructions per tile, 2 % at K = 512); the last pair's I3 goes out before the epilogue.
+  constexpr bool DEFER = CB <= 4;
+  auto clear_i3 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a3[i][e] = (_Float16)0.f;
+#pragma unroll
+    for (int j = 0; j < CB; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b3[j][e] = (_Float16)0.f;
+  };
+  if constexpr (DEFER) clear_i3();
   int li = bx, kt = 0, stage = 0, c_par = 0;
   int m_base, n_base;
   tile_coords(chunk_start + li, m_base, n_base);
@@ -203,6 +223,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_m16_kernel(SplitParams p) {
       }
       f16x8 a1[RB], b1[CB];
       read_i1(sA, a1, b1);
+      if constexpr (DEFER) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int j = 0; j < CB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3[i], b3[j], acc[i][j], 0, 0, 0);
+      }
       issue_i1(a1, b1);
       // (every lane writes, although only the g < 2 lanes' values are used - the g >= 2 lanes overwrite theirs in the odd k-tile:
       // a lane-masked write would keep the 48 registers of a3 / b3 alive through the epilogue of every tile)
@@ -219,11 +245,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_m16_kernel(SplitParams p) {
 #pragma unroll
         for (int j = 0; j < CB; ++j) b3[j] = *reinterpret_cast<const f16x8*>(sA + w_row + j * 256 + c_whi) * kDown;
       }
+      if constexpr (!DEFER) {
 #pragma unroll
-      for (int i = 0; i < RB; ++i)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
-        for (int j = 0; j < CB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3[i], b3[j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);  // (the I1 operands are read after the I3 instructions have been issued, not before)
+          for (int j = 0; j < CB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3[i], b3[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // (the I1 operands are read after the I3 instructions have been issued, not before)
+      }
       f16x8 a1[RB], b1[CB];
       read_i1(sA, a1, b1);
       issue_i1(a1, b1);
@@ -231,6 +259,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_m16_kernel(SplitParams p) {
 
     kt += 2;
     if (kt == nk) {
+      if constexpr (DEFER) {  // the last pair's I3; then zero operands for the next tile's first pair
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int j = 0; j < CB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3[i], b3[j], acc[i][j], 0, 0, 0);
+        clear_i3();
+      }
       // ---- epilogue of the finished tile, straight from the accumulators: block (i, j) register r is row 16 i + 4 g + r, column
       // 32 (j >> 1) + 2 r16 + (j & 1) of the wave tile - a lane owns the column PAIR (c, c + 1), c = 32 q + 2 r16, in blocks 2q, 2q + 1 ----
       kt = 0;

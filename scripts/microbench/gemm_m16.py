@@ -38,12 +38,15 @@ for name, N, K, act, res, cpk in shapes:
     R = torch.randn(m, N, generator=g).to(dev) if res else None
     Wp, ws = ops.pack_split_f16(W)
     Ap = ops.split_rows_f16(A)
-    outs, times = {}, {}
+    outs, times, t128 = {}, {}, {}
     for mode in (0, 1):
         lib.pmce_gemm_split_set_m16(2 * mode)    # 2 = wherever the kernel applies (1 = only where it measured faster)
         run = lambda: ops.gemm_nt_split(Ap, Wp, ws, b, R, act, a_packed=True, c_packed=cpk)
         outs[mode] = run()
         times[mode] = timeit(run)
+        lib.pmce_gemm_split_set_tuning(1)        # the 128 x 128 block tile (64 x 64 wave tile: the 16x16x32 kernel defers its I3 there)
+        t128[mode] = timeit(run)
+        lib.pmce_gemm_split_set_tuning(-1)
     lib.pmce_gemm_split_set_m16(0)
     rows = torch.randint(0, m, (512,), generator=g).to(dev)
     ref = A[rows].double() @ W.double().t() + b.double()
@@ -56,4 +59,4 @@ for name, N, K, act, res, cpk in shapes:
     d = (val[0] - val[1]).abs().max().item()
     flops = 3 * 2.0 * m * N * K
     print(f"{name:16s} {m} x {N} x {K}: 32x32x16 {times[0]:7.1f} us ({flops / times[0] / 1e6:6.0f} TF)   16x16x32 {times[1]:7.1f} us ({flops / times[1] / 1e6:6.0f} TF)   "
-          f"err vs fp64: {e0:.2e} / {e1:.2e}   max |difference| {d:.2e}   finite {bool(torch.isfinite(val[1]).all())}", flush=True)
+          f"| 128x128 tile: {t128[0]:7.1f} / {t128[1]:7.1f} us | err vs fp64: {e0:.2e} / {e1:.2e}   max |difference| {d:.2e}   finite {bool(torch.isfinite(val[1]).all())}", flush=True)
