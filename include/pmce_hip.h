@@ -65,7 +65,7 @@ const char* pmce_model_tensor_name(const pmce_model* m, int i);
 /* Optional caller-side projection (lib/core/base.py:196,225): register "jreg.indptr" (int32[R+1]), "jreg.indices"
  * (int32[nnz]), "jreg.data" (fp32[nnz]) with pmce_model_set_tensor and the row count R here. */
 int pmce_model_set_regressor_rows(pmce_model* m, int rows);
-/* Check that every tensor is registered and (split_f16 mode) pack the large weights as f16 planes in model-owned memory.
+/* Check that every tensor is registered and (split_f16 mode) pack the large weights as f16 planes (into the arena below, or memory of its own without one).
  * The packing kernels run on `stream` - pass the stream the registered tensors were produced on (they are read here) - and the
  * call returns when they are done (it synchronises that stream, nothing else).  pmce_model_finalize = ..._on(m, NULL): the null
  * stream, which is NOT ordered behind non-blocking streams (PyTorch's side streams). */
