@@ -49,3 +49,29 @@ def test_failed_rank_takes_the_job_down():
     exit code instead of leaving rank 0 waiting in a barrier."""
     r, lines = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--windows", "1"], timeout=600)
     assert r.returncode != 0 and not lines
+
+
+def test_roofline_records_of_the_non_gemm_kernels():
+    """bench.py's records for the HBM-bound attention kernel and the north-star cross-attention kernel: pure functions of the measured
+    kernel times and of the committed PMC summaries (no GPU)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", osp.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    B, J, C = 256, 17, 512
+    kernel_ms = {"seq_attention": 0.72, "vertex_ca_mlp": 0.264}
+    launches = {"seq_attention": 6, "vertex_ca_mlp": 3}
+    a = bench.attention_record(kernel_ms, launches, B, J, C, True)
+    assert a["kernel"] == "seq_attention_mfma_kernel" and a["bound"] == "hbm" and a["launches_per_step"] == 6
+    assert a["algorithmic_bytes_per_launch"] == B * 16 * J * 4 * C * 4                     # q, k, v read + result written, once each
+    assert abs(a["achieved"] - a["algorithmic_bytes_per_launch"] / 0.12e-3 / 1e9) < 1.0 and abs(a["frac"] - a["achieved"] / 8000.0) < 1e-3
+    if a["traffic"] is not None:                                                           # the committed PMC pass: no wasted re-reads
+        assert 0.98 < a["traffic"] / a["algorithmic_bytes_per_launch"] < 1.05
+    assert bench.attention_record(kernel_ms, launches, B, J, C, False)["kernel"] == "seq_attention_pair_kernel"
+    assert bench.attention_record({}, {}, B, J, C, True) is None
+    n = bench.north_star_record(kernel_ms, launches, B, J, f16_ffn=True)
+    assert n["kernel"] == "vertex_ca_mlp" and n["bytes_per_clip_dir_block"] == 229376
+    assert abs(n["hbm_floor_ms"] - 229376.0 * B / 8e12 * 1e3) < 1e-4 and n["mfma_floor_ms"] > n["hbm_floor_ms"]
+    if "valu_floor_ms" in n:                                                               # from the committed instruction count
+        assert abs(n["serial_floor_ms"] - (n["mfma_floor_ms"] + n["valu_floor_ms"])) < 1e-4
+        assert 0.0 < n["frac_of_serial_floor"] < 1.0 and n["bound"] in ("valu", "mfma")
