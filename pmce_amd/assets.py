@@ -45,13 +45,37 @@ def regressor_to_csr(reg: np.ndarray):
     return (np.asarray(indptr, np.int32), np.asarray(indices, np.int32), np.asarray(data, np.float32))
 
 
+def _torch_coo(d):
+    """scipy sparse -> torch COO exactly as the reference builds it (mesh.py:16-21: ``coo_matrix(D)``, entries in that
+    order, fp32 values, NOT coalesced), so that the product below adds a row's terms in the reference's order."""
+    import scipy.sparse as sp
+    import torch
+    c = sp.coo_matrix(d)
+    idx = torch.from_numpy(np.array([c.row, c.col]).astype(np.int64))
+    val = torch.from_numpy(np.asarray(c.data).astype(np.float32))
+    return torch.sparse_coo_tensor(idx, val, c.shape)
+
+
 def downsample_template(mean_vertices: np.ndarray, D) -> np.ndarray:
-    """[6890,3] f32 -> [431,3] f32 by the two sparse down-sampling maps (mesh.py:81-96: fp32 spmm)."""
-    x = np.asarray(mean_vertices, dtype=np.float32)
+    """[6890,3] f32 -> [431,3] f32 by the two sparse down-sampling maps.  The reference runs ``torch.matmul(sparse COO,
+    dense)`` in fp32 (mesh.py:81-96 via graph_layers.py:19,29); the same torch call on the same COO entries is used here, so
+    the template - and with it every near-tie ``argmin`` of ``vj_relation`` - has the reference's bits (a scipy ``csr @ x``
+    adds a multi-entry row's terms in another order: last-ulp differences, which can flip a tie)."""
+    import torch
+    x = torch.from_numpy(np.ascontiguousarray(mean_vertices, dtype=np.float32))
     for d in D[:2]:
-        x = np.asarray(d.astype(np.float32) @ x, dtype=np.float32)
+        x = torch.matmul(_torch_coo(d), x)
+    x = x.numpy()
     assert x.shape == (NUM_VERTS, 3), x.shape
     return x
+
+
+def template_joints(mean_vertices: np.ndarray) -> np.ndarray:
+    """[17,3] f32 = J_regressor_h36m (cast to fp32) @ mean mesh as ONE dense fp32 ``torch.matmul``
+    (CoevoDecoder.py:207-208) - the reference's call, hence its summation order."""
+    import torch
+    jreg = torch.from_numpy(load_j_regressor("h36m").astype(np.float32))
+    return torch.matmul(jreg, torch.from_numpy(np.ascontiguousarray(mean_vertices, dtype=np.float32))).numpy()
 
 
 def build_verts_joints_relation(joints: np.ndarray, vertices: np.ndarray) -> np.ndarray:
@@ -91,7 +115,7 @@ def load_base_data(base_dir: str | None = None):
         import scipy.sparse as sp
         v = np.load(mv).astype(np.float32)
         z = np.load(md, encoding="latin1", allow_pickle=True)
-        D = [sp.csr_matrix(d).astype(np.float32) for d in z["D"][:2]]
+        D = [sp.coo_matrix(d) for d in z["D"][:2]]   # entry order kept: it is the order the reference's spmm adds in
         return v, D, "files"
     if not synthetic_base_data_allowed():
         raise FileNotFoundError(
@@ -110,7 +134,5 @@ def build_template(base_dir: str | None = None):
     v, D, src = load_base_data(base_dir)
     assert v.shape == (NUM_VERTS_FULL, 3)
     v431 = downsample_template(v, D)
-    jreg = load_j_regressor("h36m").astype(np.float32)         # CoevoDecoder.py:207 (.astype(float32))
-    joints_template = jreg @ v                                  # [17,3] fp32 matmul (CoevoDecoder.py:208)
-    vj = build_verts_joints_relation(joints_template, v431)
+    vj = build_verts_joints_relation(template_joints(v), v431)
     return v431, vj, src
