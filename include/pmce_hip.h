@@ -17,10 +17,10 @@
  *   - launches are asynchronous on the hipStream_t passed in.  The calls that synchronise: pmce_model_finalize[_on] and
  *     pmce_model_set_gemm_mode[_on] (they wait for their own packing kernels on the stream given; a mode change that drops
  *     existing planes first waits for the whole device - forwards in flight may read them - and is therefore not capturable),
- *     pmce_model_profile_read (waits for the recorded events) and the diagnostics pmce_gemm_ws_timeouts / pmce_dbg_*;
+ *     pmce_model_profile_read (waits for the recorded events);
  *   - mutable state outside the handles: the thread-local error string and, while a model entry point runs, the thread-local
  *     pointer to that model's overflow word - one process per GPU or several host threads with their own streams are both fine -
- *     and the process-wide TUNING AIDS pmce_gemm_set_tuning, pmce_gemm_split_set_tuning / _set_skew / _set_ws (relaxed atomics
+ *     and the process-wide TUNING AIDS pmce_gemm_set_tuning, pmce_gemm_split_set_tuning / _set_skew / _set_clock_probe (relaxed atomics
  *     read at launch time: meant for benchmarks and tests, not to be flipped while forwards are being enqueued elsewhere).
  * Fixed structural constants of the path: T = 16 frames, F = 2048 image-feature channels, V = 431 coarse
  * vertices, 6890 mesh vertices, D = 64 decoder channels, GRU hidden 1024, 8 lifter heads.  J <= 32,
@@ -189,7 +189,7 @@ int pmce_gemm_set_tuning(int tile, int grid_per_cu);
  * |A| must be below 65504 (an element outside the f16 range yields inf/nan, never a silently wrong finite value; inside a model
  * call such a result also sets the model's sticky overflow word, pmce_model_overflowed).
  * MI355X: while a kernel that issues f16 matrix instructions runs, packed-fp32 vector arithmetic (v_pk_{fma,mul,add}_f32) of
- * any other wave on the same CU may return wrong results (pmce_dbg_victim reproduces it).  No kernel of this library contains
+ * any other wave on the same CU may return wrong results (scripts/microbench/libpmce_diag.so: pmce_dbg_victim reproduces it).  No kernel of this library contains
  * such instructions, so its entries may overlap each other freely; do not overlap these entries with foreign kernels that do. */
 int pmce_gemm_pack_split_f16(const float* W, int N, int K, int ldw, float* Wp, float* wscale, pmce_stream_t stream);
 int pmce_gemm_nt_split_f16(const float* A, const float* Wp, const float* wscale, const float* bias, const float* R, float* C,
@@ -206,33 +206,14 @@ int pmce_gemm_nt_split_f16_rowmap(const float* A, const float* Wp, const float* 
 /* a_packed != 0: A is not fp32 but already split, [M][K/16][hi 16 f16 | lo*2^11 16 f16] (the layout the lifter's own
  * producers write; pmce_split_rows_f16 makes it from fp32 rows). */
 int pmce_split_rows_f16(const float* A, long long M, int K, long long lda, float* Ap, pmce_stream_t stream);
-/* Tuning aid only: force the tile configuration of pmce_gemm_nt_split_f16 (0: 128x256, 1: 128x128, 2: 64x128 - the 4-wave
- * kernel; 3: the wave-specialised 192x256 kernel of gemm_split_ws.hip wherever it applies; -1 automatic). */
+/* Tuning aid only: force the tile configuration of pmce_gemm_nt_split_f16 (0: 128x256, 1: 128x128, 2: 64x128; -1 automatic). */
 int pmce_gemm_split_set_tuning(int tile);
-/* Tuning aid only: 0 keeps the automatic choice away from the wave-specialised kernel (PMCE_SPLIT_WS=0 at load does the same). */
-int pmce_gemm_split_set_ws(int on);
-/* Tuning aid (process-wide; env PMCE_SPLIT_M16 at load): the products with a pre-split A on v_mfma_f32_16x16x32_f16 instead of
- * 32x32x16 (csrc/gemm_split_m16.hip) - the same three-product arithmetic, a different summation order inside a k-tile. */
-int pmce_gemm_split_set_m16(int on);
-/* Number of wavefronts of the wave-specialised kernel that gave up waiting on an in-kernel hand-off since the library was
- * loaded: 0 in a healthy process (every spin is bounded instead of hanging the device).  Synchronises the device. */
-int pmce_gemm_ws_timeouts(void);
 /* Measurement aid (bench.py): while set (null = off), every launch of the 4-wave split kernel adds, per workgroup, the shader
  * clocks and the 100 MHz wall ticks its first wave was resident to device_two_words[0] / [1]: their ratio x 0.1 is the shader clock
  * in GHz the chip sustained under the kernel (MI355X is power-limited there: 1.6 - 1.8 GHz, not the 2.4 GHz of the peak figures). */
 int pmce_gemm_split_set_clock_probe(unsigned long long* device_two_words);
 /* Tuning aid only: start delay of every CU's second workgroup in units of 4096 cycles (-1: half a tile of matrix time). */
 int pmce_gemm_split_set_skew(int units);
-/* Diagnostics (scripts/microbench/victims.py; not on the product path): self-checking bystander kernels and matrix-pipe
- * spinners used to show that waves executing f16 matrix instructions disturb packed-fp32 arithmetic of other kernels' waves on
- * MI355X - the reason this library is built without packed-fp32 instructions.  bad4: 4 unsigned counters. */
-int pmce_dbg_victim(int kind, unsigned* bad4, int blocks, int iters, const float* table, pmce_stream_t stream);
-int pmce_dbg_mfma_spin(int kind, float* sink, int blocks, int iters, pmce_stream_t stream);
-/* Diagnostic: one 32x32x16 f16 matrix instruction with A = a, B = b everywhere; out2[0] = its result (16 a b if subnormal f16
- * inputs are read as they are - what pmce_vertex_sa_ex_f32's f16 form relies on for the lo halves of small k / v elements),
- * out2[1] = a as f16. */
-int pmce_dbg_mfma_subnormal(float a, float b, float* out2, pmce_stream_t stream);
-
 /* PoseEstimation.py:78-81 — x[tok] = joint_embed(pose2d) + imgfeat_embed(img_feat)[b,t] + spatial_pos[j]. */
 int pmce_embed_tokens_f32(const float* pose2d, const float* E, const float* Wje, const float* bje, const float* spos,
                           float* x, long long ntok, int J, int C, pmce_stream_t stream);

@@ -62,13 +62,7 @@ PROTOTYPES = {
     "pmce_seq_attention_split_f16": [_f, _f, _i, _i, _i, _i, _l, _l, _l, _s],
     "pmce_gemm_nt_split_f16_rowmap": [_f, _f, _f, _f, _f, _i, _i, _i, _l, _i, _l, _l, _s],
     "pmce_gemm_split_set_tuning": [_i],
-    "pmce_gemm_split_set_ws": [_i],
-    "pmce_gemm_split_set_m16": [_i],
     "pmce_gemm_split_set_clock_probe": [C.c_void_p],
-    "pmce_gemm_ws_timeouts": [],
-    "pmce_dbg_victim": [_i, _f, _i, _i, _f, _s],
-    "pmce_dbg_mfma_spin": [_i, _f, _i, _i, _s],
-    "pmce_dbg_mfma_subnormal": [_fl, _fl, _f, _s],
     "pmce_gemm_split_set_skew": [_i],
     "pmce_embed_tokens_f32": [_f, _f, _f, _f, _f, _f, _l, _i, _i, _s],
     "pmce_ln_chain_f32": [_f, _l, _i, _f, _f, _fl, _f, _i, _i, _f, _f, _f, _fl, _f, _s],

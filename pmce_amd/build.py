@@ -11,14 +11,21 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = osp.dirname(osp.abspath(__file__))
 CSRC = osp.join(HERE, "csrc")
 LIB = osp.join(HERE, "libpmce_hip.so")
-SOURCES = ["common.cpp", "gemm_f32.hip", "gemm_split_f16.hip", "gemm_split_ws.hip", "gemm_split_m16.hip", "seq_attention_mfma.hip", "lifter.hip", "gru.hip", "coevo.hip", "metrics.hip", "dbg_victims.hip", "model.cpp"]
+SOURCES = ["common.cpp", "gemm_f32.hip", "gemm_split_f16.hip", "seq_attention_mfma.hip", "lifter.hip", "gru.hip", "coevo.hip", "metrics.hip", "model.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # On MI355X waves that execute f16 matrix instructions disturb packed-fp32 (v_pk_*_f32) arithmetic of OTHER waves on the same CU
 #  - waves of other kernels and waves of the same kernel that are in a vector phase while their neighbours are
 # in the matrix phase.  No packed-fp32 instruction is generated for ANY kernel of the library, which is what allows its kernels to
 # overlap each other (two streams inside a forward, pipeline lanes); tests/test_host_logic.py checks the device code.
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-FILE_FLAGS = {src: NO_PACKED_FP32 for src in SOURCES if src.endswith(".hip") and src != "dbg_victims.hip"}  # (the diagnostic's bystanders ARE packed-fp32 code)
+FILE_FLAGS = {src: NO_PACKED_FP32 for src in SOURCES if src.endswith(".hip")}
+
+# The diagnostics library (NOT the product; scripts/microbench/README): the two experimental split-GEMM variants kept for the record and
+# the bystander kernels of the matrix-pipe interference report, which ARE packed-fp32 code on purpose.
+DIAG_DIR = osp.join(HERE, "..", "scripts", "microbench")
+DIAG_LIB = osp.join(DIAG_DIR, "libpmce_diag.so")
+DIAG_SOURCES = ["diag_entry.hip", "gemm_split_ws.hip", "gemm_split_m16.hip", "dbg_victims.hip"]
+DIAG_FILE_FLAGS = {src: NO_PACKED_FP32 for src in DIAG_SOURCES if src != "dbg_victims.hip"}
 
 
 def _hipcc():
@@ -64,5 +71,38 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_diag(force: bool = False, verbose: bool = True) -> str:
+    """scripts/microbench/libpmce_diag.so: diagnostics only (the bystander report of the GPU suite loads it); links its own copy
+    of common.cpp (error string, launch check), shares the product's headers."""
+    srcdir = osp.join(DIAG_DIR, "csrc")
+    deps = [osp.join(srcdir, f) for f in DIAG_SOURCES] + [osp.join(CSRC, f) for f in ("common.cpp", "common.hpp", "gemm_split_common.hpp")]
+    if not force and osp.exists(DIAG_LIB) and all(osp.getmtime(d) <= osp.getmtime(DIAG_LIB) for d in deps):
+        return DIAG_LIB
+    hipcc = _hipcc()
+    objdir = osp.join(srcdir, "build")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(item):
+        d, src = item
+        obj = osp.join(objdir, osp.splitext(src)[0] + ".o")
+        extra = os.environ.get("PMCE_EXTRA_HIPCC_FLAGS", "").split()
+        cmd = [hipcc, *FLAGS, "-I", CSRC, *DIAG_FILE_FLAGS.get(src, []), *extra, "-x", "hip", "-c", osp.join(d, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        err = "".join(l for l in r.stderr.splitlines(True) if "packed-fp32-ops' is not a recognized feature" not in l)
+        if verbose and err.strip():
+            sys.stderr.write(err)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=5) as ex:
+        objs = list(ex.map(compile_one, [(srcdir, s) for s in DIAG_SOURCES] + [(CSRC, "common.cpp")]))
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", *objs, "-o", DIAG_LIB], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return DIAG_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    print(build_diag(force="--force" in sys.argv))

@@ -424,24 +424,6 @@ static int pick_split_tile(int M, int N) {
   return best;
 }
 
-// gemm_split_ws.hip: the wave-specialised 192x256 kernel (pre-split A, large M)
-bool pmce_gemm_split_ws_wants(int M, int N, int K, int a_packed, int c_div);
-int pmce_gemm_split_ws_launch(SplitParams& p, int act, int c_packed, hipStream_t stream);
-static std::atomic<int> g_split_ws{pmce_env_int("PMCE_SPLIT_WS", 0)};  // off: it is not faster than the 4-wave kernel
-extern "C" int pmce_gemm_split_set_ws(int on) {
-  g_split_ws.store(on, std::memory_order_relaxed);
-  return PMCE_OK;
-}
-
-// gemm_split_m16.hip: the same products on v_mfma_f32_16x16x32_f16 (pre-split A)
-bool pmce_gemm_split_m16_wants(int K, int a_packed, int c_div);
-int pmce_gemm_split_m16_launch(SplitParams& p, int act, int c_packed, int tile, hipStream_t stream);
-static std::atomic<int> g_split_m16{pmce_env_int("PMCE_SPLIT_M16", 0)};
-extern "C" int pmce_gemm_split_set_m16(int on) {
-  g_split_m16.store(on, std::memory_order_relaxed);
-  return PMCE_OK;
-}
-
 static int gemm_split_any(const float* A, const float* Wp, const float* wscale, const float* bias, const float* R, float* C, int M,
                           int N, int K, long long lda, long long ldc, int act, int a_packed, int c_packed, int c_div,
                           long long c_lo, long long c_hi, hipStream_t stream) {
@@ -465,21 +447,6 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
   {  // half a tile of matrix time: nk iterations x 3*TM*TN instructions x 32 cycles (TM*TN = 8 or 4), / 2, in 4096-cycle units
     const int knob = g_split_skew.load(std::memory_order_relaxed);
     p.skew = knob >= 0 ? knob : (K / 16) * 12 * 32 / 4096 + 1;
-  }
-  {
-    const int forced = g_split_tile.load(std::memory_order_relaxed);
-    if ((forced == 3 || (forced < 0 && g_split_ws.load(std::memory_order_relaxed) != 0)) && pmce_gemm_split_ws_wants(M, N, K, a_packed, c_div)) {
-      PMCE_TRY(pmce_gemm_split_ws_launch(p, act, c_packed, stream));
-      return pmce_check_launch("gemm_nt_split_f16 (ws)");
-    }
-  }
-  // 16x16x32 shape: 1 = where it measures faster (wide products without a residual: the chip is power-limited there and the shape's
-  // lower energy per multiply-add buys clock; the narrow and the residual products are bound elsewhere and its extra LDS reads cost),
-  // 2 = wherever it applies (A/B)
-  const int m16 = g_split_m16.load(std::memory_order_relaxed);
-  if (m16 != 0 && pmce_gemm_split_m16_wants(K, a_packed, c_div) && (m16 >= 2 || (R == nullptr && N >= 1024 && M >= 16384))) {
-    PMCE_TRY(pmce_gemm_split_m16_launch(p, act, c_packed, pick_split_tile(M, N), stream));
-    return pmce_check_launch("gemm_nt_split_f16 (16x16x32)");
   }
   switch (pick_split_tile(M, N)) {
     case 0: PMCE_TRY((launch_cfg<2, 4>(p, act, a_packed != 0, c_packed != 0, stream))); break;

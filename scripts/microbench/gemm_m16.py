@@ -6,6 +6,7 @@ import os.path as osp
 sys.path.insert(0, osp.dirname(osp.dirname(osp.dirname(osp.abspath(__file__)))))
 import torch
 from pmce_amd import _lib, ops
+from scripts.microbench import diag      # the 16x16x32 kernel is in the diagnostics library (not in the product)
 
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 dev = torch.device("cuda:0")
@@ -40,14 +41,17 @@ for name, N, K, act, res, cpk in shapes:
     Ap = ops.split_rows_f16(A)
     outs, times, t128 = {}, {}, {}
     for mode in (0, 1):
-        lib.pmce_gemm_split_set_m16(2 * mode)    # 2 = wherever the kernel applies (1 = only where it measured faster)
-        run = lambda: ops.gemm_nt_split(Ap, Wp, ws, b, R, act, a_packed=True, c_packed=cpk)
+        if mode == 0:
+            run = lambda: ops.gemm_nt_split(Ap, Wp, ws, b, R, act, a_packed=True, c_packed=cpk)
+            run128 = run
+        else:
+            run = lambda: diag.gemm_nt_split(1, Ap, Wp, ws, b, R, act, a_packed=True, c_packed=cpk, tile=0)
+            run128 = lambda: diag.gemm_nt_split(1, Ap, Wp, ws, b, R, act, a_packed=True, c_packed=cpk, tile=1)
         outs[mode] = run()
         times[mode] = timeit(run)
         lib.pmce_gemm_split_set_tuning(1)        # the 128 x 128 block tile (64 x 64 wave tile: the 16x16x32 kernel defers its I3 there)
-        t128[mode] = timeit(run)
+        t128[mode] = timeit(run128)
         lib.pmce_gemm_split_set_tuning(-1)
-    lib.pmce_gemm_split_set_m16(0)
     rows = torch.randint(0, m, (512,), generator=g).to(dev)
     ref = A[rows].double() @ W.double().t() + b.double()
     if act:

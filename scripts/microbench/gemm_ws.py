@@ -3,7 +3,9 @@ reproducibility, hand-off timeouts and launch time at the lifter's shapes."""
 import sys, torch
 sys.path.insert(0, ".")
 from pmce_amd import ops, _lib
+from scripts.microbench import diag      # the wave-specialised kernel is in the diagnostics library (not in the product)
 lib = _lib.load()
+dlib = diag.load()
 dev = "cuda"
 torch.manual_seed(0)
 
@@ -30,9 +32,10 @@ for (M, N, K, act, res, cpk) in ([] if ("--ablate" in sys.argv or "--timeline" i
     R = torch.randn(M, N, device=dev) if res else None
     Wp, ws = ops.pack_split_f16(W)
     Ap = ops.split_rows_f16(A)
-    run = lambda: ops.gemm_nt_split(Ap, Wp, ws, b, R, act, a_packed=True, c_packed=cpk)
-    lib.pmce_gemm_split_set_tuning(0); c_old = run().clone()
-    lib.pmce_gemm_split_set_tuning(3); c_ws = run().clone()
+    run_old = lambda: ops.gemm_nt_split(Ap, Wp, ws, b, R, act, a_packed=True, c_packed=cpk)
+    run = lambda: diag.gemm_nt_split(0, Ap, Wp, ws, b, R, act, a_packed=True, c_packed=cpk)
+    lib.pmce_gemm_split_set_tuning(0); c_old = run_old().clone()
+    c_ws = run().clone()
     same = torch.equal(c_old.view(torch.int32), c_ws.view(torch.int32))
     nbad, where = 0, ""
     if not same:
@@ -46,16 +49,16 @@ for (M, N, K, act, res, cpk) in ([] if ("--ablate" in sys.argv or "--timeline" i
         c2 = run()
         rep_bad += int(not torch.equal(c2.view(torch.int32), c_ws.view(torch.int32)))
     t_ws = timeit(run)
-    lib.pmce_gemm_split_set_tuning(0); t_old = timeit(run)
-    lib.pmce_gemm_split_set_tuning(-1); t_auto = timeit(run)
+    lib.pmce_gemm_split_set_tuning(0); t_old = timeit(run_old)
+    lib.pmce_gemm_split_set_tuning(-1); t_auto = timeit(run_old)
     fl = 3 * 2.0 * M * N * K
     print(f"{M:6d} x {N:5d} x {K:5d} act={act} res={int(res)} cpk={int(cpk)}: 4-wave {t_old:7.1f} us  ws {t_ws:7.1f} us ({fl/t_ws/1e6:6.0f} TF issued = {fl/t_ws/1e6/2500:.3f})  auto {t_auto:7.1f} us | "
-          f"bitwise {'equal' if same else f'DIFFERENT ({nbad}){where}'}  reruns differing {rep_bad}  timeouts {lib.pmce_gemm_ws_timeouts()}", flush=True)
+          f"bitwise {'equal' if same else f'DIFFERENT ({nbad}){where}'}  reruns differing {rep_bad}  timeouts {dlib.pmce_gemm_ws_timeouts()}", flush=True)
 lib.pmce_gemm_split_set_tuning(-1)
 
 if "--ablate" in sys.argv:  # needs a library built with PMCE_EXTRA_HIPCC_FLAGS=-DPMCE_WS_ABLATE
     import ctypes
-    raw = ctypes.CDLL(_lib.LIB_PATH)
+    raw = ctypes.CDLL(diag.LIB_PATH)
     names = {0: "full", 1: "no stores", 2: "no DMA", 3: "no stores, no DMA", 4: "no MFMA", 5: "no MFMA, no stores", 6: "no MFMA, no DMA",
              8: "DMA from a 4 KB window", 9: "4 KB window, no stores", 18: "no DMA, no land wait", 19: "no DMA, no land wait, no stores",
              7: "loop only (no MFMA/DMA/stores)", 23: "loop only, no land wait"}
@@ -81,12 +84,12 @@ if "--ablate" in sys.argv:  # needs a library built with PMCE_EXTRA_HIPCC_FLAGS=
                 steps = 23.0 * 12 * (M + 191) // 192 * (N // 256) * (K // 16)  # compute-wave k-tiles of the 23 launches timed
                 if rnd: res.append(f"{names[k]}: {t:.0f} [cw fail/step {st[0]/steps:.2f} polled {st[2]/steps:.2f} ld fail/step {st[1]/(steps/3):.2f}] clock {ck[0] / max(ck[1], 1) * 0.1:.2f} GHz")
         raw.pmce_gemm_ws_set_dbg(0)
-        print(f"ablation {M} x {N} x {K} (us): " + "\n   ".join(res) + f" | timeouts {lib.pmce_gemm_ws_timeouts()}", flush=True)
+        print(f"ablation {M} x {N} x {K} (us): " + "\n   ".join(res) + f" | timeouts {dlib.pmce_gemm_ws_timeouts()}", flush=True)
     lib.pmce_gemm_split_set_tuning(-1)
 
 if "--timeline" in sys.argv:  # ablate build: shader clocks per wave role and phase (s_memtime instrumented, so slower than the product)
     import ctypes
-    raw = ctypes.CDLL(_lib.LIB_PATH)
+    raw = ctypes.CDLL(diag.LIB_PATH)
     lib.pmce_gemm_split_set_tuning(3)
     for (M, N, K) in [(69632, 1536, 512), (69632, 512, 1024)]:
         A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) * 0.05; b = torch.randn(N, device=dev)
@@ -112,7 +115,7 @@ if "--timeline" in sys.argv:  # ablate build: shader clocks per wave role and ph
 
 if "--check-opt" in sys.argv:  # ablate build: correctness of schedule variants (OPT bits) against the 4-wave kernel
     import ctypes
-    raw = ctypes.CDLL(_lib.LIB_PATH)
+    raw = ctypes.CDLL(diag.LIB_PATH)
     for (M, N, K) in [(69632, 1536, 512), (40000, 640, 256)]:
         A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) * 0.05; b = torch.randn(N, device=dev)
         Wp, ws = ops.pack_split_f16(W); Ap = ops.split_rows_f16(A)

@@ -1,6 +1,6 @@
 """Bystander test: does a kernel on one stream change its results because a matrix-pipe kernel runs on another?
 
-Self-checking bystanders (csrc/dbg_victims.hip: every wave recomputes one fixed function of its own registers 400 times and
+Self-checking bystanders (scripts/microbench/csrc/dbg_victims.hip: every wave recomputes one fixed function of its own registers 400 times and
 counts iterations that differ from the first) next to (a) matrix-pipe spinners - one MFMA shape on register operands, no memory
 traffic - and (b) the real GEMMs of this path; plus the lifter head kernel (compiler-scheduled, 272 workgroups) against its own
 stand-alone output.  On MI355X the f16 matrix instructions disturb packed-fp32 (op_sel forms) arithmetic of bystanders; the
@@ -8,7 +8,9 @@ fp32 matrix instructions do not.  That is why the split-f16 mode runs everything
 import ctypes as C, sys, torch
 sys.path.insert(0, ".")
 from pmce_amd import ops, _lib
+from scripts.microbench import diag      # bystander / spinner kernels: the diagnostics library
 lib = _lib.load()
+dlib = diag.load()
 dev = "cuda"
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
 tab = ((torch.arange(4096 * 1024 + 32 * 1024, device=dev, dtype=torch.int64) % 8191).float() * 0.5).contiguous()
@@ -30,12 +32,12 @@ def trial(aggr, kind, reps=10):
     bad = torch.zeros(4, dtype=torch.int32, device=dev)
     for r in range(reps):
         aggr()
-        _lib.check(lib.pmce_dbg_victim(kind, _lib.ptr(bad), 1024, 400, _lib.ptr(tab), C.c_void_p(s1.cuda_stream)))
+        diag.check(dlib.pmce_dbg_victim(kind, _lib.ptr(bad), 1024, 400, _lib.ptr(tab), C.c_void_p(s1.cuda_stream)))
         torch.cuda.synchronize()
     return bad.tolist()[0]
 rows = [("nothing", lambda: None), ("fp32 GEMM of this path", lambda: [gemm_f32() for _ in range(3)]),
         ("split-f16 GEMM of this path", lambda: [gemm_split() for _ in range(3)])]
-rows += [(f"spinner {n}", (lambda k: lambda: _lib.check(lib.pmce_dbg_mfma_spin(k, _lib.ptr(sink), 512, 20000, C.c_void_p(s2.cuda_stream))))(k))
+rows += [(f"spinner {n}", (lambda k: lambda: diag.check(dlib.pmce_dbg_mfma_spin(k, _lib.ptr(sink), 512, 20000, C.c_void_p(s2.cuda_stream))))(k))
          for k, n in enumerate(shapes)]
 print("lanes (of 262144) whose result changed at least once, per bystander kind:")
 for label, aggr in rows:

@@ -1,7 +1,9 @@
-"""A REPORT, not a gate: does work of OTHER kernels change its results because kernels that issue f16 matrix instructions run
-beside it on the same chip?  (on the builder's boxes, packed-fp32 vector arithmetic of co-resident waves did.)
-Every fresh MI355X the suite runs on prints the table below into the pytest output, so the claim is confirmed or refuted on
-hardware the builder never saw; the test itself only fails if the measurement cannot be made."""
+"""Does work of OTHER kernels change its results because kernels that issue f16 matrix instructions run beside it on the same chip?
+(on the builder's boxes, hand-written packed-fp32 arithmetic with op_sel operands of co-resident waves did; cause unknown.)
+Part (1) is a REPORT: self-checking bystander kernels of the diagnostics library next to matrix-pipe work; every fresh MI355X the
+suite runs on prints the table into the pytest output, so the claim is confirmed or refuted on hardware the builder never saw.
+Part (2) is a GATE: the torch kernels the docs name as safe beside a forward (elementwise a*b+c, fp64 reductions, layer_norm,
+softmax, gelu - what pmce_amd/eval.py overlaps with pipeline lanes) must be bit-correct beside forwards in BOTH product modes."""
 import ctypes as C
 
 import pytest
@@ -14,12 +16,14 @@ pytestmark = pytest.mark.gpu
 
 def test_bystander_interference_report():
     from pmce_amd import _lib, assets, models, ops, synth
+    from scripts.microbench import diag      # bystander / spinner kernels: the diagnostics library, not the product
     lib = _lib.load()
+    dlib = diag.load()
     dev = torch.device("cuda:0")
     s_by, s_mx = torch.cuda.Stream(), torch.cuda.Stream()
     lines = []
 
-    # ---- (1) self-checking bystander kernels (csrc/dbg_victims.hip: every wave recomputes one fixed function of its own registers
+    # ---- (1) self-checking bystander kernels (scripts/microbench/csrc/dbg_victims.hip: every wave recomputes one fixed function of its own registers
     # 400 times and counts the iterations that differ from the first) next to matrix-pipe work on the other stream
     tab = ((torch.arange(4096 * 1024 + 32 * 1024, device=dev, dtype=torch.int64) % 8191).float() * 0.5).contiguous()
     sink = torch.zeros(256, device=dev)
@@ -40,7 +44,7 @@ def test_bystander_interference_report():
             _lib.check(lib.pmce_gemm_nt_f32(_lib.ptr(A), _lib.ptr(W), _lib.ptr(b), None, _lib.ptr(outg), M, N, K, K, K, N, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, mx))
 
     def spin(kind):
-        return lambda: _lib.check(lib.pmce_dbg_mfma_spin(kind, _lib.ptr(sink), 512, 20000, mx))
+        return lambda: diag.check(dlib.pmce_dbg_mfma_spin(kind, _lib.ptr(sink), 512, 20000, mx))
 
     aggressors = [("nothing", lambda: None), ("fp32 GEMM of this path", gemm_f32), ("split-f16 GEMM of this path", gemm_split),
                   ("bare v_mfma_f32_32x32x16_f16", spin(0)), ("bare v_mfma_f32_16x16x32_f16", spin(1)), ("bare v_mfma_f32_32x32x2_f32", spin(4))]
@@ -52,7 +56,7 @@ def test_bystander_interference_report():
             bad = torch.zeros(4, dtype=torch.int32, device=dev)
             for _ in range(6):
                 aggr()
-                _lib.check(lib.pmce_dbg_victim(kind, _lib.ptr(bad), 1024, 400, _lib.ptr(tab), C.c_void_p(s_by.cuda_stream)))
+                diag.check(dlib.pmce_dbg_victim(kind, _lib.ptr(bad), 1024, 400, _lib.ptr(tab), C.c_void_p(s_by.cuda_stream)))
                 torch.cuda.synchronize()
             row[vname] = int(bad[0])
         lines.append(f"    next to {label:30s}: {row}")
@@ -74,6 +78,7 @@ def test_bystander_interference_report():
     ref_sm = torch.softmax(xs, -1)
     ref_ge = torch.nn.functional.gelu(xs)
     torch.cuda.synchronize()
+    gate = []
     for mode in ("f32", "split_f16"):
         model.set_gemm_mode(mode, min_batch=1)
         model(p2, f)
@@ -96,8 +101,12 @@ def test_bystander_interference_report():
             wrong_sums += sum(int(not torch.equal(s, ref_sum)) for s in sums)
         lines.append(f"(2) torch `a * b + c` (64 M floats, 6 launches x {trials} trials) beside forwards in mode {mode:9s}: {wrong_elems} wrong elements in "
                      f"{wrong_trials} trials; {wrong_sums} of {2 * trials} fp64 reductions differ; layer_norm / softmax / gelu over 16 M floats: {wrong_other} wrong elements")
+        gate.append((mode, wrong_elems, wrong_sums, wrong_other))
     model.set_gemm_mode(None)
     print("\n=== bystander interference report (MI355X, this box) ===")
     for ln in lines:
         print(ln)
     print("=== end of report ===")
+    for mode, wrong_elems, wrong_sums, wrong_other in gate:
+        assert wrong_elems == 0 and wrong_sums == 0 and wrong_other == 0, \
+            f"torch kernels beside forwards in mode {mode}: {wrong_elems} wrong elementwise results, {wrong_sums} wrong reductions, {wrong_other} wrong layer_norm/softmax/gelu elements"

@@ -159,48 +159,6 @@ def test_gemm_split_packed_result(M, N, K, tile):
     assert ((sp[:, :, 0, :] + sp[:, :, 1, :] * 2.0 ** -11).reshape(M, N) - plain).abs().max().item() < 2e-6
 
 
-@pytest.mark.parametrize("M,N,K,act,res,cpk", [
-    (69632, 1536, 512, 0, False, False),   # qkv at B = 256, C = 512
-    (69632, 512, 1024, 0, True, False),    # fc2 + residual
-    (69632, 1024, 512, 1, False, True),    # fc1: GELU, result written pre-split
-    (40000, 640, 256, 1, False, False),    # last row tile 64 of 192 rows, last column tile 128 of 256 columns
-    (50001, 1024, 128, 0, True, False),    # ragged M inside a wave's 64 rows, shortest K
-    (37000, 256, 256, 1, False, True),
-])
-def test_gemm_split_wave_specialised(M, N, K, act, res, cpk):
-    """gemm_split_ws.hip (12 compute + 4 loader waves, LDS progress words instead of barriers; an opt-in alternative to the 4-wave
-    kernel, tuning knob 3) computes the same bits as the 4-wave kernel - same per-accumulator order of the three products - run
-    after run, and no wave ever gives up on a hand-off."""
-    from pmce_amd import _lib, ops
-    lib = _lib.load()
-    A = rnd("gemm.A", (M, K)).to(dev())
-    A[::5] *= 1e-3
-    W = rnd("gemm.W", (N, K), scale=K ** -0.5).to(dev())
-    b = rnd("gemm.b", (N,)).to(dev())
-    R = rnd("gemm.R", (M, N)).to(dev()) if res else None
-    Wp, ws = ops.pack_split_f16(W)
-    Ap = ops.split_rows_f16(A)
-    run = lambda: ops.gemm_nt_split(Ap, Wp, ws, b, R, act, a_packed=True, c_packed=cpk)
-    try:
-        lib.pmce_gemm_split_set_tuning(0)
-        ref = run().clone()
-        lib.pmce_gemm_split_set_tuning(3)
-        outs = [run().clone() for _ in range(6)]
-    finally:
-        lib.pmce_gemm_split_set_tuning(-1)
-    assert lib.pmce_gemm_ws_timeouts() == 0
-    for o in outs:
-        assert torch.equal(o.view(torch.int32), outs[0].view(torch.int32))       # run to run
-    if not cpk:
-        assert torch.equal(outs[0].view(torch.int32), ref.view(torch.int32))     # and the 4-wave kernel's bits
-    else:   # (the packed-output instantiations' GELUs differ by an ulp in ~0.01 % of the elements, see test_gemm_split_packed_result)
-        def val(t):
-            pl = t.view(torch.float16).reshape(M, N // 16, 2, 16).float()
-            return (pl[:, :, 0, :] + pl[:, :, 1, :] * 2.0 ** -11).reshape(M, N)
-        assert (val(outs[0]) - val(ref)).abs().max().item() < 1e-6
-        assert int((outs[0].view(torch.int32) != ref.view(torch.int32)).sum()) <= outs[0].numel() // 1000
-
-
 def test_gemm_split_row_map():
     """GI0 form on the f16 pipe: A rows (b,t) -> C rows (t,b)."""
     from pmce_amd import _lib, ops
@@ -287,39 +245,6 @@ def test_seq_attention(C, J):
     pt = ops.seq_attention(qkv, B * J, Tn, C, J, 1, Tn * J, J, out_split=True)
     assert torch.equal(ps.view(torch.int32), ops.split_rows_f16(out_s).view(torch.int32))
     assert torch.equal(pt.view(torch.int32), ops.split_rows_f16(out_t).view(torch.int32))
-
-
-@pytest.mark.parametrize("M,N,K,act,res,cpk", [(4352, 1536, 512, 0, False, False), (5003, 512, 512, 0, True, False), (1000, 1024, 512, 1, False, True),
-                                               (4352, 256, 1024, 0, True, False), (777, 160, 128, 1, False, False), (40000, 768, 256, 0, False, False)])
-def test_gemm_split_16x16x32_shape(M, N, K, act, res, cpk):
-    """The opt-in kernel on v_mfma_f32_16x16x32_f16 (gemm_split_m16.hip: products concatenated along the instruction's K, W rows
-    permuted into LDS so that a lane owns adjacent columns): every element against an fp64 product next to the default kernel's
-    error on the same operands; edge tiles in M and N, residual, GELU, pre-split result; bitwise repeatable."""
-    from pmce_amd import _lib, ops
-    lib = _lib.load()
-    A = rnd("gemm.A", (M, K)).to(dev())
-    W = rnd("gemm.W", (N, K), scale=K ** -0.5).to(dev())
-    b = rnd("gemm.b", (N,)).to(dev())
-    R = rnd("gemm.R", (M, N)).to(dev()) if res else None
-    Wp, ws = ops.pack_split_f16(W)
-    Ap = ops.split_rows_f16(A)
-    ref = A.double() @ W.double().t() + b.double()
-    if act:
-        ref = torch.nn.functional.gelu(ref)
-    if res:
-        ref = ref + R.double()
-    base = ops.gemm_nt_split(Ap, Wp, ws, b, R, act, a_packed=True, c_packed=cpk)
-    lib.pmce_gemm_split_set_m16(2)
-    try:
-        out = ops.gemm_nt_split(Ap, Wp, ws, b, R, act, a_packed=True, c_packed=cpk)
-        again = ops.gemm_nt_split(Ap, Wp, ws, b, R, act, a_packed=True, c_packed=cpk)
-    finally:
-        lib.pmce_gemm_split_set_m16(0)
-    val = (lambda t: ops.unsplit_rows_f16(t) if cpk else t.double())
-    e, e0 = (val(out) - ref).abs().max().item(), (val(base) - ref).abs().max().item()
-    print(f"gemm 16x16x32 {M}x{N}x{K} act={act} res={res} packed_out={cpk}: {e:.2e} (32x32x16 kernel {e0:.2e})")
-    assert torch.equal(out.view(torch.int32), again.view(torch.int32))
-    assert e < 2e-5 and e <= 1.5 * e0 + 1e-7
 
 
 @pytest.mark.parametrize("C,J,B", [(512, 17, 2), (256, 17, 2), (512, 19, 1), (256, 19, 3), (512, 17, 37)])
@@ -466,10 +391,11 @@ def test_mfma_reads_f16_subnormals():
     """The f16 form of vertex_sa keeps the lo halves of k / v at their true magnitude: for |x| < 0.25 they are subnormal f16
     numbers.  The matrix pipe must read them as they are (a flush to zero would cost 2^-12 relative on those elements)."""
     from pmce_amd import _lib
-    lib = _lib.load()
+    from scripts.microbench import diag          # the probe kernel lives in the diagnostics library, not in the product
+    lib = diag.load()
     out = torch.zeros(2, device=dev())
     for a in (2.0 ** -20, 2.0 ** -24, 3 * 2.0 ** -24, 2.0 ** -14):
-        _lib.check(lib.pmce_dbg_mfma_subnormal(a, 1024.0, _lib.ptr(out), None), "dbg_mfma_subnormal")
+        diag.check(lib.pmce_dbg_mfma_subnormal(a, 1024.0, _lib.ptr(out), None), "dbg_mfma_subnormal")
         torch.cuda.synchronize()
         got, a16 = out.tolist()
         assert a16 == a and got == 16 * 1024.0 * a, (a, a16, got)
