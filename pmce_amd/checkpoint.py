@@ -78,17 +78,46 @@ def _reference_checkpoint_globals():
     return allowed
 
 
+_REF_GLOBALS = None     # built once: the allow-list does not change during a process
+
+
+def _safe_globals_ctx():
+    """Context manager that adds the allow-list to torch's restricted unpickler.  ``torch.serialization.safe_globals`` exists
+    since torch 2.5; torch 2.4 has the process-wide ``add_safe_globals`` only; older releases have neither and cannot read a
+    reference checkpoint with ``weights_only=True`` at all - that is said in so many words instead of surfacing as an
+    unpickling failure of a perfectly good file."""
+    global _REF_GLOBALS
+    if _REF_GLOBALS is None:
+        _REF_GLOBALS = _reference_checkpoint_globals()
+    ser = torch.serialization
+    if hasattr(ser, "safe_globals"):
+        return ser.safe_globals(_REF_GLOBALS)
+    if hasattr(ser, "add_safe_globals"):
+        import contextlib
+        ser.add_safe_globals(_REF_GLOBALS)
+        return contextlib.nullcontext()
+    raise RuntimeError(f"torch {torch.__version__} has no allow-list for the restricted unpickler (needs torch >= 2.4): a reference "
+                       "checkpoint (numpy scalars in its logs, a Counter in its scheduler state) can only be read with "
+                       "allow_pickle=True on this torch")
+
+
 def torch_load_checkpoint(path, map_location="cpu", allow_pickle=False):
     """torch.load that cannot execute code: ``weights_only=True`` with an allow-list of exactly the non-tensor objects the
     reference's own checkpoints contain (numpy scalars in the error logs, the scheduler's ``Counter`` - see
     :func:`_reference_checkpoint_globals`; without it a genuine ``best.pth.tar`` is rejected).  ``allow_pickle=True`` is the
-    explicit opt-in to the unrestricted unpickler for files that carry anything else."""
+    explicit opt-in to the unrestricted unpickler, used ONLY when the restricted one refused the file's contents
+    (``pickle.UnpicklingError``) or this torch has no allow-list - never to paper over an unrelated failure."""
+    import pickle
     try:
-        with torch.serialization.safe_globals(_reference_checkpoint_globals()):
+        ctx = _safe_globals_ctx()
+    except RuntimeError:
+        if not allow_pickle:
+            raise
+        return torch.load(path, map_location=map_location, weights_only=False)
+    try:
+        with ctx:
             return torch.load(path, map_location=map_location, weights_only=True)
-    except FileNotFoundError:
-        raise
-    except Exception:  # noqa: BLE001
+    except pickle.UnpicklingError:
         if not allow_pickle:
             raise
     return torch.load(path, map_location=map_location, weights_only=False)
@@ -101,7 +130,8 @@ def load_reference_checkpoint(path, map_location="cpu", allow_pickle=False):
     try:
         obj = torch_load_checkpoint(path, map_location, allow_pickle)
     except Exception as e:  # noqa: BLE001 - same contract as the reference
-        hint = "" if isinstance(e, FileNotFoundError) or allow_pickle else \
+        import pickle
+        hint = "" if not isinstance(e, pickle.UnpicklingError) or allow_pickle else \
             "  (the file exists but holds objects outside the tensors / numpy scalars / Counter a reference checkpoint contains; " \
             "allow_pickle=True loads it with the unrestricted unpickler)"
         raise ValueError(f"No checkpoint exists!\n{type(e).__name__}: {e}{hint}") from e

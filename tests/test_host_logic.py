@@ -244,6 +244,35 @@ def test_checkpoint_written_like_the_reference_training_loop(tmp_path):
     assert set(sd3) == set(lifter)
 
 
+def test_checkpoint_loader_on_a_torch_without_safe_globals(tmp_path, monkeypatch):
+    """torch < 2.5 has no ``torch.serialization.safe_globals``: the loader must use ``add_safe_globals`` (2.4) or say that this
+    torch cannot read a reference checkpoint restricted - not swallow an AttributeError into "the file holds objects outside ..."
+    and not fall through to the unrestricted unpickler for an unrelated failure."""
+    from pmce_amd import checkpoint
+    sd = cached_state_dict(17, 256)
+    lifter = {k[len("pose_lifter."):]: v for k, v in sd.items() if k.startswith("pose_lifter.")}
+    p = tmp_path / "pose.pth.tar"
+    torch.save({"epoch": 1, "model_state_dict": lifter, "test_log": [np.float64(1.5)]}, p)
+    ser = torch.serialization
+    monkeypatch.delattr(ser, "safe_globals")                 # "torch 2.4"
+    assert checkpoint.load_reference_checkpoint(str(p))[1] == "lifter"
+    monkeypatch.delattr(ser, "add_safe_globals")             # "torch < 2.4"
+    with pytest.raises(ValueError) as e:
+        checkpoint.load_reference_checkpoint(str(p))
+    assert "no allow-list" in str(e.value) and "holds objects outside" not in str(e.value)
+    assert checkpoint.load_reference_checkpoint(str(p), allow_pickle=True)[1] == "lifter"
+    monkeypatch.undo()
+    # an unrelated failure (a truncated file) is reported as what it is and never retried with the unrestricted unpickler
+    q = tmp_path / "cut.pth.tar"
+    q.write_bytes(p.read_bytes()[:2000])
+    calls = []
+    real = torch.load
+    monkeypatch.setattr(torch, "load", lambda *a, **k: (calls.append(k.get("weights_only")), real(*a, **k))[1])
+    with pytest.raises(ValueError):
+        checkpoint.load_reference_checkpoint(str(q), allow_pickle=True)
+    assert calls == [True]
+
+
 def test_workload_flops_agree_with_oracle_count():
     from oracle import pmce_oracle as O
     from pmce_amd.workload import flops_per_clip
