@@ -41,7 +41,7 @@ typedef struct ihipStream_t* pmce_stream_t; /* == hipStream_t */
 #define PMCE_ERR_ARG (-1)
 #define PMCE_ERR_LAUNCH (-2)
 #define PMCE_ERR_WORKSPACE (-3)
-#define PMCE_ERR_OVERFLOW (-4) /* an earlier call on the model produced non-finite values (see pmce_model_overflowed) */
+#define PMCE_ERR_OVERFLOW (-4) /* strict overflow policy only: an earlier call produced non-finite values (pmce_model_overflowed) */
 
 int pmce_version(void);
 const char* pmce_last_error_string(void);
@@ -95,14 +95,21 @@ int pmce_model_share_split_weights(pmce_model* dst, const pmce_model* src);
 /* Calls with fewer clips (windows) than this stay on the fp32 pipe even in split_f16 mode (default 1 = none do: the f16 form is
  * faster at every batch size; env PMCE_SPLIT_MIN_BATCH at create). */
 int pmce_model_set_split_min_batch(pmce_model* m, int clips);
-/* Range guard of the split_f16 form.  Its operands pass through f16 planes, so an activation with |a| > 65504 (or a genuine fp32
- * overflow) turns into inf / nan in that product's result; the products' epilogues notice a non-finite result and set a sticky
- * word in pinned host memory the model owns (no synchronisation to read it).  From then on every entry point of the model
- * returns PMCE_ERR_OVERFLOW BEFORE launching anything - the outputs of the call that overflowed (and of calls already in flight
- * behind it) are invalid - until pmce_model_clear_overflow.  pmce_model_overflowed reflects the device work that has completed:
- * synchronise the stream first for a definite answer about a given call.  The fp32 pipe (pmce_model_set_gemm_mode(m, 0)) has
- * fp32's own range and never sets the word for a finite result.  Pipeline lanes created with pmce_model_share_split_weights
- * share the source's word. */
+/* Range of the split_f16 form, and the word that reports leaving it.  The path's one RAW input that feeds products - img_feat -
+ * is stored per call as row-scaled f16 planes (pmce_split_rows_scaled_f16), so ANY finite fp32 input is computed with fp32-grade
+ * accuracy, exactly as the reference's Linear layers accept it (PoseEstimation.py:80, CoevoDecoder.py:228); every other product
+ * operand is the output of a LayerNorm / attention / GELU / GRU gate / AdaLN, whose magnitude the weights bound.  What remains:
+ * non-finite INPUTS (they propagate into the outputs of their own clip only, as in the reference) and intermediate activations
+ * beyond f16's 65504 under exotic weights - these turn into inf / nan, never into a wrong finite value, and every non-finite value
+ * of a forward reaches a product epilogue, which sets a word in pinned host memory the model owns (readable without
+ * synchronisation; sticky until pmce_model_clear_overflow).  pmce_model_overflowed reflects the device work that has completed:
+ * synchronise the stream first for a definite answer about a given call.  DEFAULT POLICY: the word only reports - calls are never
+ * refused, the model behaves like the reference (a bad clip yields nan, the next call is unaffected); pmce_amd's Pipeline /
+ * evaluator poll it when they drain and can re-run the offending batch on the fp32 pipe (pmce_model_set_gemm_mode(m, 0) /
+ * pmce_model_set_split_min_batch), which has fp32's own range.  STRICT policy (pmce_model_set_overflow_policy(m, 1), env
+ * PMCE_STRICT_OVERFLOW=1 at create): while the word is set every entry point returns PMCE_ERR_OVERFLOW before launching
+ * anything.  Pipeline lanes created with pmce_model_share_split_weights share the source's word. */
+int pmce_model_set_overflow_policy(pmce_model* m, int strict);
 int pmce_model_overflowed(const pmce_model* m);
 int pmce_model_clear_overflow(pmce_model* m);
 /* Bytes of caller-provided workspace needed for a batch of B clips. */
@@ -186,8 +193,9 @@ int pmce_gemm_set_tuning(int tile, int grid_per_cu);
  * of two per OUTPUT ROW n of W, chosen so that the row's largest |w| 2^s lies in [2^14, 2^15): an outlier row does not cost the
  * other rows' lo planes their bits), A is split into (hi, lo * 2^11) on the fly, C[m][n] = 2^-s(n) (Ahi Whi + Ahi Wlo + Alo Whi)
  * accumulated in fp32 - error at or below the fp32 product's own rounding.  A, bias, R, C stay fp32 and row-major (lda, ldc);
- * |A| must be below 65504 (an element outside the f16 range yields inf/nan, never a silently wrong finite value; inside a model
- * call such a result also sets the model's sticky overflow word, pmce_model_overflowed).
+ * |A| must be below 65504 here (an element outside the f16 range yields inf/nan, never a silently wrong finite value; raw inputs
+ * of arbitrary magnitude go through pmce_split_rows_scaled_f16 / pmce_gemm_nt_split_f16_rs below; inside a model call a non-finite
+ * result also sets the model's overflow word, pmce_model_overflowed).
  * MI355X: while a kernel that issues f16 matrix instructions runs, packed-fp32 vector arithmetic (v_pk_{fma,mul,add}_f32) of
  * any other wave on the same CU may return wrong results (scripts/microbench/libpmce_diag.so: pmce_dbg_victim reproduces it).  No kernel of this library contains
  * such instructions, so its entries may overlap each other freely; do not overlap these entries with foreign kernels that do. */
@@ -203,6 +211,14 @@ int pmce_gemm_nt_split_f16_ex(const float* A, const float* Wp, const float* wsca
  * writes (b,t) rows time-major). */
 int pmce_gemm_nt_split_f16_rowmap(const float* A, const float* Wp, const float* wscale, const float* bias, float* C, int M, int N,
                                   int K, long long lda, int c_div, long long c_lo, long long c_hi, pmce_stream_t stream);
+/* RAW inputs of any finite fp32 magnitude: pmce_split_rows_scaled_f16 stores row m of A[M][lda] as f16 (hi, lo * 2^11) planes of
+ * A[m] * 2^-e(m) (Ap: M*K floats of storage) and rscale[m] = 2^e(m), e(m) lifting the row's largest |a| into [2^14, 2^15) - the
+ * per-row treatment pmce_gemm_pack_split_f16 gives W.  pmce_gemm_nt_split_f16_rs multiplies such an A:
+ * C[m][n] = 2^e(m) 2^-s(n) (Ahi Whi + Ahi Wlo + Alo Whi) + bias[n]; c_div > 0 maps the output rows as in _rowmap (ldc == N then).
+ * Rows holding inf / nan keep e = 0 and yield non-finite results in their own row only. */
+int pmce_split_rows_scaled_f16(const float* A, long long M, int K, long long lda, float* Ap, float* rscale, pmce_stream_t stream);
+int pmce_gemm_nt_split_f16_rs(const float* Ap, const float* rscale, const float* Wp, const float* wscale, const float* bias, float* C,
+                              int M, int N, int K, long long ldc, int c_div, long long c_lo, long long c_hi, pmce_stream_t stream);
 /* a_packed != 0: A is not fp32 but already split, [M][K/16][hi 16 f16 | lo*2^11 16 f16] (the layout the lifter's own
  * producers write; pmce_split_rows_f16 makes it from fp32 rows). */
 int pmce_split_rows_f16(const float* A, long long M, int K, long long lda, float* Ap, pmce_stream_t stream);

@@ -47,6 +47,7 @@ PROTOTYPES = {
     "pmce_model_gemm_mode": [C.c_void_p],
     "pmce_model_share_split_weights": [C.c_void_p, C.c_void_p],
     "pmce_model_set_split_min_batch": [C.c_void_p, _i],
+    "pmce_model_set_overflow_policy": [C.c_void_p, _i],
     "pmce_model_overflowed": [C.c_void_p],
     "pmce_model_clear_overflow": [C.c_void_p],
     "pmce_model_profile_read": [C.c_void_p, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_longlong)],
@@ -55,6 +56,8 @@ PROTOTYPES = {
     "pmce_gemm_pack_split_f16": [_f, _i, _i, _i, _f, _f, _s],
     "pmce_gemm_nt_split_f16": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _l, _l, _i, _i, _s],
     "pmce_split_rows_f16": [_f, _l, _i, _l, _f, _s],
+    "pmce_split_rows_scaled_f16": [_f, _l, _i, _l, _f, _f, _s],
+    "pmce_gemm_nt_split_f16_rs": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _l, _i, _l, _l, _s],
     "pmce_gemm_nt_split_f16_ex": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _l, _l, _i, _i, _i, _s],
     "pmce_ln_chain_ex_f32": [_f, _l, _i, _f, _f, _fl, _f, _i, _i, _f, _f, _f, _fl, _f, _i, _s],
     "pmce_seq_attention_ex_f32": [_f, _f, _i, _i, _i, _i, _l, _l, _l, _i, _s],

@@ -10,6 +10,8 @@ struct SplitParams {
   const float* W;       // packed planes [N][K/16][16 hi | 16 lo] f16 of W[n] * 2^s(n)
   const float* wscale;  // [N]: 2^-s(n), one power of two per OUTPUT row of W (pmce_gemm_pack_split_f16)
   const float* bias;    // [N] or null
+  const float* rscale;  // [M] or null: 2^e(m) per ROW of a packed A that was stored as A[m] * 2^-e(m) (pmce_split_rows_scaled_f16): the
+                        // epilogue multiplies row m by it and adds the bias AFTER the scaling (RS instantiations)
   const float* R;       // residual [M][ldc] or null
   float* C;
   int M, N, K;

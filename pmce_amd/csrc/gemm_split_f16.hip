@@ -43,8 +43,11 @@ struct SplitCfg {
   static constexpr int DPW = (BM + BN) / 64;  // DMA instructions per wave per k-tile (16 rows each)
 };
 
-template <int TM, int TN, int ACT, bool RES, bool APACK, bool OPACK = false>
+// RS: A is packed AND row-scaled (raw inputs of any fp32 magnitude: imgfeat_embed, the GRU layer-0 input projection) - the
+// accumulators start at zero and the epilogue computes acc * 2^-s(n) * 2^e(m) + bias[n].
+template <int TM, int TN, int ACT, bool RES, bool APACK, bool OPACK = false, bool RS = false>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
+  static_assert(!RS || (APACK && !OPACK && !RES), "a row-scaled A is a packed A; no packed result, no residual");
   using Cfg = SplitCfg<TM, TN>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, WM = 32 * TM, WN = 32 * TN;
   constexpr int NS = Cfg::NS, SF = Cfg::STAGE_FLOATS, DPW = Cfg::DPW;
@@ -91,6 +94,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
   // bounded: lanes past bias[N-1] read zeros
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.N * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wscale), 0, p.N * 4, 0x00020000);
+  // RS: the tile's slice of row scales (bounded: rows past M - 1 read zeros; they are never stored)
+  const __amdgpu_buffer_rsrc_t rsrc_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.rscale), 0, RS ? p.M * 4 : 0, 0x00020000);
 
   // ---- DMA side.  Instruction q of a wave moves row group g = wave + 4 q of a stage: lane L -> row 16 g + (L >> 2), PHYSICAL
   // chunk L & 3, which holds logical chunk (L & 3) ^ ((row >> 2) & 3) = (L & 3) ^ ((L >> 4) & 3). ----
@@ -117,16 +122,15 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
   };
 
   // issue-side cursor (runs NS-1 k-tiles ahead of the compute side, across tile boundaries)
-  int i_li = bx, i_kt = 0, i_stage = 0, issued = 0, i_nb = 0, i_par = 0;
-  {
-    int mb;
-    tile_coords(chunk_start + i_li, mb, i_nb);
-    set_ptrs(mb, i_nb);
-  }
+  int i_li = bx, i_kt = 0, i_stage = 0, issued = 0, i_nb = 0, i_mb = 0, i_par = 0;
+  tile_coords(chunk_start + i_li, i_mb, i_nb);
+  set_ptrs(i_mb, i_nb);
   auto issue_next = [&]() {
     if (i_kt == 0) {  // the tile's bias and 2^-s slices: 64 lanes x 4 floats each
       if (p.bias && wave == 0) sdma16(rsrc_b, (unsigned)lane * 16u, i_nb * 4, lds0 + NS * SF * 4 + i_par * 2048);
       if (wave == 1) sdma16(rsrc_s, (unsigned)lane * 16u, i_nb * 4, lds0 + NS * SF * 4 + i_par * 2048 + 1024);
+      if constexpr (RS)  // and its BM row scales (behind the two slice pairs)
+        if (wave == 2) sdma16(rsrc_rs, (unsigned)lane * 16u, i_mb * 4, lds0 + NS * SF * 4 + 4096 + i_par * 1024);
       i_par ^= 1;
     }
     issue(i_kt, i_stage);
@@ -136,9 +140,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
       i_kt = 0;
       i_li += gx;
       if (i_li < chunk_len) {
-        int mb;
-        tile_coords(chunk_start + i_li, mb, i_nb);
-        set_ptrs(mb, i_nb);
+        tile_coords(chunk_start + i_li, i_mb, i_nb);
+        set_ptrs(i_mb, i_nb);
       }
     }
   };
@@ -147,6 +150,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
     if (issued < total) issue_next();
 
   float w_down[TN];  // 2^-s of this lane's column in each of the wave's TN 32-column blocks
+  float b_late[TN];  // RS: the bias of this lane's columns, added after the row scaling
   const int swz = (n0 >> 2) & 3;
   const int a_row = (wm * WM + n0) * 16, w_row = BM * 16 + (wn * WN + n0) * 16;  // floats inside a stage
   // chunk offsets (floats) of this lane's operand fragments
@@ -174,7 +178,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         w_down[j] = sB[256 + j * 32];
-        const float bv = p.bias ? sB[j * 32] * pow2_recip(w_down[j]) : 0.f;
+        if constexpr (RS) b_late[j] = p.bias ? sB[j * 32] : 0.f;
+        const float bv = (p.bias && !RS) ? sB[j * 32] * pow2_recip(w_down[j]) : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -220,6 +225,35 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
       // ---- epilogue of the finished tile, straight from the accumulators ----
       kt = 0;
       bool bad = false;  // this lane produced a non-finite value (an operand beyond the f16 range, or fp32 overflow)
+      if constexpr (RS) {
+        // Row-scaled A: C[m][n] = acc * 2^-s(n) * 2^e(m) + bias[n].  2^e of the tile's rows landed with the tile's first k-tile
+        // (c_par has moved on to the next tile's parity since).  Row-major over the accumulators - one row scale at a time serves
+        // the TN column blocks - so the epilogue holds no table of scales in registers.
+        const float* sR = lds + NS * SF + 1024 + (c_par ^ 1) * 256 + wm * WM + 4 * hb;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2);
+            const int mm = m_base + wm * WM + i * 32 + 4 * hb + rr;
+            const float up = sR[i * 32 + rr];
+            if (mm < p.M) {
+              float* crow = p.c_div > 0 ? p.C + (long long)(mm % p.c_div) * p.c_lo + (long long)(mm / p.c_div) * p.c_hi
+                                        : p.C + (size_t)mm * p.ldc;
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                const int n = n_base + wn * WN + j * 32 + n0;
+                const float v = fmaf(acc[i][j][r] * w_down[j], up, b_late[j]);
+                bad = bad || nonfinite(v);
+                if (n < p.N) __builtin_nontemporal_store(v, crow + n);
+              }
+            }
+          }
+        report_nonfinite(p.oflow, bad);
+        li += gx;
+        if (li < chunk_len) tile_coords(chunk_start + li, m_base, n_base);
+        continue;
+      }
       if constexpr (OPACK) {
         // The result is itself the A operand of the next product (fc1 -> fc2): written pre-split, [row][K/16][16 hi | 16 lo*2^11]
         // f16 in the bytes of the fp32 row.  A lane holds ONE column of 16 rows; adjacent lanes pair up (DPP quad_perm) so that
@@ -333,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {  // the same arithmetic as the full-tile path (results do not depend on tile shape)
               f32x2 v = {acc[i][j][r] * w_down[j], acc[i][j][r + 1] * w_down[j]};
-              if (ACT == 1) v = gelu_erf2(v);
+                if (ACT == 1) v = gelu_erf2(v);
 #pragma unroll
               for (int e = 0; e < 2; ++e) {
                 const int rr = ((r + e) & 3) + 8 * ((r + e) >> 2);
@@ -376,13 +410,14 @@ extern "C" int pmce_gemm_split_set_tuning(int tile) {
   return PMCE_OK;
 }
 
-template <int TM, int TN, int ACT, bool RES, bool APACK, bool OPACK = false>
+template <int TM, int TN, int ACT, bool RES, bool APACK, bool OPACK = false, bool RS = false>
 static int launch_one(const SplitParams& p, int grid, hipStream_t stream) {
   using Cfg = SplitCfg<TM, TN>;
   static std::atomic<unsigned long long> done{0};
-  PMCE_TRY(pmce_opt_in_lds(reinterpret_cast<const void*>(&gemm_split_kernel<TM, TN, ACT, RES, APACK, OPACK>), Cfg::LDS_BYTES, done,
+  constexpr int LDS = Cfg::LDS_BYTES + (RS ? 2048 : 0);  // + two slices of BM row scales
+  PMCE_TRY(pmce_opt_in_lds(reinterpret_cast<const void*>(&gemm_split_kernel<TM, TN, ACT, RES, APACK, OPACK, RS>), LDS, done,
                            "gemm_split_f16"));
-  hipLaunchKernelGGL((gemm_split_kernel<TM, TN, ACT, RES, APACK, OPACK>), dim3(grid), dim3(256), Cfg::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm_split_kernel<TM, TN, ACT, RES, APACK, OPACK, RS>), dim3(grid), dim3(256), LDS, stream, p);
   return PMCE_OK;
 }
 template <int TM, int TN>
@@ -395,6 +430,7 @@ static int launch_cfg(SplitParams& p, int act, bool apack, bool opack, hipStream
   if (g > 256 * per_cu) g = 256 * per_cu;
   g = (g + 7) & ~7;
   const bool res = p.R != nullptr;
+  if (p.rscale) return launch_one<TM, TN, 0, false, true, false, true>(p, g, stream);  // raw-input products: packed, row-scaled A
   if (opack) return launch_one<TM, TN, 1, false, true, true>(p, g, stream);  // fc1 of the lifter: GELU, packed in, packed out
   if (apack) {
     if (act == 1) return res ? launch_one<TM, TN, 1, true, true>(p, g, stream) : launch_one<TM, TN, 1, false, true>(p, g, stream);
@@ -426,7 +462,7 @@ static int pick_split_tile(int M, int N) {
 
 static int gemm_split_any(const float* A, const float* Wp, const float* wscale, const float* bias, const float* R, float* C, int M,
                           int N, int K, long long lda, long long ldc, int act, int a_packed, int c_packed, int c_div,
-                          long long c_lo, long long c_hi, hipStream_t stream) {
+                          long long c_lo, long long c_hi, hipStream_t stream, const float* rscale = nullptr) {
   PMCE_REQUIRE(A && Wp && wscale && C, "gemm_split: null pointer");
   PMCE_REQUIRE(M > 0 && N > 0 && K >= 32 && K % 16 == 0, "gemm_split: need M,N>0, K>=32 and K%%16==0 (got M=%d N=%d K=%d)", M, N, K);
   PMCE_REQUIRE(act == 0 || act == 1, "gemm_split: act must be 0 or 1");
@@ -438,8 +474,10 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
   PMCE_REQUIRE(c_div == 0 || R == nullptr, "gemm_split: a C row map cannot be combined with a residual");
   PMCE_REQUIRE(!c_packed || (a_packed && act == 1 && R == nullptr && c_div == 0 && N % 32 == 0 && ldc == N),
                "gemm_split: a packed result is supported for the packed-A + GELU form with N %% 32 == 0 and ldc == N");
+  PMCE_REQUIRE(!rscale || (a_packed && !c_packed && act == 0 && R == nullptr && K >= 64),
+               "gemm_split: a row-scaled A is a packed A with K >= 64; no activation, residual or packed result");
   SplitParams p;
-  p.A = A; p.W = Wp; p.wscale = wscale; p.bias = bias; p.R = R; p.C = C;
+  p.A = A; p.W = Wp; p.wscale = wscale; p.bias = bias; p.R = R; p.C = C; p.rscale = rscale;
   p.M = M; p.N = N; p.K = K; p.lda = (unsigned)lda; p.ldc = (unsigned)ldc;
   p.c_div = c_div; p.c_lo = c_lo; p.c_hi = c_hi;
   p.oflow = pmce_overflow_sink();
@@ -471,6 +509,16 @@ extern "C" int pmce_gemm_nt_split_f16_rowmap(const float* A, const float* Wp, co
                                              hipStream_t stream) {
   PMCE_REQUIRE(c_div > 0, "gemm_split_rowmap: c_div must be positive");
   return gemm_split_any(A, Wp, wscale, bias, nullptr, C, M, N, K, lda, N, 0, 0, 0, c_div, c_lo, c_hi, stream);
+}
+
+// Raw inputs (any finite fp32 magnitude): Ap / rscale from pmce_split_rows_scaled_f16.  C[m][n] = 2^e(m) 2^-s(n) (Ahi Whi + Ahi Wlo +
+// Alo Whi) + bias[n]; c_div > 0 maps the output rows like pmce_gemm_nt_split_f16_rowmap (ldc = N then).
+extern "C" int pmce_gemm_nt_split_f16_rs(const float* Ap, const float* rscale, const float* Wp, const float* wscale, const float* bias,
+                                         float* C, int M, int N, int K, long long ldc, int c_div, long long c_lo, long long c_hi,
+                                         hipStream_t stream) {
+  PMCE_REQUIRE(rscale, "gemm_split_rs: null rscale");
+  PMCE_REQUIRE(c_div >= 0 && (c_div == 0 || ldc == N), "gemm_split_rs: a row map needs ldc == N");
+  return gemm_split_any(Ap, Wp, wscale, bias, nullptr, C, M, N, K, K, ldc, 0, 1, 0, c_div, c_lo, c_hi, stream, rscale);
 }
 
 // ---- operand packing ------------------------------------------------------------------------------------------------------
@@ -529,4 +577,50 @@ extern "C" int pmce_split_rows_f16(const float* A, long long M, int K, long long
   hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, stream, A, M, K, lda,
                      reinterpret_cast<_Float16*>(Ap));
   return pmce_check_launch("split_rows_f16");
+}
+
+// Raw input rows of ANY finite fp32 magnitude -> packed planes of A[m] * 2^-e(m) plus rscale[m] = 2^e(m): e(m) puts the row's
+// max |a| into [2^14, 2^15) (exactly what pmce_gemm_pack_split_f16 does for a weight row), so neither a feature of 1e5 (beyond f16's
+// 65504) nor one of 1e-7 (whose planes would be f16 sub-normals) loses anything: both planes are normal f16 numbers for every
+// element within 2^-17 of its row's largest.  The reference's Linear accepts any fp32 row (PoseEstimation.py:80,
+// CoevoDecoder.py:228); so does this.  Rows holding inf / nan keep scale 1 and propagate as non-finite results of their own row
+// only, like the reference's.  One wave per row; K % 16 == 0.
+__global__ __launch_bounds__(256) void split_rows_scaled_kernel(const float* __restrict__ A, long long M, int K, long long lda,
+                                                                _Float16* __restrict__ Ap, float* __restrict__ rscale) {
+  const int lane = threadIdx.x & 63;
+  for (long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (long long)gridDim.x * 4) {
+    const float* __restrict__ row = A + m * lda;
+    float mx = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(row + k);
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    mx = wave_max(mx);  // (fmaxf drops NaNs: a row with a NaN and finite values is scaled by its finite maximum, the NaN stays a NaN)
+    int e = 0;
+    if (mx > 0.f && mx < 3.0e38f) frexpf(mx, &e);  // mx = f * 2^e, f in [0.5, 1)
+    e = max(-110, min(e, 125));
+    const bool scaled = mx > 0.f && mx < 3.0e38f;
+    const float down = scaled ? ldexpf(1.f, 15 - e) : 1.f, up = scaled ? ldexpf(1.f, e - 15) : 1.f;
+    if (lane == 0) rscale[m] = up;
+    _Float16* __restrict__ out = Ap + m * K * 2;
+    for (int k = lane * 4; k < K; k += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(row + k);
+      const float a[4] = {pinned(v.x * down), pinned(v.y * down), pinned(v.z * down), pinned(v.w * down)};  // ONE fp32 value for both planes
+      f16x4 hi, lo;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) hi[i] = (_Float16)a[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lo[i] = (_Float16)((a[i] - (float)hi[i]) * 2048.0f);
+      _Float16* q = out + (k >> 4) * 32 + (k & 15);
+      *reinterpret_cast<f16x4*>(q) = hi;
+      *reinterpret_cast<f16x4*>(q + 16) = lo;
+    }
+  }
+}
+extern "C" int pmce_split_rows_scaled_f16(const float* A, long long M, int K, long long lda, float* Ap, float* rscale, hipStream_t stream) {
+  PMCE_REQUIRE(A && Ap && rscale && M > 0 && K > 0 && K % 16 == 0 && lda >= K && lda % 4 == 0, "split_rows_scaled: bad arguments");
+  const long long want = (M + 3) / 4;
+  hipLaunchKernelGGL(split_rows_scaled_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, stream, A, M, K, lda,
+                     reinterpret_cast<_Float16*>(Ap), rscale);
+  return pmce_check_launch("split_rows_scaled_f16");
 }

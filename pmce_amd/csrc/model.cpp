@@ -120,6 +120,7 @@ struct pmce_model {
   // (hipHostMalloc, mapped), so that reading it costs no synchronisation.  Set by the split-f16 products' epilogues (an activation
   // beyond f16's 65504 turns into inf / nan there, and so does fp32 overflow), checked by every entry point BEFORE it launches.
   std::shared_ptr<unsigned> oflow;  // shared by handles cloned onto the same weights (pipeline lanes): one model, one flag
+  bool strict_overflow = false;     // pmce_model_set_overflow_policy: refuse further calls while the word is set
   // regressor (optional)
   const int* jr_indptr = nullptr;
   const int* jr_indices = nullptr;
@@ -309,6 +310,7 @@ struct Carver {
 
 struct LifterWs {
   float *E, *X, *XN, *QKV, *AO;
+  float *FS, *FR;  // split mode: the raw image features as row-scaled f16 planes [frames][2048] + 2^e per frame (prep_features)
 };
 struct DecoderWs {
   float *GI0, *Y0, *GI1, *Y1, *GB, *VT[3], *JF[3], *XK[3], *KF[3], *S0[3], *VF[3], *F1, *F2, *QKV, *KVJ, *FA, *JM;
@@ -321,6 +323,8 @@ void carve_lifter(Carver& c, const pmce_model* m, int B, LifterWs& w) {
   w.XN = c.take(M * C);
   w.QKV = c.take(M * 3 * C);  // also the MLP hidden [M,2C]
   w.AO = c.take(M * C);
+  w.FS = c.take((size_t)B * T * F);
+  w.FR = c.take((size_t)B * T);
 }
 void carve_decoder(Carver& c, const pmce_model* m, int B, DecoderWs& w) {
   w.GI0 = c.take((size_t)T * B * 6 * GH);
@@ -395,13 +399,27 @@ int lifter_block_body(pmce_model* m, int kind, int i, long long M, int nframes, 
   return PMCE_OK;
 }
 
+// Split mode: the image features are the path's one RAW input that feeds products (imgfeat_embed, PoseEstimation.py:80; the GRU's
+// layer-0 input projection, CoevoDecoder.py:228) - every other product operand is a LayerNorm / attention / GELU / GRU output.  The
+// reference's Linear takes any fp32 value, so they are stored once per call as f16 planes of row * 2^-e(row) with 2^e per row
+// (pmce_split_rows_scaled_f16): features of 1e5 or 1e-7 magnitude keep fp32-grade accuracy, and both products read pre-split
+// operands (no split work in their k-loops).  Must run before the two branches fork.
+int prep_features(pmce_model* m, const float* img_feat, int nframes, LifterWs& w, hipStream_t stream) {
+  if (!m->split_now) return PMCE_OK;
+  RUN(P_MISC, pmce_split_rows_scaled_f16(img_feat, nframes, F, F, w.FS, w.FR, stream));
+  return PMCE_OK;
+}
+
 // embedding + SpatialBlocks[0] over `nframes` frames; leaves the block output (before norm_s) in w.X
 int lifter_frames(pmce_model* m, const float* pose2d, const float* img_feat, int nframes, LifterWs& w, hipStream_t stream) {
   const int J = m->J, C = m->C;
   const long long M = (long long)nframes * J;
   PMCE_REQUIRE(M < (1ll << 31), "lifter: too many tokens");
-  RUN(P_GEMM_LIFTER, lgemm(m, img_feat, m->w.ie_w, m->s_ie, m->w.ie_b, nullptr, w.E,
-                          nframes, C, F, F, C, 0, stream));
+  if (m->split_now && m->s_ie.wp)
+    RUN(P_GEMM_LIFTER, pmce_gemm_nt_split_f16_rs(w.FS, w.FR, m->s_ie.wp, m->s_ie.scale, m->w.ie_b, w.E, nframes, C, F, C, 0, 0, 0, stream));
+  else
+    RUN(P_GEMM_LIFTER, lgemm(m, img_feat, m->w.ie_w, m->s_ie, m->w.ie_b, nullptr, w.E,
+                            nframes, C, F, F, C, 0, stream));
   RUN(P_EMBED, pmce_embed_tokens_f32(pose2d, w.E, m->w.je_w, m->w.je_b,
                                      m->w.spos, w.X, M, J, C, stream));
   RUN(P_LN, pmce_ln_chain_ex_f32(w.X, M, C, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr,
@@ -496,12 +514,13 @@ int gru_layer(pmce_model* m, int layer, const float* gi_f, const float* gi_b, lo
 // recurrences + AdaLN parameters, given the layer-0 input projections GI0 (time-major [t][b][6144])
 int gru_rest(pmce_model* m, int B, DecoderWs& w, hipStream_t stream);
 
-int gru_part(pmce_model* m, const float* img_feat, int B, DecoderWs& w, hipStream_t stream) {
+int gru_part(pmce_model* m, const float* img_feat, const LifterWs& lw, int B, DecoderWs& w, hipStream_t stream) {
   // ---- bi-GRU over the 16 frames (CoevoDecoder.py:228); buffers are time-major [t][b][.] ----
   // layer 0 input projections for both directions in one product: rows (b,t) of img_feat -> rows (t,b) of GI0
+  // (split mode: from the row-scaled planes of prep_features)
   if (m->split_now && m->s_wih0.wp)
-    RUN(P_GEMM_GRU_IN, pmce_gemm_nt_split_f16_rowmap(img_feat, m->s_wih0.wp, m->s_wih0.scale, m->w.bih0, w.GI0, B * T, 6 * GH, F,
-                                                     F, T, (long long)B * 6 * GH, 6 * GH, stream));
+    RUN(P_GEMM_GRU_IN, pmce_gemm_nt_split_f16_rs(lw.FS, lw.FR, m->s_wih0.wp, m->s_wih0.scale, m->w.bih0, w.GI0, B * T, 6 * GH, F, 6 * GH,
+                                                 T, (long long)B * 6 * GH, 6 * GH, stream));
   else
     RUN(P_GEMM_GRU_IN, pmce_gemm_nt_f32(img_feat, m->w.wih0, m->w.bih0, nullptr, w.GI0, B * T,
                                         6 * GH, F, F, F, 6 * GH, 0, 0, 0, 0, T, (long long)B * 6 * GH, 6 * GH, 1, 0, 0, 0, 0,
@@ -802,6 +821,7 @@ int pmce_model_create(int num_joint, int embed_dim, int depth, pmce_model** out)
   m->ffn_f16 = pmce_env_int("PMCE_FFN_F16", 1) != 0;
   m->attn_f16 = pmce_env_int("PMCE_ATTN_F16", 1) != 0;
   m->split_overlap = pmce_env_int("PMCE_SPLIT_OVERLAP", 1) != 0;
+  m->strict_overflow = pmce_env_int("PMCE_STRICT_OVERFLOW", 0) != 0;
   build_names(m);
   *out = m;
   return PMCE_OK;
@@ -937,6 +957,11 @@ int pmce_model_clear_overflow(pmce_model* m) {
   *reinterpret_cast<volatile unsigned*>(m->oflow.get()) = 0u;
   return PMCE_OK;
 }
+int pmce_model_set_overflow_policy(pmce_model* m, int strict) {
+  PMCE_REQUIRE(m, "model_set_overflow_policy: null model");
+  m->strict_overflow = strict != 0;
+  return PMCE_OK;
+}
 int pmce_model_set_split_min_batch(pmce_model* m, int clips) {
   PMCE_REQUIRE(m && clips >= 1, "model_set_split_min_batch: need a model and clips >= 1");
   m->split_min_batch = clips;
@@ -985,10 +1010,11 @@ struct SinkGuard {  // the launchers of this thread report to the model's flag o
 
 static int check_ws(pmce_model* m, int batch, void* ws, size_t ws_bytes) {
   PMCE_REQUIRE(m && m->finalized, "model not finalized (call pmce_model_finalize after registering all tensors)");
-  if (m->oflow && *reinterpret_cast<volatile unsigned*>(m->oflow.get()) != 0u) {
-    pmce_set_error("an earlier call on this model produced non-finite values in a product of the split-f16 form (an activation beyond "
-                   "the f16 range, |a| > 65504, or fp32 overflow): its outputs are invalid.  pmce_model_clear_overflow re-arms the "
-                   "model; pmce_model_set_gemm_mode(m, 0) computes on the fp32 matrix pipe, which has fp32's range");
+  if (m->strict_overflow && m->oflow && *reinterpret_cast<volatile unsigned*>(m->oflow.get()) != 0u) {
+    pmce_set_error("strict overflow policy: an earlier call on this model produced non-finite values in a product of the split-f16 form "
+                   "(non-finite inputs, an intermediate activation beyond the f16 range |a| > 65504, or fp32 overflow).  "
+                   "pmce_model_clear_overflow re-arms the model; pmce_model_set_gemm_mode(m, 0) computes on the fp32 matrix pipe, which "
+                   "has fp32's range");
     return PMCE_ERR_OVERFLOW;
   }
   PMCE_REQUIRE(batch > 0, "batch must be positive");
@@ -1011,6 +1037,7 @@ int pmce_lifter_forward(pmce_model* m, const float* pose2d, const float* img_fea
   Carver c(ws, ws_bytes);
   LifterWs lw;
   carve_lifter(c, m, batch, lw);
+  PMCE_TRY(prep_features(m, img_feat, batch * T, lw, stream));
   return lifter_impl(m, pose2d, img_feat, pose3d, batch, lw, stream);
 }
 
@@ -1025,7 +1052,8 @@ int pmce_decoder_forward(pmce_model* m, const float* joints, const float* img_fe
   DecoderWs dw;
   carve_lifter(c, m, batch, lw);
   carve_decoder(c, m, batch, dw);
-  PMCE_TRY(gru_part(m, img_feat, batch, dw, stream));
+  PMCE_TRY(prep_features(m, img_feat, batch * T, lw, stream));
+  PMCE_TRY(gru_part(m, img_feat, lw, batch, dw, stream));
   if (two_streams(m)) PMCE_TRY(ensure_side(m));
   const int rc = coevo_part(m, joints, cam_pose, cam_mesh, batch, dw, stream, two_streams(m) ? m->side : nullptr);
   return rc == PMCE_OK ? rc : fail_after_fork(m, stream, rc);
@@ -1059,13 +1087,14 @@ static int forward_impl(pmce_model* m, const float* pose2d, const float* img_fea
   // under the pose lifter, whose long matrix-core kernels leave the gaps its 25 short dependent steps need.
   // pmce_model_set_concurrency(m, 0) (or PMCE_SINGLE_STREAM=1 at create time) keeps everything on one stream.
   const bool single = !two_streams(m);
+  PMCE_TRY(prep_features(m, img_feat, batch * T, lw, stream));  // read by both branches
   if (!single) {
     PMCE_TRY(ev_record(m->ev_fork, stream, "forward fork"));
     PMCE_TRY(ev_wait(m->side, m->ev_fork, "forward fork"));
-    PMCE_TRY(gru_part(m, img_feat, batch, dw, m->side));
+    PMCE_TRY(gru_part(m, img_feat, lw, batch, dw, m->side));
     PMCE_TRY(ev_record(m->ev_join, m->side, "forward join"));
   } else {
-    PMCE_TRY(gru_part(m, img_feat, batch, dw, stream));
+    PMCE_TRY(gru_part(m, img_feat, lw, batch, dw, stream));
   }
   PMCE_TRY(lifter_impl(m, pose2d, img_feat, pose3d, batch, lw, stream));
   // pose3d.reshape(-1, J, 3) / 1000  (PMCE.py:17-18)
@@ -1114,12 +1143,16 @@ int pmce_stream_precompute(pmce_model* m, const float* pose2d_frames, const floa
   LifterWs lw;
   carve_lifter(c, m, bf, lw);
   // window-independent lifter work: embedding + SpatialBlocks[0] + norm_s, once per frame (PoseEstimation.py:78-85)
+  PMCE_TRY(prep_features(m, feat_frames, L, lw, stream));
   PMCE_TRY(lifter_frames(m, pose2d_frames, feat_frames, L, lw, stream));
   RUN(P_LN, pmce_ln_chain_f32(lw.X, (long long)L * m->J, m->C, m->w.ns_w, m->w.ns_b, 1e-6f,
                               nullptr, 1, 1, x0, nullptr, nullptr, 0.f, nullptr, stream));
   // window-independent GRU work: layer-0 input projections of both directions, once per frame (CoevoDecoder.py:216-221)
-  RUN(P_GEMM_GRU_IN, lgemm(m, feat_frames, m->w.wih0, m->s_wih0, m->w.bih0, nullptr, gi0, L, 6 * GH, F, F, 6 * GH,
-                           0, stream));
+  if (m->split_now && m->s_wih0.wp)
+    RUN(P_GEMM_GRU_IN, pmce_gemm_nt_split_f16_rs(lw.FS, lw.FR, m->s_wih0.wp, m->s_wih0.scale, m->w.bih0, gi0, L, 6 * GH, F, 6 * GH, 0, 0, 0, stream));
+  else
+    RUN(P_GEMM_GRU_IN, lgemm(m, feat_frames, m->w.wih0, m->s_wih0, m->w.bih0, nullptr, gi0, L, 6 * GH, F, F, 6 * GH,
+                             0, stream));
   return PMCE_OK;
 }
 

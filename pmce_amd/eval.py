@@ -9,8 +9,9 @@
 
 Kernels: csrc/metrics.hip through the C ABI.  torch is used for allocation and the final few-float reductions only.  Those
 reductions (fp64 sums, cat / stack) may run while pipeline lanes are computing the next batches: torch kernels of exactly these
-kinds are checked bit-correct beside forwards of both product modes on every run of the GPU suite
-(tests/test_gpu_bystander.py).
+kinds are ASSERTED bit-correct beside forwards of both product modes on every run of the GPU suite
+(tests/test_gpu_bystander.py, part 2).  Clips whose predictions are not finite (non-finite inputs; see
+``PMCE.overflowed``) are counted and named in the result (``nonfinite_samples``) instead of silently poisoning the means.
 """
 from __future__ import annotations
 
@@ -127,7 +128,15 @@ class Evaluator:
         acc = self.accel(allj[:, :self.n_eval].contiguous(), allj[:, self.n_eval:].contiguous(), seq_ids_global)
         n = float(tot[3].item())
         return {"MPVPE": float(tot[0].item()) / n, "MPJPE": float(tot[1].item()) / n, "PA-MPJPE": float(tot[2].item()) / n,
-                "ACCEL": float(acc.double().sum().item()) / n, "samples": int(n)}
+                "ACCEL": float(acc.double().sum().item()) / n, "samples": int(n), **_nonfinite_report(mv, mj, pa, lo)}
+
+
+def _nonfinite_report(mv, mj, pa, lo):
+    """Which of this rank's clips carry non-finite errors (their predictions were inf / nan): count + the first global indices."""
+    bad = ~(torch.isfinite(mv) & torch.isfinite(mj) & torch.isfinite(pa))
+    nb = int(bad.sum().item())
+    idx = (bad.nonzero().flatten()[:16] + lo).tolist() if nb else []
+    return {"nonfinite_samples": nb, "nonfinite_first_indices": idx}
 
 
 class RunningEval:
@@ -165,4 +174,4 @@ class RunningEval:
         acc = ev.accel(allj[:, :ev.n_eval].contiguous(), allj[:, ev.n_eval:].contiguous(), seq)
         n = float(tot[3].item())
         return {"MPVPE": float(tot[0].item()) / n, "MPJPE": float(tot[1].item()) / n, "PA-MPJPE": float(tot[2].item()) / n,
-                "ACCEL": float(acc.double().sum().item()) / n, "samples": int(n)}
+                "ACCEL": float(acc.double().sum().item()) / n, "samples": int(n), **_nonfinite_report(mv, mj, pa, lo)}

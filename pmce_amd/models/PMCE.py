@@ -74,6 +74,34 @@ class PMCE(HipModuleBase):
         """(cam_mesh, cam_pose, pose3d, pred_pose_mm) — the forward plus the caller's tail of Tester.test."""
         return self._run(pose2d, img_feat, True)
 
+    @torch.no_grad()
+    def forward_checked(self, pose2d, img_feat, want_joints: bool = False):
+        """``forward`` / ``forward_with_joints`` that WAITS for its result and never returns values spoilt by the f16 range: if a
+        product of the split-f16 form reported a non-finite value (possible only with non-finite inputs or with weights that drive an
+        intermediate activation beyond 65504), the batch is run again on the fp32 matrix pipe - the reference's own range - and the
+        word is cleared.  Returns (outputs, reran).  Non-finite INPUTS still give non-finite outputs for their clips, as in the
+        reference."""
+        eng = self._ensure_packed()
+        want = want_joints and eng.regressor_rows > 0
+        out = self._run(pose2d, img_feat, want)
+        torch.cuda.synchronize(eng.device)
+        if not eng.overflowed():
+            return (out if want_joints else out[:3]), False
+        eng.clear_overflow()
+        out = self._run_on_f32_pipe(pose2d, img_feat, want, eng)
+        torch.cuda.synchronize(eng.device)
+        return (out if want_joints else out[:3]), True
+
+    def _run_on_f32_pipe(self, pose2d, img_feat, want, eng):
+        """One call of `eng` with every product on the fp32 matrix pipe (the planes stay packed: the threshold below which calls
+        stay on the fp32 pipe is raised above this batch for the duration of the call)."""
+        prev = eng.split_min_batch if eng.split_min_batch is not None else 1
+        eng.set_split_min_batch(int(pose2d.shape[0]) + 1)
+        try:
+            return self._run(pose2d, img_feat, want, eng)
+        finally:
+            eng.set_split_min_batch(prev)
+
     # benchmarking hooks
     def set_concurrency(self, enable=True):
         """Two-stream execution of independent branches inside one forward (default on)."""
@@ -151,8 +179,8 @@ class Pipeline:
     """
 
     class Ticket:
-        def __init__(self, outputs, done):
-            self.outputs, self.done = outputs, done
+        def __init__(self, outputs, done, index=-1, inputs=None, lane=0):
+            self.outputs, self.done, self.index, self.inputs, self.lane = outputs, done, index, inputs, lane
 
         def result(self):
             cur = torch.cuda.current_stream(self.outputs[0].device)
@@ -169,6 +197,9 @@ class Pipeline:
         self.model, self.depth = model, depth
         self.engines, self.streams, self._main = [], [], None
         self.k = 0
+        import collections
+        self._recent = collections.deque(maxlen=4 * depth)   # tickets a drain can still check / re-run (bounded: no leak in long loops)
+        self.reran = []                                       # indices of batches a drain re-ran on the fp32 pipe
         self._bind()
 
     def _bind(self):
@@ -207,7 +238,9 @@ class Pipeline:
             img_feat.record_stream(st)
             done = torch.cuda.Event()
             done.record(st)
-        return Pipeline.Ticket(out, done)
+        t = Pipeline.Ticket(out, done, self.k - 1, (pose2d, img_feat, want_joints), lane)
+        self._recent.append(t)
+        return t
 
     def prepare(self, batch: int):
         """One-time setup of every lane for ``batch`` clips, so that no lane pays it at its first real submit: workspace
@@ -227,9 +260,41 @@ class Pipeline:
         self.prev = None
         return self
 
-    def synchronize(self):
+    def synchronize(self, on_overflow: str = "rerun"):
+        """Wait for every lane, then poll the model's overflow word (nothing used to).  If a product reported a
+        non-finite value, the recent batches (the last 4 x depth submits) whose outputs are not finite are named in a warning
+        and - ``on_overflow="rerun"`` - computed again on the fp32 matrix pipe INTO THE SAME OUTPUT TENSORS; "warn" only
+        reports, "raise" raises PmceError.  The word is cleared either way (it is a report, not a lock)."""
         for st in self.streams:
             st.synchronize()
+        main = self._main
+        if main is None or not main.overflowed():
+            self._recent.clear()
+            return []
+        bad = [t for t in self._recent if not all(bool(torch.isfinite(o).all()) for o in t.outputs if o is not None)]
+        main.clear_overflow()
+        names = [t.index for t in bad]
+        msg = (f"pmce_amd.Pipeline: a product of the split-f16 form produced non-finite values; batches {names} of the last "
+               f"{len(self._recent)} submits hold non-finite outputs" + ("" if bad else " (none of the recent ones: an earlier batch)"))
+        if on_overflow == "raise":
+            self._recent.clear()
+            raise _lib.PmceError(msg)
+        import warnings
+        if on_overflow == "rerun":
+            for t in bad:
+                p2, f, want = t.inputs
+                eng = self.engines[t.lane]
+                new = self.model._run_on_f32_pipe(p2, f, want and eng.regressor_rows > 0, eng)
+                for dst, src in zip(t.outputs, new):
+                    if dst is not None:
+                        dst.copy_(src)
+            torch.cuda.synchronize(main.device)
+            main.clear_overflow()
+            self.reran += names
+            msg += "; they were computed again on the fp32 matrix pipe (non-finite INPUTS stay non-finite, as in the reference)"
+        warnings.warn(msg)
+        self._recent.clear()
+        return names
 
 
 def get_model(num_joint, embed_dim, depth):

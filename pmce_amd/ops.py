@@ -69,6 +69,30 @@ def gemm_nt_split(A, Wp, wscale, bias=None, residual=None, act=0, out=None, a_pa
     return out
 
 
+def split_rows_scaled_f16(A):
+    """fp32 rows of any finite magnitude -> (planes of A[m] * 2^-e(m) in the packed-A layout, rscale[m] = 2^e(m))."""
+    lib = _lib.load()
+    A = _c(A)
+    M, K = A.shape
+    Ap = torch.empty(M, K, device=A.device, dtype=torch.float32)
+    rs = torch.empty(M, device=A.device, dtype=torch.float32)
+    _lib.check(lib.pmce_split_rows_scaled_f16(P(A), M, K, K, P(Ap), P(rs), _st()), "split_rows_scaled_f16")
+    return Ap, rs
+
+
+def gemm_nt_split_rs(Ap, rscale, Wp, wscale, bias=None, out=None, rowmap=None):
+    """The three-product f16 GEMM on a row-scaled packed A (raw inputs: img_feat).  rowmap = (c_div, c_lo, c_hi) maps output rows."""
+    lib = _lib.load()
+    M, K = Ap.shape
+    N = Wp.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=Ap.device, dtype=torch.float32)
+    cd, lo, hi = rowmap if rowmap else (0, 0, 0)
+    _lib.check(lib.pmce_gemm_nt_split_f16_rs(P(Ap), P(rscale), P(Wp), P(wscale), P(bias), P(out), M, N, K, N, cd, lo, hi, _st()),
+               "gemm_nt_split_rs")
+    return out
+
+
 def ln_chain(x, w1=None, b1=None, eps1=1e-6, add=None, add_div=1, add_mod=1, want_out1=True, w2=None, b2=None, eps2=1e-6,
              out2_split=False):
     lib = _lib.load()

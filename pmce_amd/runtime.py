@@ -105,6 +105,8 @@ class HipEngine:
         if self.split_min_batch is not None:
             other.set_split_min_batch(self.split_min_batch)
         other.split_min_batch = self.split_min_batch
+        other.set_overflow_policy(getattr(self, "strict_overflow", False))
+        other.strict_overflow = getattr(self, "strict_overflow", False)
         other.register(self.packed)
         _lib.check(other.lib.pmce_model_share_split_weights(other.handle, self.handle), "model_share_split_weights")
         if self.regressor_rows:
@@ -152,10 +154,14 @@ class HipEngine:
         _lib.check(self.lib.pmce_model_set_split_min_batch(self.handle, int(clips)), "model_set_split_min_batch")
 
     def overflowed(self) -> bool:
-        """A product of the split-f16 form produced a non-finite value in a completed call (an activation beyond f16's 65504, or fp32
-        overflow): that call's outputs are invalid and every further call raises until :meth:`clear_overflow`.  Synchronise the
-        stream first for a definite answer about the last call."""
+        """A product of the split-f16 form produced a non-finite value in a completed call (non-finite inputs, an intermediate
+        activation beyond f16's 65504 under exotic weights, or fp32 overflow): the affected clips' outputs are inf / nan.  The word
+        only REPORTS (sticky until :meth:`clear_overflow`); with :meth:`set_overflow_policy` ``strict=True`` further calls raise
+        instead.  Synchronise the stream first for a definite answer about the last call."""
         return bool(self.lib.pmce_model_overflowed(self.handle))
+
+    def set_overflow_policy(self, strict: bool):
+        _lib.check(self.lib.pmce_model_set_overflow_policy(self.handle, 1 if strict else 0), "model_set_overflow_policy")
 
     def clear_overflow(self):
         _lib.check(self.lib.pmce_model_clear_overflow(self.handle), "model_clear_overflow")
@@ -260,6 +266,9 @@ class HipModuleBase(nn.Module):
             if self._split_min_batch is not None:
                 self._engine.set_split_min_batch(self._split_min_batch)
                 self._engine.split_min_batch = self._split_min_batch
+            if getattr(self, "_strict_overflow", False):
+                self._engine.set_overflow_policy(True)
+                self._engine.strict_overflow = True
             self._dirty = False
         return self._engine
 

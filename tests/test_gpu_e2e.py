@@ -576,10 +576,50 @@ def test_entry_points_in_one_process():
     assert "smoke: max-abs vs oracle" in r.stdout
 
 
-def test_overflow_guard_of_the_split_mode():
-    """An image feature beyond f16's range (the raw features enter the GRU projection and imgfeat_embed unnormalised,
-    CoevoDecoder.py:216-229): the forward that saw it sets the model's sticky word, every later call fails with PMCE_ERR_OVERFLOW
-    BEFORE launching, clear_overflow re-arms, and the fp32 pipe computes the same input without complaint."""
+def test_any_finite_feature_magnitude_matches_oracle():
+    """The reference accepts any fp32 image feature (raw img_feat enters imgfeat_embed, PoseEstimation.py:80, and the GRU's input
+    projection, CoevoDecoder.py:228, un-normalised).  Clips whose features are scaled by 1e5 (beyond f16's 65504), 1e-7 (below
+    f16's normal range) and 3e3, and a clip mixing both inside one frame, against the oracle in fp64 - in BOTH product modes: the
+    default split-f16 form must be as close as the fp32 pipe (<= 1.5 x its error), and nothing may trip the overflow word
+    (VERDICT r03 weak #1: a drop-in may not have an error mode the reference lacks)."""
+    from oracle import pmce_oracle as O
+    from pmce_amd import synth
+    J, C, B = 17, 256, 6
+    model = get_model(J, C)
+    sd = cached_state_dict(J, C)
+    pose2d, img_feat = synth.make_inputs(B, J, 77)
+    img_feat = img_feat.copy()
+    img_feat[1] *= 1e5
+    img_feat[2] *= 1e-7
+    img_feat[3] *= 3e3
+    img_feat[4, :, ::2] *= 1e5
+    img_feat[4, :, 1::2] *= 1e-7
+    img_feat[5, 3] *= 1e5                                        # one frame of a clip only
+    with torch.no_grad():
+        rm, rp, rl = O.pmce_forward(sd, T(pose2d), T(img_feat), model.vj_relation, dtype=torch.float64)
+    p2, f = T(pose2d).to(dev()), T(img_feat).to(dev())
+    errs = {}
+    try:
+        for mode in ("f32", "split_f16"):
+            model.set_gemm_mode(mode, min_batch=1)
+            mesh, pose, pose3d = model(p2, f)
+            assert not model.overflowed(), mode                  # (synchronises)
+            assert all(torch.isfinite(t).all() for t in (mesh, pose, pose3d)), mode
+            errs[mode] = (maxabs(mesh, rm), maxabs(pose, rp), maxabs(pose3d, rl))
+    finally:
+        model.set_gemm_mode(None)
+    print(f"features x 1e5 / 1e-7 / mixed vs fp64 oracle: fp32 pipe mesh {errs['f32'][0]:.2e} m pose3d {errs['f32'][2]:.2e} mm; "
+          f"split-f16 mesh {errs['split_f16'][0]:.2e} m pose3d {errs['split_f16'][2]:.2e} mm")
+    for k, floor, tol in ((0, 2e-6, TIGHT_M), (1, 2e-6, TIGHT_M), (2, 4e-4, TOL_MM)):
+        assert errs["split_f16"][k] <= 1.5 * errs["f32"][k] + floor, (k, errs)
+        assert errs["split_f16"][k] < tol and errs["f32"][k] < tol, (k, errs)
+
+
+def test_nonfinite_inputs_propagate_like_the_reference():
+    """inf / nan in a clip's features: that clip's outputs are not finite - as the reference's would be - the other clips of the
+    batch are bit-identical to a clean run, the model's overflow word REPORTS it and nothing is refused: the next forward runs and
+    is bit-identical.  The strict policy refuses until cleared; ``forward_checked`` and ``Pipeline.synchronize`` poll the word
+    (ADVICE r03: nothing did) and name / re-run the batch."""
     from pmce_amd import _lib, synth
     J, C, B = 17, 256, 4
     model = get_model(J, C)
@@ -590,23 +630,47 @@ def test_overflow_guard_of_the_split_mode():
         good = [t.clone() for t in model(p2, f)]
         assert not model.overflowed()
         f_bad = f.clone()
-        f_bad[1, 5, 77] = 1.0e5
-        out = model(p2, f_bad)
-        assert model.overflowed()                                   # (synchronises)
-        assert not torch.isfinite(out[0][1]).all()                  # the clip that overflowed is visibly invalid ...
-        assert torch.equal(out[0][0], good[0][0]) and torch.equal(out[0][2:], good[0][2:])   # ... its neighbours are not touched
-        with pytest.raises(_lib.PmceError, match="non-finite"):
-            model(p2, f)
-        model.clear_overflow()
-        again = model(p2, f)
+        f_bad[1, 5, 77] = float("inf")
+        f_bad[3, 0, 5] = float("nan")
+        out = [t.clone() for t in model(p2, f_bad)]
+        assert model.overflowed()                                   # (synchronises) reported ...
+        for k in (1, 3):
+            assert not torch.isfinite(out[0][k]).all() and not torch.isfinite(out[2][k]).all()
+        for k in (0, 2):                                            # ... neighbours untouched ...
+            assert all(torch.equal(o[k], g[k]) for o, g in zip(out, good))
+        again = model(p2, f)                                        # ... and nothing is refused
         torch.cuda.synchronize()
-        assert not model.overflowed()
         for a, b in zip(again, good):
             assert torch.equal(a, b)
-        model.set_gemm_mode("f32")
-        out32 = model(p2, f_bad)
-        assert not model.overflowed() and all(torch.isfinite(t).all() for t in out32)
+        model.clear_overflow()
+        assert not model.overflowed()
+        # strict policy: the round-3 behaviour on request
+        model.set_overflow_policy(True)
+        model(p2, f_bad)
+        assert model.overflowed()
+        with pytest.raises(_lib.PmceError, match="strict overflow policy"):
+            model(p2, f)
+        model.clear_overflow()
+        model.set_overflow_policy(False)
+        # forward_checked: waits, re-runs on the fp32 pipe, clears the word
+        outs, reran = model.forward_checked(p2, f_bad)
+        assert reran and not model.overflowed()
+        for k in (0, 2):          # the clean clips, now from the fp32 pipe: equal to the split form's within fp32 noise
+            assert maxabs(outs[0][k], good[0][k]) < TIGHT_M and maxabs(outs[2][k], good[2][k]) < TOL_MM
+        assert not torch.isfinite(outs[0][1]).all()               # non-finite inputs stay non-finite (as in the reference)
+        outs, reran = model.forward_checked(p2, f)
+        assert not reran and all(torch.equal(o, g) for o, g in zip(outs, good))
+        # the pipeline polls when it drains and names the batch
+        pipe = model.pipeline(2)
+        ts = [pipe.submit(p2, x) for x in (f, f_bad, f)]
+        with pytest.warns(UserWarning, match="non-finite"):
+            named = pipe.synchronize()
+        assert named == [1] and pipe.reran == [1] and not model.overflowed()
+        for a, b in zip(ts[2].result(), good):
+            assert torch.equal(a, b)
+        assert pipe.synchronize() == []
     finally:
+        model.set_overflow_policy(False)
         model.set_gemm_mode(None)
         model.clear_overflow()
 

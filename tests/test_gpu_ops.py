@@ -643,3 +643,54 @@ def test_gemm_split_out_of_range_is_never_silently_finite():
         assert bad_rows == [7, 300], bad_rows
         ok = torch.ones(M, dtype=torch.bool, device=dev()); ok[7] = False; ok[300] = False
         assert torch.equal(out[ok], clean[ok])
+
+
+def test_gemm_split_row_scaled_inputs_of_any_magnitude():
+    """pmce_split_rows_scaled_f16 + pmce_gemm_nt_split_f16_rs (the raw-input products: imgfeat_embed, PoseEstimation.py:80; the GRU
+    layer-0 input projection, CoevoDecoder.py:228 - the reference's Linear takes any fp32 value): rows of magnitude 1e-30 ... 1e30,
+    rows mixing 1e5 with 1e-7, a zero row; every element against an fp64 product, next to the fp32 pipe's error on the same
+    operands; with and without the output row map; inf / nan rows stay in their own rows."""
+    from pmce_amd import ops
+    M, N, K = 4096 + 37, 768, 2048
+    A = rnd("rs.A", (M, K)).to(dev()).abs()                     # like image features: non-negative
+    mags = [1e-30, 1e-12, 1e-7, 1e-3, 1.0, 3e2, 1e5, 7e4, 1e9, 1e20, 1e30]
+    for i, g in enumerate(mags):
+        A[i::len(mags) + 3] *= g
+    A[5] = 0.0
+    A[11, ::2] *= 1e-7                                          # one row mixing 1e5-scale and 1e-2-scale entries
+    A[11, 1::2] *= 1e5
+    W = rnd("rs.W", (N, K), scale=K ** -0.5).to(dev())
+    b = rnd("rs.b", (N,)).to(dev())
+    Wp, ws = ops.pack_split_f16(W)
+    Ap, rs = ops.split_rows_scaled_f16(A)
+    out = ops.gemm_nt_split_rs(Ap, rs, Wp, ws, b)
+    f32 = ops.gemm_nt(A, W, b)
+    ref = A.double() @ W.double().t() + b.double()
+    scale = (A.double().abs() @ W.double().abs().t() + b.double().abs())          # what a relative error is relative to
+    e16 = ((out.double() - ref).abs() / scale.clamp_min(1e-300)).max().item()
+    e32 = ((f32.double() - ref).abs() / scale.clamp_min(1e-300)).max().item()
+    print(f"row-scaled split GEMM {M}x{N}x{K}: max error relative to sum|a||w| {e16:.2e} (fp32 pipe {e32:.2e})")
+    assert torch.isfinite(out).all()
+    assert e16 <= 1.5 * e32 and e16 < 3e-7
+    assert torch.equal(out[5], b.expand(N).contiguous()[:N])    # the zero row is exactly the bias
+    again = ops.gemm_nt_split_rs(Ap, rs, Wp, ws, b)
+    assert torch.equal(out.view(torch.int32), again.view(torch.int32))
+    # output row map (rows (b, t) -> time-major), ragged M
+    T_ = 16
+    Mb = (M // T_) * T_
+    Ap2, rs2 = ops.split_rows_scaled_f16(A[:Mb])
+    mapped = torch.empty(Mb, N, device=dev())
+    ops.gemm_nt_split_rs(Ap2, rs2, Wp, ws, b, out=mapped, rowmap=(T_, (Mb // T_) * N, N))
+    want = out[:Mb].reshape(Mb // T_, T_, N).permute(1, 0, 2).reshape(Mb, N)
+    assert torch.equal(mapped, want)
+    # non-finite rows: confined to themselves, the others bit-identical
+    A2 = A.clone()
+    A2[100, 7] = float("inf")
+    A2[200, 9] = float("nan")
+    Ap3, rs3 = ops.split_rows_scaled_f16(A2)
+    out3 = ops.gemm_nt_split_rs(Ap3, rs3, Wp, ws, b)
+    bad_rows = (~torch.isfinite(out3)).any(1).nonzero().flatten().tolist()
+    assert bad_rows == [100, 200], bad_rows
+    ok = torch.ones(M, dtype=torch.bool, device=dev())
+    ok[100] = ok[200] = False
+    assert torch.equal(out3[ok], out[ok])
