@@ -91,12 +91,58 @@ def launch_ranks(n: int, argv) -> int:
     return rc
 
 
+def bind_rank_to_cpus(local: int, nlocal: int):
+    """One process per GPU: give rank `local` of `nlocal` its own contiguous slice of the CPUs this process may run on, so that
+    the ranks' launch threads (and rank 0's CPU baseline) do not migrate over each other.  Returns the slice (or None when the
+    platform has no sched_setaffinity / there is one rank)."""
+    if nlocal <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = max(1, len(cpus) // nlocal)
+        mine = cpus[local * per:(local + 1) * per] or cpus
+        os.sched_setaffinity(0, mine)
+        return mine
+    except OSError:
+        return None
+
+
+def shared_state_dict(J, C, local, barrier):
+    """The synthetic weights (412 MB at C = 256, 6-7 s of host time to generate) made ONCE per node: local rank 0 writes them to
+    /dev/shm, the other ranks map the file (torch.load(mmap=True)) instead of regenerating them 8 times.  `barrier` is a callable all
+    ranks of the node call; the file is removed by its writer after the second barrier."""
+    import torch
+    from pmce_amd import synth
+    tag = os.environ.get("MASTER_PORT", "0")
+    path = f"/dev/shm/pmce_bench_weights_J{J}_C{C}_{os.getuid()}_{tag}.pt"
+    sd = None
+    if local == 0:
+        sd = synth.make_state_dict(synth.pmce_spec(J, C, 3), seed=123)
+        try:
+            torch.save(sd, path + ".tmp")
+            os.replace(path + ".tmp", path)
+        except OSError:
+            path = None
+    barrier()
+    if local != 0:
+        try:
+            sd = torch.load(path, mmap=True, weights_only=True)
+        except Exception:  # noqa: BLE001  (no /dev/shm, or the writer failed): generate locally
+            sd = synth.make_state_dict(synth.pmce_spec(J, C, 3), seed=123)
+    return sd, path
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # analytical work (what measured times are divided into)
 # ------------------------------------------------------------------------------------------------------------------
-def gemm_lifter_flops(B, J, C, depth=3, T=16, F=2048):
+def gemm_lifter_flops(B, J, C, depth=3, T=16, F=2048, streaming=False):
+    """2MNK of the lifter's products per step.  streaming: a WINDOW batch of the stride-1 mode - imgfeat_embed and SpatialBlocks[0]
+    were computed once per frame (pmce_stream_precompute), the window pass runs the other 2*depth - 1 blocks."""
     M = B * T * J
-    return 2.0 * B * T * F * C + depth * 2 * (2.0 * M * C * 3 * C + 2.0 * M * C * C + 2 * 2.0 * M * C * 2 * C)
+    block = 2.0 * M * C * 3 * C + 2.0 * M * C * C + 2 * 2.0 * M * C * 2 * C
+    if streaming:
+        return (depth * 2 - 1) * block
+    return 2.0 * B * T * F * C + depth * 2 * block
 
 
 # kernel function behind each timing class of model.cpp: the four GEMM classes are one kernel - gemm_split_kernel in the
@@ -110,15 +156,18 @@ def kernel_of(cls, gemm_mode):
     return cls
 
 
-def gemm_class_bytes(name, B, J, C, depth=3, T=16, F=2048):
+def gemm_class_bytes(name, B, J, C, depth=3, T=16, F=2048, streaming=False):
     """ALGORITHMIC HBM bytes of a GEMM class: every operand and result once (fp32: A, W, C, + residual where there is one)."""
     GH = 1024
     M = B * T * J
     if name == "gemm_lifter":
         per_block = (M * C + 3 * M * C + 3 * C * C) + (M * C + 2 * M * C + C * C) + (M * C + 2 * M * C + 2 * C * C) + (2 * M * C + 2 * M * C + 2 * C * C)
+        if streaming:
+            return 4.0 * (2 * depth - 1) * per_block
         return 4.0 * (B * T * F + B * T * C + F * C + 2 * depth * per_block)
     if name == "gemm_gru_in":
-        return 4.0 * (16 * B * F + 16 * B * 6 * GH + 6 * GH * F + 17 * B * 2 * GH + 17 * B * 3 * GH + 6 * GH * 2 * GH)
+        l1 = 17 * B * 2 * GH + 17 * B * 3 * GH + 6 * GH * 2 * GH
+        return 4.0 * (l1 if streaming else 16 * B * F + 16 * B * 6 * GH + 6 * GH * F + l1)
     if name == "gemm_ada":
         return 4.0 * (B * 2048 + B * 3072 + 3072 * 2048)
     if name == "gemm_final":
@@ -126,14 +175,15 @@ def gemm_class_bytes(name, B, J, C, depth=3, T=16, F=2048):
     return None
 
 
-def class_work(name, B, J, C):
+def class_work(name, B, J, C, streaming=False):
     """ALGORITHMIC work one forward asks of a kernel class (2*M*N*K of the products actually launched; the pruned GRU
-    layer-1 steps and the dead joint stream are NOT counted as work): (amount, unit-kind)."""
+    layer-1 steps and the dead joint stream are NOT counted as work): (amount, unit-kind).  streaming: one WINDOW batch of the
+    stride-1 mode (the per-frame products ran once per frame in pmce_stream_precompute and are not in the window pass)."""
     GH, F = 1024, 2048
     if name == "gemm_lifter":
-        return gemm_lifter_flops(B, J, C), "flop"
+        return gemm_lifter_flops(B, J, C, streaming=streaming), "flop"
     if name == "gemm_gru_in":          # layer 0: 16 steps x 2 directions; layer 1: 9 fwd + 8 bwd steps
-        return 2.0 * 16 * B * 6 * GH * F + 2.0 * 17 * B * 3 * GH * 2 * GH, "flop"
+        return (0.0 if streaming else 2.0 * 16 * B * 6 * GH * F) + 2.0 * 17 * B * 3 * GH * 2 * GH, "flop"
     if name == "gru_step":             # 16 + 16 layer-0 steps minus the two h0 = 0 steps, 9 + 8 layer-1 steps minus two
         return (30 + 15) * 2.0 * B * 3 * GH * GH, "flop"
     if name == "gemm_final":
@@ -247,6 +297,59 @@ def attention_record(kernel_ms, launches, B, J, C, split):
             "traffic_source": src}
 
 
+def dominant_kernel_roofline(kernel_ms, launches, B, J, C, gemm_mode, clk_ghz=None, streaming=False):
+    """`roofline` of a profiled configuration: the kernel (function, not timing class) with the largest HIP-event time, its
+    algorithmic work per launch against the peak that bounds it.  kernel_ms / launches: per timing class of model.cpp, per step."""
+    by_kernel = {}
+    for k_ in kernel_ms:
+        by_kernel.setdefault(kernel_of(k_, gemm_mode), []).append(k_)
+    dominant = max(by_kernel, key=lambda kn: sum(kernel_ms[c] for c in by_kernel[kn]))
+    dom_classes = by_kernel[dominant]
+    dom_ms = sum(kernel_ms[c] for c in dom_classes)
+    dom_launches = sum(launches[c] for c in dom_classes)
+    works = [class_work(c, B, J, C, streaming) for c in dom_classes]
+    roofline = None
+    if all(w[0] is not None for w in works):
+        kind = works[0][1]
+        work = sum(w[0] for w in works)
+        secs = dom_ms * 1e-3
+        traffic, traffic_src = pmc_traffic_per_launch(dominant, C)
+        common = {"kernel": dominant, "classes": dom_classes, "launches_per_step": dom_launches,
+                  "avg_launch_ms": round(dom_ms / dom_launches, 5), "traffic": traffic, "traffic_source": traffic_src,
+                  "algorithmic_per_launch": work / dom_launches}
+        if kind == "flop" and dominant == "gemm_split_kernel":
+            # the kernel issues THREE f16 matrix products per algorithmic fp32 product: achieved = issued f16 FLOP/s against the
+            # dense f16 peak; the fp32-equivalent rate and the same launches against the HBM roofline (every operand and
+            # result once) are printed beside it - at these shapes the two floors are within 15 % of each other
+            ach = 3.0 * work / secs / 1e12
+            byt = sum(gemm_class_bytes(c, B, J, C, streaming=streaming) for c in dom_classes)
+            common["algorithmic_per_launch"] = 3.0 * work / dom_launches
+            roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_F16_TFLOPS, 4), **common,
+                        "arithmetic": "3 x v_mfma_f32_32x32x16_f16 per fp32 product (hi*hi + hi*lo + lo*hi), fp32 accumulate",
+                        "measured_pipe_ceiling_tflops": MEASURED_F16_CEILING_TFLOPS,
+                        "frac_of_measured_pipe_ceiling": round(ach / MEASURED_F16_CEILING_TFLOPS, 4),
+                        "note": "achieved / frac count the f16 FLOPs the kernel ISSUES (3 x 2MNK); frac_algorithmic_2mnk is the same time "
+                                "against the algorithmic 2MNK of the fp32 products",
+                        "fp32_equiv_tflops": round(work / secs / 1e12, 1),
+                        "frac_algorithmic_2mnk": round(work / secs / 1e12 / PEAK_F16_TFLOPS, 4),
+                        # MI355X runs this kernel power-limited: the shader clock its workgroups measured (s_memtime vs the 100 MHz
+                        # wall counter, in these very launches), and the issued rate against the matrix peak AT that clock
+                        "sustained_clock_ghz": round(clk_ghz, 3) if clk_ghz else None,
+                        "frac_of_peak_at_sustained_clock": round(ach / (PEAK_F16_TFLOPS * clk_ghz / 2.4), 4) if clk_ghz else None,
+                        "hbm": {"algorithmic_bytes_per_launch": round(byt / dom_launches), "achieved_gbs": round(byt / secs / 1e9, 1),
+                                "peak_gbs": PEAK_HBM_GBS, "frac": round(byt / secs / 1e9 / PEAK_HBM_GBS, 4)}}
+        elif kind == "flop":
+            ach = work / secs / 1e12
+            roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_F32_TFLOPS, 4), **common}
+        else:
+            ach = work / secs / 1e9
+            roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(ach / PEAK_HBM_GBS, 4), **common}
+    return roofline
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full=True):
     """Throughput + per-kernel-class timing of one configuration.  Returns (record, model, pipe, inputs)."""
@@ -255,11 +358,23 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
     from pmce_amd.workload import flops_per_clip
 
     assets.allow_synthetic_base_data()                                  # no SMPL-derived files offline: synthetic template
-    sd = synth.make_state_dict(synth.pmce_spec(J, C, 3), seed=123)      # random-init weights of the named architecture
+    # random-init weights of the named architecture; at N > 1 generated once per node and mapped by the other ranks
+    if world > 1:
+        sd, shm_path = shared_state_dict(J, C, int(os.environ.get("LOCAL_RANK", rank)), sharding.barrier)
+    else:
+        sd, shm_path = synth.make_state_dict(synth.pmce_spec(J, C, 3), seed=123), None
     model = models.PMCE.get_model(J, C, 3)
     model.load_state_dict(sd)
     model.set_j_regressor(assets.load_j_regressor("h36m"))
     model = model.to(dev)
+    if world > 1:
+        torch.cuda.synchronize()
+        sharding.barrier()                                               # every rank has its copy on its GPU
+        if shm_path and int(os.environ.get("LOCAL_RANK", rank)) == 0:
+            try:
+                os.remove(shm_path)
+            except OSError:
+                pass
     model.set_gemm_mode(args.gemm_mode)
     gemm_mode = model.gemm_mode()
 
@@ -332,6 +447,7 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
                       "batches_enqueued_ahead": depth, "distinct_input_batches": NB},
            "ref_equiv_tflops": round(fpc * clips_per_s / 1e12, 2), "outputs_finite": finite,
            "per_rank_clips_s": [round(x, 1) for x in per_rank],
+           "per_rank_ms_per_step": [round(B / x * 1e3, 4) for x in per_rank],
            "metric_reduction": {"collective": "all_reduce(SUM) of 3 fp64 partials per rank", "clips_counted": int(total[2].item()),
                                 "backend": (torch.distributed.get_backend() if world > 1 else None)}}
     if not full:
@@ -357,53 +473,10 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
         model.set_concurrency(False)
     kernel_ms = {k_: round(v[0] / nprof, 4) for k_, v in prof.items() if v[1] > 0}
     launches = {k_: int(v[1] // nprof) for k_, v in prof.items() if v[1] > 0}
-    by_kernel = {}
-    for k_ in kernel_ms:
-        by_kernel.setdefault(kernel_of(k_, gemm_mode), []).append(k_)
-    dominant = max(by_kernel, key=lambda kn: sum(kernel_ms[c] for c in by_kernel[kn]))
-    dom_classes = by_kernel[dominant]
-    dom_ms = sum(kernel_ms[c] for c in dom_classes)
-    dom_launches = sum(launches[c] for c in dom_classes)
-    works = [class_work(c, B, J, C) for c in dom_classes]
-    roofline = None
-    if all(w[0] is not None for w in works):
-        kind = works[0][1]
-        work = sum(w[0] for w in works)
-        secs = dom_ms * 1e-3
-        traffic, traffic_src = pmc_traffic_per_launch(dominant, C)
-        common = {"kernel": dominant, "classes": dom_classes, "launches_per_step": dom_launches,
-                  "avg_launch_ms": round(dom_ms / dom_launches, 5), "traffic": traffic, "traffic_source": traffic_src,
-                  "algorithmic_per_launch": work / dom_launches}
-        if kind == "flop" and dominant == "gemm_split_kernel":
-            # the kernel issues THREE f16 matrix products per algorithmic fp32 product: achieved = issued f16 FLOP/s against the
-            # dense f16 peak; the fp32-equivalent rate and the same launches against the HBM roofline (every operand and
-            # result once) are printed beside it - at these shapes the two floors are within 15 % of each other
-            ach = 3.0 * work / secs / 1e12
-            byt = sum(gemm_class_bytes(c, B, J, C) for c in dom_classes)
-            common["algorithmic_per_launch"] = 3.0 * work / dom_launches
-            roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_F16_TFLOPS, 4), **common,
-                        "arithmetic": "3 x v_mfma_f32_32x32x16_f16 per fp32 product (hi*hi + hi*lo + lo*hi), fp32 accumulate",
-                        "measured_pipe_ceiling_tflops": MEASURED_F16_CEILING_TFLOPS,
-                        "frac_of_measured_pipe_ceiling": round(ach / MEASURED_F16_CEILING_TFLOPS, 4),
-                        "note": "achieved / frac count the f16 FLOPs the kernel ISSUES (3 x 2MNK); frac_algorithmic_2mnk is the same time "
-                                "against the algorithmic 2MNK of the fp32 products",
-                        "fp32_equiv_tflops": round(work / secs / 1e12, 1),
-                        "frac_algorithmic_2mnk": round(work / secs / 1e12 / PEAK_F16_TFLOPS, 4),
-                        # MI355X runs this kernel power-limited: the shader clock its workgroups measured (s_memtime vs the 100 MHz
-                        # wall counter, in these very launches), and the issued rate against the matrix peak AT that clock
-                        "sustained_clock_ghz": round(clk_ghz, 3) if clk_ghz else None,
-                        "frac_of_peak_at_sustained_clock": round(ach / (PEAK_F16_TFLOPS * clk_ghz / 2.4), 4) if clk_ghz else None,
-                        "hbm": {"algorithmic_bytes_per_launch": round(byt / dom_launches), "achieved_gbs": round(byt / secs / 1e9, 1),
-                                "peak_gbs": PEAK_HBM_GBS, "frac": round(byt / secs / 1e9 / PEAK_HBM_GBS, 4)}}
-        elif kind == "flop":
-            ach = work / secs / 1e12
-            roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_F32_TFLOPS, 4), **common}
-        else:
-            ach = work / secs / 1e9
-            roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(ach / PEAK_HBM_GBS, 4), **common}
+    roofline = dominant_kernel_roofline(kernel_ms, launches, B, J, C, gemm_mode, clk_ghz)
+    # every rank's own sustained shader clock under the dominant kernel (power-limited: 8 GPUs in one chassis need not hold the same)
+    rec["per_rank_sustained_clock_ghz"] = [round(x, 3) for x in
+                                           sharding.gather_rows(torch.tensor([[clk_ghz or 0.0]], dtype=torch.float64, device=dev)).flatten().tolist()]
     rec.update({"roofline": roofline, "roofline_cross_attention": north_star_record(kernel_ms, launches, B, J, f16_ffn=(gemm_mode == "split_f16")),
                 "roofline_attention": attention_record(kernel_ms, launches, B, J, C, gemm_mode == "split_f16" and J in (17, 19)),
                 "kernel_ms_per_step": kernel_ms, "launches_per_step": launches,
@@ -489,7 +562,7 @@ def cpu_baseline_record(sd, vj_relation, J, C, seconds):
     import torch
     from oracle import pmce_oracle as O
     from pmce_amd import synth
-    ncores = os.cpu_count() or 1
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)   # (a rank's own CPU slice at N > 1)
     # torch's intra-op pool degrades badly when oversubscribed on many-core hosts: calibrate the thread count on a small
     # batch (a few seconds), then time a bounded sample of batch-64 forwards with the best one.
     p_cpu, f_cpu = (torch.from_numpy(a) for a in synth.make_inputs(64, J, seed=1))
@@ -591,8 +664,34 @@ def main():
             return rec
         return {"error": (r.stderr or r.stdout)[-400:]}
 
+    def script_record(script, extra, what):
+        """One of BASELINE.json's other configurations, run by its own script in a child process (same reasons as above); the
+        script prints one JSON line with the configuration's rate and the roofline of its dominant kernel."""
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        r = subprocess.run([sys.executable, os.path.join(REPO, "scripts", script), *extra], env=env, capture_output=True, text=True)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and lines:
+            d = json.loads(lines[-1])
+            d["what"] = what
+            d["measured_by"] = f"child process: python scripts/{script} {' '.join(extra)}"
+            return d
+        return {"error": (r.stderr or r.stdout)[-400:], "what": what}
+
+    other_configs = {}
     if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_variant and not args.single_stream
             and not args.dist_check and C in (256, 512)):
+        # BASELINE.json configs[1], [3], [4] (C = 256, the width every reference config ships): decoder-only at batch 64; the
+        # 3DPW-sized clip-sharded evaluation (35,515 clips, COCO input J = 19: forward + on-device metrics + the one reduction)
+        # and the stride-1 streaming of one long sequence (frame reuse + acceleration error), both on synthetic stand-ins
+        other_configs["config_decoder_b64"] = script_record(
+            "decoder_bench.py", ["--batch", "64", "--steps", "50"], "BASELINE configs[1]: CoEvoDecoder-only forward, batch 64, 1 GPU")
+        other_configs["config_eval_sharded_j19"] = script_record(
+            "eval_sharded.py", ["--clips", "35515", "--joints", "19"],
+            "BASELINE configs[3] stand-in: 35,515 clips (3DPW test-set size), J = 19, forward + on-device MPJPE / PA-MPJPE / MPVPE / accel + "
+            "the final reduction; this rank count's shard of the clip range")
+        other_configs["config_streaming"] = script_record(
+            "stream_bench.py", ["--frames", "16384"],
+            "BASELINE configs[4] stand-in: one 16,384-frame sequence, stride-1 T = 16 windows with per-frame reuse, acceleration error on the device")
         C2 = 256 if C == 512 else 512
         variant = child_record(["--embed-dim", str(C2), "--gemm-mode", args.gemm_mode], True)
         variant["why"] = ("the width every reference config ships (lib/core/config.py:59)" if C2 == 256
@@ -608,6 +707,7 @@ def main():
     rank, local, world = sharding.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}")
+    cpu_slice = bind_rank_to_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
 
     if args.dist_check:
         import torch.distributed as dist
@@ -664,7 +764,11 @@ def main():
             "kernel_ms_per_step": head["kernel_ms_per_step"], "launches_per_step": head["launches_per_step"],
             "kernel_ms_total_single_stream": head["kernel_ms_total_single_stream"],
             "ref_equiv_tflops": head["ref_equiv_tflops"], "outputs_finite": head["outputs_finite"],
-            "per_rank_clips_s": head["per_rank_clips_s"], "metric_reduction": head["metric_reduction"],
+            "per_rank_clips_s": head["per_rank_clips_s"], "per_rank_ms_per_step": head["per_rank_ms_per_step"],
+            "per_rank_sustained_clock_ghz": head.get("per_rank_sustained_clock_ghz"),
+            "rank0_cpu_affinity": ({"cpus": len(cpu_slice), "first": cpu_slice[0], "last": cpu_slice[-1]} if cpu_slice else None),
+            "metric_reduction": head["metric_reduction"],
+            **other_configs,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -43,6 +43,7 @@ def main():
     launches = {k: v[1] // 3 for k, v in prof.items() if v[1] > 0}
     out = {"config": f"CoEvoDecoder-only forward, batch={B}, J=17", "clips_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4),
            "gemm_mode": eng.gemm_mode(),
+           "roofline": bench.dominant_kernel_roofline({k: round(v, 4) for k, v in kernel_ms.items()}, launches, B, J, 256, eng.gemm_mode()),
            "cross_attention": bench.north_star_record(kernel_ms, launches, B, J, f16_ffn=(eng.gemm_mode() == "split_f16")),
            "kernel_ms_per_step": {k: round(v[0] / 3, 4) for k, v in prof.items() if v[1] > 0 and v[0] / 3 > 0.01},
            "outputs_finite": bool(torch.isfinite(mesh).all().item() and torch.isfinite(pose).all().item())}

@@ -15,6 +15,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("PMCE_SYNTHETIC_BASE_DATA", "1")   # synthetic weights on the synthetic template (explicit opt-in)
 
 
+def gt_noise_pool(dev, P=64, seed=4321):
+    """Deterministic stand-in ground truth: clip i's mesh = its prediction + 2 cm x pool[(31 i) % P] - a function of the GLOBAL
+    clip index only, so every sharding of the set (and a test recomputing it unsharded) sees the same ground truth."""
+    g = torch.Generator().manual_seed(seed)
+    return (0.02 * torch.randn(P, 6890, 3, generator=g)).to(dev)
+
+
+def synthetic_gt(mesh, first_index, pool):
+    idx = (torch.arange(first_index, first_index + mesh.shape[0], device=mesh.device) * 31) % pool.shape[0]
+    return mesh + pool[idx]
+
+
+def clip_inputs(p_pool, f_pool, first_index, n):
+    idx = (torch.arange(first_index, first_index + n, device=p_pool.device) * 7919) % p_pool.shape[0]
+    return p_pool[idx], f_pool[idx]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--clips", type=int, default=4096)
@@ -25,6 +42,8 @@ def main():
     from pmce_amd import models, sharding, synth
     from pmce_amd.eval import Evaluator
     rank, local, world = sharding.init_from_env()
+    if os.environ.get("PMCE_BENCH_SHARE_GPU"):      # plumbing runs of the N > 1 path on a box with fewer GPUs (ranks share devices)
+        local = local % max(torch.cuda.device_count(), 1)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     J = args.joints
@@ -37,34 +56,51 @@ def main():
     # synthetic inputs for this shard: one pool of `batch` clips, re-indexed (keeps host memory small)
     p_np, f_np = synth.make_inputs(args.batch, J, seed=7)
     p_pool, f_pool = torch.from_numpy(p_np).to(dev), torch.from_numpy(f_np).to(dev)
-    g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
+    pool = gt_noise_pool(dev)
     from pmce_amd.eval import RunningEval
     run = RunningEval(ev)
     pipe = model.pipeline(2).prepare(args.batch)
     torch.cuda.synchronize(); sharding.barrier(); t0 = time.perf_counter()
     pending = None
 
-    def consume(ticket):
+    def consume(item):
+        ticket, b0 = item
         mesh = ticket.result()[0]
-        gt = mesh + 0.02 * torch.randn(mesh.shape, device=dev, generator=g)       # stand-in ground truth (2 cm noise)
-        run.add(mesh, gt)                                                           # per-sample errors + 14x3 joints; the mesh is dropped
+        run.add(mesh, synthetic_gt(mesh, b0, pool))                                 # per-sample errors + 14x3 joints; the mesh is dropped
 
     for b0 in range(lo, hi, args.batch):
         n = min(args.batch, hi - b0)
-        idx = (torch.arange(b0, b0 + n, device=dev) * 7919) % args.batch
-        ticket = pipe.submit(p_pool[idx], f_pool[idx], want_joints=False)           # two batches in flight
+        ticket = pipe.submit(*clip_inputs(p_pool, f_pool, b0, n), want_joints=False)   # two batches in flight
         if pending is not None:
             consume(pending)
-        pending = ticket
+        pending = (ticket, b0)
     if pending is not None:
         consume(pending)
     res = run.finish(seq_ids, lo, hi)
     torch.cuda.synchronize(); sharding.barrier()
     dt = sharding.reduce_max(time.perf_counter() - t0, dev)
+    named = pipe.synchronize()          # polls the model's overflow word (non-finite predictions are named in the result anyway)
     if rank == 0:
-        res.update({"clips": args.clips, "n_gpus": world, "clips_per_s_incl_metrics": round(args.clips / dt, 1), "J": J,
+        # where a batch of this configuration spends its time, and the roofline of its dominant kernel (one stream, HIP events)
+        import bench
+        nb = min(args.batch, args.clips)
+        model.profile(True)
+        for _ in range(3):
+            model(*clip_inputs(p_pool, f_pool, 0, nb))
+        torch.cuda.synchronize()
+        prof = model.profile_read()
+        model.profile(False)
+        kernel_ms = {k: round(v[0] / 3, 4) for k, v in prof.items() if v[1] > 0}
+        launches = {k: int(v[1] // 3) for k, v in prof.items() if v[1] > 0}
+        res.update({"clips": args.clips, "n_gpus": world, "clips_per_s_incl_metrics": round(args.clips / dt, 1), "seconds": round(dt, 4),
+                    "J": J, "batch": args.batch, "gemm_mode": model.gemm_mode(), "batches_rerun_on_fp32_pipe": named,
+                    "metric_reduction": {"collective": "all_reduce(SUM) of 4 fp64 partials + all_gather of 28x3 joints per clip",
+                                         "backend": (torch.distributed.get_backend() if world > 1 else None)},
+                    "roofline": bench.dominant_kernel_roofline(kernel_ms, launches, nb, J, 256, model.gemm_mode()),
                     "data": "synthetic stand-in (no 3DPW/H36M files offline)"})
         print(json.dumps(res))
+    if world > 1:
+        sharding.barrier()
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -43,7 +43,23 @@ def main():
         m = mesh[a:a + 1024]
         runev.add(m, m + 0.005 * torch.randn(m.shape, device=dev, generator=g))      # stand-in ground truth (5 mm noise)
     res = runev.finish(np.zeros(len(win), dtype=np.int64))
-    res.update({"frames": L, "windows": int(len(win)), "windows_per_s": round(len(win) / dt, 1), "lanes": args.lanes, "J": J,
+    # where a window batch spends its time (HIP events around every launch, one stream, one lane) and the roofline of its dominant
+    # kernel: the window pass runs 2*depth - 1 lifter blocks and the layer-1 GRU projections only (frame reuse)
+    import bench
+    cache = streaming.precompute_frames(model, pose_fr, feat_fr)
+    nb = min(args.batch, len(win))
+    model.profile(True)
+    for _ in range(3):
+        streaming.stream_forward_cached(model, cache, windows=win[:nb], batch=nb, lanes=1)
+    torch.cuda.synchronize()
+    prof = model.profile_read()
+    model.profile(False)
+    kernel_ms = {k: round(v[0] / 3, 4) for k, v in prof.items() if v[1] > 0}
+    launches = {k: int(v[1] // 3) for k, v in prof.items() if v[1] > 0}
+    res.update({"frames": L, "windows": int(len(win)), "windows_per_s": round(len(win) / dt, 1), "ms_per_window_batch": round(dt / max(1, (len(win) + args.batch - 1) // args.batch) * 1e3, 4),
+                "batch": args.batch, "lanes": args.lanes, "J": J, "gemm_mode": model.gemm_mode(),
+                "roofline": bench.dominant_kernel_roofline(kernel_ms, launches, nb, J, 256, model.gemm_mode(), streaming=True),
+                "kernel_ms_per_window_batch": {k: v for k, v in kernel_ms.items() if v > 0.01},
                 "data": "synthetic stand-in sequence (no H36M files offline)"})
     print(json.dumps(res))
 
