@@ -1,25 +1,41 @@
 #!/bin/bash
-# GPU session script: bash scripts/gpu_session.sh [tests] [bench] [sweep] [prof] [pmc] (any subset, in this order).
-# Everything lands under gpurun_out/r03/.
+# GPU session script: bash scripts/gpu_session.sh [tests] [bench] [order_ab] [prof] [pmc] [quick "<pytest -k expr>"] (any subset, in this order).
+# Everything lands under gpurun_out/r04/.
 set -u
-mkdir -p gpurun_out/r03
-O=gpurun_out/r03
+R=${PMCE_ROUND:-r04}
+mkdir -p gpurun_out/$R
+O=gpurun_out/$R
 export TMPDIR=/tmp PMCE_SYNTHETIC_BASE_DATA=1
-python -c "import pmce_amd.build as b; print(b.build())" > $O/build.log 2>&1 || { cat $O/build.log; exit 1; }
-for what in "$@"; do
+python -c "import pmce_amd.build as b; print(b.build()); print(b.build_diag())" > $O/build.log 2>&1 || { cat $O/build.log; exit 1; }
+QUICK="--no-variant --no-cpu-baseline --no-latency --no-host-fed --steps 20 --warmup 5 --windows 3"
+while [[ $# -gt 0 ]]; do
+what=$1; shift
 case $what in
 tests)
   timeout 1500 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $O/pytest_gpu.log 2>&1
   echo "pytest exit: $?" | tee -a $O/pytest_gpu.log
   grep -E "passed|failed|error" $O/pytest_gpu.log | tail -5
+  grep -E "^(FAILED|ERROR)" $O/pytest_gpu.log | head -20
+  ;;
+quick)
+  expr=$1; shift
+  timeout 900 python -m pytest tests -m gpu -q -s -x -p no:cacheprovider -k "$expr" > $O/pytest_quick.log 2>&1
+  echo "pytest quick exit: $?"; tail -n 40 $O/pytest_quick.log
   ;;
 bench)
-  timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
-  echo "bench exit: $?"; python scripts/show_bench.py $O/bench.json 2>/dev/null | head -80 || head -c 3000 $O/bench.json
+  timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err
+  echo "bench exit: $?"; python scripts/show_bench.py $O/bench.json 2>/dev/null | head -120 || head -c 3000 $O/bench.json
   tail -n 5 $O/bench.err | grep -v amdgpu.ids || true
   ;;
-sweep)
-  bash scripts/sweep_r02.sh > $O/sweep.log 2>&1; cp gpurun_out/sweep_r02.txt $O/ 2>/dev/null; cat $O/sweep_r02.txt
+order_ab)
+  for i in 1 2; do for o in 0 1; do
+    PMCE_SPLIT_ORDER=$o timeout 300 python bench.py $QUICK > $O/bench_order${o}_$i.json 2>> $O/order_ab.err
+    python - <<PY
+import json
+d=json.loads(open("$O/bench_order${o}_$i.json").read().strip().splitlines()[-1])
+print("order $o run $i: ms/step", d["ms_per_step"], "gemm_lifter", d["kernel_ms_per_step"].get("gemm_lifter"), "gemm_gru_in", d["kernel_ms_per_step"].get("gemm_gru_in"), "clock", d["roofline"].get("sustained_clock_ghz"))
+PY
+  done; done
   ;;
 prof)
   for C in 512 256; do

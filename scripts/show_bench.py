@@ -24,5 +24,8 @@ for l in src:
         for k, v in d.items():
             if k.startswith("variant_") and v:
                 rec(k, v)
+            if k.startswith("config_") and v:
+                print(f"[{k}]", {kk: vv for kk, vv in v.items() if kk not in ("roofline", "cross_attention", "kernel_ms_per_step", "kernel_ms_per_window_batch", "what", "measured_by")})
+                print("   roofline:", {kk: vv for kk, vv in (v.get("roofline") or {}).items() if kk in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches_per_step")})
     else:
         print(l.strip()[:200])

@@ -1,0 +1,100 @@
+"""The harnesses behind BASELINE.json's other configurations are part of the suite: what bench.py reports as
+`config_decoder_b64`, `config_eval_sharded_j19` and `config_streaming` comes from these very scripts.
+
+* scripts/eval_sharded.py with TWO ranks (gloo above the same pmce_amd.sharding code: RCCL refuses two ranks on one device),
+  600 clips, J = 19, the rank boundary inside a sequence: its MPJPE / PA-MPJPE / MPVPE / ACCEL against oracle/metrics_oracle.py
+  (the reference's evaluate arithmetic, data/PW3D/dataset.py:351-462) on predictions recomputed unsharded in this process;
+* scripts/stream_bench.py and scripts/decoder_bench.py on small sizes: they run, count what they should and carry a roofline.
+"""
+import json
+import os
+import os.path as osp
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = osp.dirname(osp.abspath(__file__))
+REPO = osp.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_script(script, argv, world=1, timeout=900):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, PMCE_SYNTHETIC_BASE_DATA="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if world > 1:
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       PMCE_DIST_BACKEND="gloo", PMCE_BENCH_SHARE_GPU="1")
+        else:
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+        procs.append(subprocess.Popen([sys.executable, osp.join(REPO, "scripts", script), *argv], env=env, cwd=REPO,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert lines, outs[0][1][-2000:]
+    return json.loads(lines[-1])
+
+
+def test_eval_sharded_script_two_ranks_vs_metrics_oracle():
+    from oracle import metrics_oracle as MO
+    from pmce_amd import assets, models, synth
+    sys.path.insert(0, osp.join(REPO, "scripts"))
+    import eval_sharded as ES
+    clips, J, batch, seq_len = 600, 19, 128, 250          # 2 ranks x 300 clips: the boundary cuts sequence 1 (clips 250..499)
+    got = _run_script("eval_sharded.py", ["--clips", str(clips), "--joints", str(J), "--batch", str(batch), "--seq-len", str(seq_len)], world=2)
+    assert got["n_gpus"] == 2 and got["samples"] == clips and got["nonfinite_samples"] == 0
+    assert got["metric_reduction"]["backend"] == "gloo" and got["batches_rerun_on_fp32_pipe"] == []
+    assert got["roofline"] and got["roofline"]["frac"] > 0
+
+    # the same clips unsharded, in this process: predictions from the model, ground truth by the script's own rule
+    assets.allow_synthetic_base_data()
+    dev = torch.device("cuda:0")
+    model = models.PMCE.get_model(J, 256, 3)
+    model.load_state_dict(synth.make_state_dict(synth.pmce_spec(J, 256, 3), seed=123))
+    model = model.to(dev)
+    p_np, f_np = synth.make_inputs(batch, J, seed=7)
+    p_pool, f_pool = torch.from_numpy(p_np).to(dev), torch.from_numpy(f_np).to(dev)
+    pool = ES.gt_noise_pool(dev)
+    pred, gt = [], []
+    for b0 in range(0, clips, 100):                        # (other batch boundaries than either rank's: clips are independent)
+        mesh = model(*ES.clip_inputs(p_pool, f_pool, b0, min(100, clips - b0)))[0]
+        pred.append(mesh.double().cpu().numpy())
+        gt.append(ES.synthetic_gt(mesh, b0, pool).double().cpu().numpy())
+    pred, gt = np.concatenate(pred) * 1000, np.concatenate(gt) * 1000
+    jr = assets.load_j_regressor("h36m").astype(np.float32)
+    ref = MO.evaluate_samples(pred, gt, jr[:1], 0, jr, np.arange(clips) // seq_len)
+    print("2 ranks:", {k: got[k] for k in ("MPVPE", "MPJPE", "PA-MPJPE", "ACCEL")}, "\noracle :", {k: ref[k] for k in ("MPVPE", "MPJPE", "PA_MPJPE", "ACCEL")})
+    for k, r in (("MPVPE", "MPVPE"), ("MPJPE", "MPJPE"), ("PA-MPJPE", "PA_MPJPE"), ("ACCEL", "ACCEL")):
+        assert abs(got[k] - ref[r]) < 2e-3, (k, got[k], ref[r])          # millimetres
+
+
+def test_stream_bench_script():
+    L = 700
+    got = _run_script("stream_bench.py", ["--frames", str(L), "--batch", "128"])
+    assert got["frames"] == L and got["windows"] == L - 15 and got["samples"] == L - 15     # stride-1 windows (lib/_img_utils.py:27-55)
+    assert got["windows_per_s"] > 0 and got["nonfinite_samples"] == 0
+    assert all(np.isfinite(got[k]) for k in ("MPVPE", "MPJPE", "PA-MPJPE", "ACCEL"))
+    r = got["roofline"]
+    assert r and r["kernel"] and 0 < r["frac"] < 1 and "gemm_lifter" in got["kernel_ms_per_window_batch"]
+
+
+def test_decoder_bench_script():
+    got = _run_script("decoder_bench.py", ["--batch", "64", "--steps", "10"])
+    assert got["clips_per_s"] > 0 and got["outputs_finite"] and got["cross_attention"]["kernel"] in ("vertex_ca_mlp", "vertex_ca")
+    assert got["roofline"] and got["roofline"]["kernel"] and 0 < got["roofline"]["frac"] < 1
