@@ -1185,19 +1185,111 @@ struct JointStreamW {
   int i_normq, i_norm2, i_snorm1, i_snorm2;                     // AdaLN instance indices into GB
 };
 
-__global__ __launch_bounds__(256) void joint_stream_kernel(const float* __restrict__ xq_in, const float* __restrict__ jQ,
-                                                           const float* __restrict__ kv, const float* __restrict__ GB,
-                                                           int gb_stride, JointStreamW w, const float* __restrict__ jt,
-                                                           float* __restrict__ y_out, float* __restrict__ pose_out, int J,
-                                                           int stage) {
+// ---- weight tiles for the joint stream's Linear layers --------------------------------------------------------------------------
+// A 64 x 64 tile W[n0 .. n0+63][k0 .. k0+63] of a row-major [NOUT][KIN] nn.Linear weight travels global -> registers (coalesced:
+// 16 lanes x 16 B cover a row's 256 bytes, a wave instruction four rows) -> LDS [64][JWL] (row stride 68 floats: 16-byte aligned
+// rows, conflict-free ds_read_b128 with lane = row).  Until round 4 every lane walked its OWN weight row in global memory (64 cache
+// lines per load instruction): 6,000 such instructions made 180 of the kernel's 233 us.
+#define JWL 68
+#define JS_THREADS 512
+struct JTile {
+  f32x4 r[2];  // 512 threads x 2 x 16 B = one 16 KB tile
+};
+__device__ __forceinline__ void jtile_fetch(JTile& t, const float* __restrict__ W, int ld, int n0, int k0, int tid) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = (tid >> 4) + 32 * q, c4 = tid & 15;
+    t.r[q] = *reinterpret_cast<const f32x4*>(W + (long long)(n0 + row) * ld + k0 + 4 * c4);
+  }
+}
+__device__ __forceinline__ void jtile_store(float* s_w, const JTile& t, int tid) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = (tid >> 4) + 32 * q, c4 = tid & 15;
+    *reinterpret_cast<f32x4*>(s_w + row * JWL + 4 * c4) = t.r[q];
+  }
+}
+// out[i][n] = act(b[n] + sum_k W[n][k] in[i][k]) for i < J: 512 threads = 64 output columns (lane) x 8 token groups (wave; tokens
+// i = wave, wave + 8, ...: at most 4 for J <= 32).  The k order of every sum is 0, 1, 2, ... as in the reference's dot product.
+// `pre` holds this layer's FIRST tile on entry (fetched by the previous phase, so its latency hid under that phase's arithmetic) and
+// the NEXT layer's first tile (Wnext, ldnext; null = none) on return.
+template <int KIN, int NOUT>
+__device__ __forceinline__ void lin_tiled(const float* in, int ild, const float* __restrict__ W, const float* __restrict__ b, float* out,
+                                          int old, int J, int tid, bool gelu, float* s_w, JTile& pre, const float* __restrict__ Wnext,
+                                          int ldnext) {
+  constexpr int NT = NOUT / 64, KT = KIN / 64;
+  const int lane = tid & 63, tg = tid >> 6;
+#pragma unroll 1
+  for (int nt = 0; nt < NT; ++nt) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kt = 0; kt < KT; ++kt) {
+      __syncthreads();  // every wave is done with the previous tile in s_w (and, first time, `in` is complete)
+      jtile_store(s_w, pre, tid);
+      __syncthreads();
+      // next tile of this layer, or the first tile of the next one: in flight under the arithmetic below
+      if (kt + 1 < KT) jtile_fetch(pre, W, KIN, nt * 64, (kt + 1) * 64, tid);
+      else if (nt + 1 < NT) jtile_fetch(pre, W, KIN, (nt + 1) * 64, 0, tid);
+      else if (Wnext) jtile_fetch(pre, Wnext, ldnext, 0, 0, tid);
+      const float* wrow = s_w + lane * JWL;
+#pragma unroll 4
+      for (int k4 = 0; k4 < 16; ++k4) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + 4 * k4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int i = tg + 8 * t;
+          if (i < J) {  // (wave-uniform)
+            const float* x = in + i * ild + kt * 64 + 4 * k4;
+            acc[t] = fmaf(wv.x, x[0], acc[t]);
+            acc[t] = fmaf(wv.y, x[1], acc[t]);
+            acc[t] = fmaf(wv.z, x[2], acc[t]);
+            acc[t] = fmaf(wv.w, x[3], acc[t]);
+          }
+        }
+      }
+    }
+    const int n = nt * 64 + lane;
+    const float bn = b[n];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = tg + 8 * t;
+      if (i < J) {
+        const float v = acc[t] + bn;
+        out[i * old + n] = gelu ? gelu_erf(v) : v;
+      }
+    }
+  }
+}
+// AdaLN over J tokens of 64 channels held in LDS: one wavefront per token (8 waves), lane = channel.
+__device__ __forceinline__ void adaln_small8(const float* in, float* out, const float* __restrict__ gb, int J, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int i = wave; i < J; i += 8) {
+    const float x = in[i * JLD + lane];
+    const float mean = wave_sum(x) * (1.0f / 64.0f);
+    const float d = x - mean;
+    const float var = wave_sum(d * d) * (1.0f / 63.0f);
+    out[i * JLD + lane] = gb[lane] * d / (sqrtf(var) + 1e-6f) + gb[64 + lane];
+  }
+}
+
+__global__ __launch_bounds__(JS_THREADS) void joint_stream_kernel(const float* __restrict__ xq_in, const float* __restrict__ jQ,
+                                                                  const float* __restrict__ kv, const float* __restrict__ GB,
+                                                                  int gb_stride, JointStreamW w, const float* __restrict__ jt,
+                                                                  float* __restrict__ y_out, float* __restrict__ pose_out, int J,
+                                                                  int stage) {
   __shared__ float s_y[32 * JLD];
   __shared__ float s_a[32 * JLD];
   __shared__ float s_q[32 * JLD];
-  __shared__ __attribute__((aligned(16))) float s_h[32 * 257];   // MLP hidden / qkv scratch (>= 32*193)
+  __shared__ __attribute__((aligned(16))) float s_h[32 * 257];   // MLP hidden / qkv scratch (>= 32*193); partial attention states
   __shared__ __attribute__((aligned(16))) float s_kv[64 * 128];  // one tile of 64 vertex keys: k | v
+  __shared__ __attribute__((aligned(16))) float s_w[64 * JWL];   // one 64 x 64 weight tile
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* gb = GB + (long long)b * gb_stride;
-  for (int idx = tid; idx < J * 64; idx += 256) {
+  JTile pre;
+  // the first weight tile this launch needs, requested before anything else
+  if (stage != 4) jtile_fetch(pre, w.wq, 64, 0, 0, tid);
+  else jtile_fetch(pre, w.qkv_w, 64, 0, 0, tid);
+  for (int idx = tid; idx < J * 64; idx += JS_THREADS) {
     const int i = idx >> 6, c = idx & 63;
     float v = xq_in[((long long)b * J + i) * 64 + c];
     if (jQ) v += jQ[i * 64 + c];
@@ -1205,17 +1297,20 @@ __global__ __launch_bounds__(256) void joint_stream_kernel(const float* __restri
   }
   __syncthreads();
   if (stage != 4) {  // stage 4 = joint_SA_FFN alone on xq (the reference's Block module, CoevoDecoder.py:102-105)
-    adaln_small(s_y, s_a, gb + w.i_normq * 128, J, tid);
+    adaln_small8(s_y, s_a, gb + w.i_normq * 128, J, tid);
+    lin_tiled<64, 64>(s_a, JLD, w.wq, w.bq, s_q, JLD, J, tid, false, s_w, pre, w.proj_w, 64);
     __syncthreads();
-    lin_small<64, 64>(s_a, JLD, w.wq, w.bq, s_q, JLD, J, tid, false);
-    __syncthreads();
-    // ---- attention over 431 keys: thread (i,h) for i<J, h<8 (J*8 <= 256) ----
+    // ---- attention over the 431 vertex keys, 8 heads of 8: thread = (key slice s, query i, head h).  P = 8 J (query, head) pairs,
+    // NSL = 512 / P key slices (3 at J = 17): slice s takes keys s, s + NSL, ... of every staged tile with its own online softmax
+    // (m, l, o[8]); the slices' states are merged once at the end.  Four keys per step: one rescale per step, four independent dots.
     {
-      const int i = tid >> 3, h = tid & 7;
-      const bool act = i < J;
+      const int P = J * 8, NSL = JS_THREADS / P;
+      const int pr = tid % P, sl = tid / P;
+      const int i = pr >> 3, h = pr & 7;
+      const bool act = sl < NSL;
       float qv[8], o[8];
       const float scale = 0.35355339059327376220f * 1.44269504088896340736f;  // 8^-0.5 (8 heads of 8) * log2(e): 2^x softmax
-  #pragma unroll
+#pragma unroll
       for (int d = 0; d < 8; ++d) {
         qv[d] = act ? s_q[i * JLD + 8 * h + d] * scale : 0.f;
         o[d] = 0.f;
@@ -1225,74 +1320,108 @@ __global__ __launch_bounds__(256) void joint_stream_kernel(const float* __restri
       for (int j0 = 0; j0 < NV; j0 += 64) {
         const int nj = min(64, NV - j0);
         __syncthreads();
-        for (int idx = tid; idx < nj * 32; idx += 256) {
+        for (int idx = tid; idx < nj * 32; idx += JS_THREADS) {
           const int r = idx >> 5, c4 = idx & 31;
           *reinterpret_cast<f32x4*>(&s_kv[r * 128 + 4 * c4]) =
               *reinterpret_cast<const f32x4*>(kvb + (long long)(j0 + r) * 128 + 4 * c4);
         }
         __syncthreads();
         if (act) {
-          for (int r = 0; r < nj; ++r) {
-            const f32x4 k0 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 8 * h]);
-            const f32x4 k1 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 8 * h + 4]);
-            const float sc = qv[0] * k0.x + qv[1] * k0.y + qv[2] * k0.z + qv[3] * k0.w + qv[4] * k1.x + qv[5] * k1.y +
-                             qv[6] * k1.z + qv[7] * k1.w;
-            const float mn = fmaxf(m, sc);
-            const float corr = __builtin_amdgcn_exp2f(m - mn), pj = __builtin_amdgcn_exp2f(sc - mn);
-            l = l * corr + pj;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 64 + 8 * h]);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 64 + 8 * h + 4]);
-            o[0] = o[0] * corr + pj * v0.x;
-            o[1] = o[1] * corr + pj * v0.y;
-            o[2] = o[2] * corr + pj * v0.z;
-            o[3] = o[3] * corr + pj * v0.w;
-            o[4] = o[4] * corr + pj * v1.x;
-            o[5] = o[5] * corr + pj * v1.y;
-            o[6] = o[6] * corr + pj * v1.z;
-            o[7] = o[7] * corr + pj * v1.w;
+          for (int r0 = sl; r0 < nj; r0 += 4 * NSL) {
+            float sc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int r = r0 + u * NSL;
+              if (r < nj) {
+                const f32x4 k0 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 8 * h]);
+                const f32x4 k1 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 8 * h + 4]);
+                sc[u] = qv[0] * k0.x + qv[1] * k0.y + qv[2] * k0.z + qv[3] * k0.w + qv[4] * k1.x + qv[5] * k1.y + qv[6] * k1.z +
+                        qv[7] * k1.w;
+              } else {
+                sc[u] = -INFINITY;
+              }
+            }
+            const float mn = fmaxf(fmaxf(m, fmaxf(sc[0], sc[1])), fmaxf(sc[2], sc[3]));   // finite: key r0 exists
+            const float corr = __builtin_amdgcn_exp2f(m - mn);
+            l *= corr;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) o[d] *= corr;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int r = r0 + u * NSL;
+              if (r < nj) {
+                const float pj = __builtin_amdgcn_exp2f(sc[u] - mn);
+                l += pj;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 64 + 8 * h]);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(&s_kv[r * 128 + 64 + 8 * h + 4]);
+                o[0] += pj * v0.x;
+                o[1] += pj * v0.y;
+                o[2] += pj * v0.z;
+                o[3] += pj * v0.w;
+                o[4] += pj * v1.x;
+                o[5] += pj * v1.y;
+                o[6] += pj * v1.z;
+                o[7] += pj * v1.w;
+              }
+            }
             m = mn;
           }
         }
       }
+      // merge the slices' states (s_h is free here): st[sl][pr] = {m, l, o[8]}
       if (act) {
-        const float inv = 1.0f / l;
-  #pragma unroll
-        for (int d = 0; d < 8; ++d) s_a[i * JLD + 8 * h + d] = o[d] * inv;
+        float* st = s_h + (sl * P + pr) * 10;
+        st[0] = m;
+        st[1] = l;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) st[2 + d] = o[d];
+      }
+      __syncthreads();
+      if (act && sl == 0) {
+        float M = m;
+        for (int s2 = 1; s2 < NSL; ++s2) M = fmaxf(M, s_h[(s2 * P + pr) * 10]);
+        float L = 0.f, O[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s2 = 0; s2 < NSL; ++s2) {
+          const float* st = s_h + (s2 * P + pr) * 10;
+          const float c = __builtin_amdgcn_exp2f(st[0] - M);   // (a slice that saw no key has m = -inf, l = 0: contributes 0)
+          L += st[1] * c;
+#pragma unroll
+          for (int d = 0; d < 8; ++d) O[d] += st[2 + d] * c;
+        }
+        const float inv = 1.0f / L;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) s_a[i * JLD + 8 * h + d] = O[d] * inv;
       }
     }
+    lin_tiled<64, 64>(s_a, JLD, w.proj_w, w.proj_b, s_q, JLD, J, tid, false, s_w, pre, stage == 1 ? nullptr : w.fc1_w, 64);
     __syncthreads();
-    lin_small<64, 64>(s_a, JLD, w.proj_w, w.proj_b, s_q, JLD, J, tid, false);
-    __syncthreads();
-    for (int idx = tid; idx < J * 64; idx += 256) {
+    for (int idx = tid; idx < J * 64; idx += JS_THREADS) {
       const int i = idx >> 6, c = idx & 63;
       s_y[i * JLD + c] += s_q[i * JLD + c];
     }
     __syncthreads();
     if (stage == 1) {
-      for (int idx = tid; idx < J * 64; idx += 256) y_out[(long long)b * J * 64 + idx] = s_y[(idx >> 6) * JLD + (idx & 63)];
+      for (int idx = tid; idx < J * 64; idx += JS_THREADS) y_out[(long long)b * J * 64 + idx] = s_y[(idx >> 6) * JLD + (idx & 63)];
       return;
     }
     // ---- FFN of the cross-attention block ----
-    adaln_small(s_y, s_a, gb + w.i_norm2 * 128, J, tid);
+    adaln_small8(s_y, s_a, gb + w.i_norm2 * 128, J, tid);
+    lin_tiled<64, 256>(s_a, JLD, w.fc1_w, w.fc1_b, s_h, 257, J, tid, true, s_w, pre, w.fc2_w, 256);
+    lin_tiled<256, 64>(s_h, 257, w.fc2_w, w.fc2_b, s_q, JLD, J, tid, false, s_w, pre, stage == 2 ? nullptr : w.qkv_w, 64);
     __syncthreads();
-    lin_small<64, 256>(s_a, JLD, w.fc1_w, w.fc1_b, s_h, 257, J, tid, true);
-    __syncthreads();
-    lin_small<256, 64>(s_h, 257, w.fc2_w, w.fc2_b, s_q, JLD, J, tid, false);
-    __syncthreads();
-    for (int idx = tid; idx < J * 64; idx += 256) {
+    for (int idx = tid; idx < J * 64; idx += JS_THREADS) {
       const int i = idx >> 6, c = idx & 63;
       s_y[i * JLD + c] += s_q[i * JLD + c];
     }
     __syncthreads();
     if (stage == 2) {
-      for (int idx = tid; idx < J * 64; idx += 256) y_out[(long long)b * J * 64 + idx] = s_y[(idx >> 6) * JLD + (idx & 63)];
+      for (int idx = tid; idx < J * 64; idx += JS_THREADS) y_out[(long long)b * J * 64 + idx] = s_y[(idx >> 6) * JLD + (idx & 63)];
       return;
     }
   }
   // ---- self-attention block over the J joint tokens (8 heads of 8) ----
-  adaln_small(s_y, s_a, gb + w.i_snorm1 * 128, J, tid);
-  __syncthreads();
-  lin_small<64, 192>(s_a, JLD, w.qkv_w, w.qkv_b, s_h, 193, J, tid, false);
+  adaln_small8(s_y, s_a, gb + w.i_snorm1 * 128, J, tid);
+  lin_tiled<64, 192>(s_a, JLD, w.qkv_w, w.qkv_b, s_h, 193, J, tid, false, s_w, pre, w.sproj_w, 64);
   __syncthreads();
   {
     const int i = tid >> 3, h = tid & 7;
@@ -1321,30 +1450,27 @@ __global__ __launch_bounds__(256) void joint_stream_kernel(const float* __restri
       for (int d = 0; d < 8; ++d) s_a[i * JLD + 8 * h + d] = o[d] * inv;
     }
   }
+  lin_tiled<64, 64>(s_a, JLD, w.sproj_w, w.sproj_b, s_q, JLD, J, tid, false, s_w, pre, w.sfc1_w, 64);
   __syncthreads();
-  lin_small<64, 64>(s_a, JLD, w.sproj_w, w.sproj_b, s_q, JLD, J, tid, false);
-  __syncthreads();
-  for (int idx = tid; idx < J * 64; idx += 256) {
+  for (int idx = tid; idx < J * 64; idx += JS_THREADS) {
     const int i = idx >> 6, c = idx & 63;
     s_y[i * JLD + c] += s_q[i * JLD + c];
   }
   __syncthreads();
-  adaln_small(s_y, s_a, gb + w.i_snorm2 * 128, J, tid);
+  adaln_small8(s_y, s_a, gb + w.i_snorm2 * 128, J, tid);
+  lin_tiled<64, 256>(s_a, JLD, w.sfc1_w, w.sfc1_b, s_h, 257, J, tid, true, s_w, pre, w.sfc2_w, 256);
+  lin_tiled<256, 64>(s_h, 257, w.sfc2_w, w.sfc2_b, s_q, JLD, J, tid, false, s_w, pre, nullptr, 0);
   __syncthreads();
-  lin_small<64, 256>(s_a, JLD, w.sfc1_w, w.sfc1_b, s_h, 257, J, tid, true);
-  __syncthreads();
-  lin_small<256, 64>(s_h, 257, w.sfc2_w, w.sfc2_b, s_q, JLD, J, tid, false);
-  __syncthreads();
-  for (int idx = tid; idx < J * 64; idx += 256) {
+  for (int idx = tid; idx < J * 64; idx += JS_THREADS) {
     const int i = idx >> 6, c = idx & 63;
     s_y[i * JLD + c] += s_q[i * JLD + c];
   }
   __syncthreads();
   if (y_out)
-    for (int idx = tid; idx < J * 64; idx += 256) y_out[(long long)b * J * 64 + idx] = s_y[(idx >> 6) * JLD + (idx & 63)];
+    for (int idx = tid; idx < J * 64; idx += JS_THREADS) y_out[(long long)b * J * 64 + idx] = s_y[(idx >> 6) * JLD + (idx & 63)];
   // ---- proj_joint_feat2coor + residual on the ORIGINAL joints (CoevoDecoder.py:189) ----
   if (pose_out) {
-    for (int idx = tid; idx < J * 3; idx += 256) {
+    for (int idx = tid; idx < J * 3; idx += JS_THREADS) {
       const int i = idx / 3, k = idx % 3;
       float s = 0.f;
       for (int c = 0; c < 64; ++c) s += w.coor_w[k * 64 + c] * s_y[i * JLD + c];
@@ -1533,7 +1659,7 @@ extern "C" int pmce_joint_stream_f32(const float* xq, const float* jQ, const flo
   w.sfc1_w = wptr[12]; w.sfc1_b = wptr[13]; w.sfc2_w = wptr[14]; w.sfc2_b = wptr[15];
   w.coor_w = wptr[16]; w.coor_b = wptr[17];
   w.i_normq = inst[0]; w.i_norm2 = inst[1]; w.i_snorm1 = inst[2]; w.i_snorm2 = inst[3];
-  hipLaunchKernelGGL(joint_stream_kernel, dim3(B), dim3(256), 0, stream, xq, jQ, kv, GB, gb_stride, w, jt, y_out, pose_out, J,
+  hipLaunchKernelGGL(joint_stream_kernel, dim3(B), dim3(JS_THREADS), 0, stream, xq, jQ, kv, GB, gb_stride, w, jt, y_out, pose_out, J,
                      stage);
   return pmce_check_launch("joint_stream");
 }

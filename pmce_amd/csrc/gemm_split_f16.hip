@@ -69,11 +69,6 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
   constexpr int GROUP_M = 8;
   const int per_group = GROUP_M * p.ntn;
   auto tile_coords = [&](int bid, int& mb, int& nb) {
-    if (p.order == 1) {  // panel-major: the ntn column tiles of a row panel run side by side, so an A panel is fetched from HBM once
-      mb = (bid / p.ntn) * BM;
-      nb = (bid % p.ntn) * BN;
-      return;
-    }
     const int group = bid / per_group;
     const int first_m = group * GROUP_M;
     const int gsz = min(p.ntm - first_m, GROUP_M);
@@ -401,7 +396,6 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
 // ---- launch ---------------------------------------------------------------------------------------------------------------
 static std::atomic<int> g_split_tile{pmce_env_int("PMCE_SPLIT_TILE", -1)};
 static std::atomic<int> g_split_skew{pmce_env_int("PMCE_SPLIT_SKEW", -1)};
-static const int g_split_order = pmce_env_int("PMCE_SPLIT_ORDER", 0);  // A/B knob, read once at load
 static std::atomic<unsigned long long*> g_split_clk{nullptr};
 extern "C" int pmce_gemm_split_set_clock_probe(unsigned long long* device_two_words) {
   g_split_clk.store(device_two_words, std::memory_order_relaxed);
@@ -487,7 +481,6 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
   p.M = M; p.N = N; p.K = K; p.lda = (unsigned)lda; p.ldc = (unsigned)ldc;
   p.c_div = c_div; p.c_lo = c_lo; p.c_hi = c_hi;
   p.oflow = pmce_overflow_sink();
-  p.order = g_split_order;
   p.clk = g_split_clk.load(std::memory_order_relaxed);
   {  // half a tile of matrix time: nk iterations x 3*TM*TN instructions x 32 cycles (TM*TN = 8 or 4), / 2, in 4096-cycle units
     const int knob = g_split_skew.load(std::memory_order_relaxed);

@@ -225,13 +225,23 @@ class HipModuleBase(nn.Module):
         return self._ensure_packed().gemm_mode()
 
     def overflowed(self, synchronize: bool = True) -> bool:
-        """True if a call on this module ran out of the split-f16 form's range (|activation| > 65504 in a product operand, or fp32
-        overflow): the outputs of that call are invalid, and further forwards raise PmceError until :meth:`clear_overflow`.
-        ``set_gemm_mode('f32')`` has fp32's own range."""
+        """True if a product of a call on this module produced a non-finite value: non-finite INPUTS (they propagate into the
+        outputs of their own clip, as in the reference), an intermediate activation beyond f16's range under exotic weights, or
+        fp32 overflow.  Finite inputs of any magnitude are in range (img_feat is row-scaled before its products).  The word only
+        reports; the affected clips' outputs are inf / nan, other clips and later calls are unaffected.
+        ``set_overflow_policy(strict=True)`` makes further forwards raise PmceError until :meth:`clear_overflow`;
+        ``PMCE.forward_checked`` re-runs an offending batch on the fp32 pipe; ``set_gemm_mode('f32')`` has fp32's range throughout."""
         eng = self._ensure_packed()
         if synchronize:
             torch.cuda.synchronize(eng.device)
         return eng.overflowed()
+
+    def set_overflow_policy(self, strict: bool = False):
+        """strict=True: while the overflow word is set every further call raises (round-3 behaviour); default: report only."""
+        self._strict_overflow = bool(strict)
+        eng = self._ensure_packed()
+        eng.set_overflow_policy(self._strict_overflow)
+        eng.strict_overflow = self._strict_overflow
 
     def clear_overflow(self):
         self._ensure_packed().clear_overflow()

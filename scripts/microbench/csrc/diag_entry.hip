@@ -26,7 +26,6 @@ extern "C" int pmce_diag_gemm_nt_split_f16(int kind, const float* A, const float
   p.oflow = nullptr;
   p.clk = nullptr;
   p.skew = (K / 16) * 12 * 32 / 4096 + 1;
-  p.order = 0;
   if (kind == 0) {
     PMCE_REQUIRE(pmce_gemm_split_ws_wants(M, N, K, a_packed, 0), "diag gemm_split: the wave-specialised kernel does not apply to this product");
     PMCE_TRY(pmce_gemm_split_ws_launch(p, act, c_packed, stream));

@@ -14,7 +14,6 @@ _f, _i, _l, _s, _fl = C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_float
 PROTOTYPES = {
     "pmce_diag_gemm_nt_split_f16": [_i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _l, _l, _i, _i, _i, _i, _s],
     "pmce_gemm_ws_timeouts": [],
-    "pmce_gemm_ws_set_dbg": [_i],
     "pmce_dbg_victim": [_i, _f, _i, _i, _f, _s],
     "pmce_dbg_mfma_spin": [_i, _f, _i, _i, _s],
     "pmce_dbg_mfma_subnormal": [_fl, _fl, _f, _s],

@@ -85,9 +85,12 @@ def test_eval_sharded_script_two_ranks_vs_metrics_oracle():
 
 
 def test_stream_bench_script():
+    from pmce_amd import streaming
     L = 700
     got = _run_script("stream_bench.py", ["--frames", str(L), "--batch", "128"])
-    assert got["frames"] == L and got["windows"] == L - 15 and got["samples"] == L - 15     # stride-1 windows (lib/_img_utils.py:27-55)
+    nwin = len(streaming.window_indices(L))      # stride-1 windows, tail dropped to the last full VIBE chunk (lib/_img_utils.py:27-55): 673
+    assert nwin == (L // 16) * 16 - 15
+    assert got["frames"] == L and got["windows"] == nwin and got["samples"] == nwin
     assert got["windows_per_s"] > 0 and got["nonfinite_samples"] == 0
     assert all(np.isfinite(got[k]) for k in ("MPVPE", "MPJPE", "PA-MPJPE", "ACCEL"))
     r = got["roofline"]
