@@ -5,8 +5,11 @@ from __future__ import annotations
 import ctypes as C
 import os.path as osp
 
+import os
+
 HERE = osp.dirname(osp.abspath(__file__))
-LIB_PATH = osp.join(HERE, "libpmce_hip.so")
+# PMCE_LIB_PATH: another build of the SAME library (scripts/build_variant.sh: A/B runs of two revisions inside one GPU session)
+LIB_PATH = os.environ.get("PMCE_LIB_PATH") or osp.join(HERE, "libpmce_hip.so")
 
 _f = C.c_void_p      # device pointer (float*/int*)
 _i = C.c_int

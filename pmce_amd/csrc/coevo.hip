@@ -1222,6 +1222,8 @@ __device__ __forceinline__ void lin_tiled(const float* in, int ild, const float*
 #pragma unroll 1
   for (int nt = 0; nt < NT; ++nt) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int n = nt * 64 + lane;
+    const float bn = b[n];  // requested here: in flight under the tile's arithmetic
 #pragma unroll 1
     for (int kt = 0; kt < KT; ++kt) {
       __syncthreads();  // every wave is done with the previous tile in s_w (and, first time, `in` is complete)
@@ -1248,8 +1250,6 @@ __device__ __forceinline__ void lin_tiled(const float* in, int ild, const float*
         }
       }
     }
-    const int n = nt * 64 + lane;
-    const float bn = b[n];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int i = tg + 8 * t;
@@ -1283,8 +1283,17 @@ __global__ __launch_bounds__(JS_THREADS) void joint_stream_kernel(const float* _
   __shared__ __attribute__((aligned(16))) float s_h[32 * 257];   // MLP hidden / qkv scratch (>= 32*193); partial attention states
   __shared__ __attribute__((aligned(16))) float s_kv[64 * 128];  // one tile of 64 vertex keys: k | v
   __shared__ __attribute__((aligned(16))) float s_w[64 * JWL];   // one 64 x 64 weight tile
+  __shared__ float s_gb[4 * 128];                                // this clip's gamma | beta of the four AdaLN instances
+  __shared__ float s_cw[3 * 64 + 3];                             // proj_joint_feat2coor
   const int b = blockIdx.x, tid = threadIdx.x;
-  const float* gb = GB + (long long)b * gb_stride;
+  {  // small per-clip / per-launch operands, fetched once up front instead of at their (latency-exposed) points of use
+    const float* gbg = GB + (long long)b * gb_stride;
+    const int inst = tid >> 7, c = tid & 127;
+    const int ii = inst == 0 ? w.i_normq : inst == 1 ? w.i_norm2 : inst == 2 ? w.i_snorm1 : w.i_snorm2;
+    s_gb[inst * 128 + c] = gbg[ii * 128 + c];
+    if (tid < 192) s_cw[tid] = w.coor_w[tid];
+    if (tid < 3) s_cw[192 + tid] = w.coor_b[tid];
+  }
   JTile pre;
   // the first weight tile this launch needs, requested before anything else
   if (stage != 4) jtile_fetch(pre, w.wq, 64, 0, 0, tid);
@@ -1297,7 +1306,7 @@ __global__ __launch_bounds__(JS_THREADS) void joint_stream_kernel(const float* _
   }
   __syncthreads();
   if (stage != 4) {  // stage 4 = joint_SA_FFN alone on xq (the reference's Block module, CoevoDecoder.py:102-105)
-    adaln_small8(s_y, s_a, gb + w.i_normq * 128, J, tid);
+    adaln_small8(s_y, s_a, s_gb + 0 * 128, J, tid);
     lin_tiled<64, 64>(s_a, JLD, w.wq, w.bq, s_q, JLD, J, tid, false, s_w, pre, w.proj_w, 64);
     __syncthreads();
     // ---- attention over the 431 vertex keys, 8 heads of 8: thread = (key slice s, query i, head h).  P = 8 J (query, head) pairs,
@@ -1317,15 +1326,27 @@ __global__ __launch_bounds__(JS_THREADS) void joint_stream_kernel(const float* _
       }
       float m = -INFINITY, l = 0.f;
       const float* kvb = kv + (long long)b * NV * 128;
+      // a tile of 64 keys (k | v: 32 KB) = 4 x 16 B per thread; the NEXT tile travels global -> registers under this tile's arithmetic
+      f32x4 kvr[4];
+      auto kv_fetch = [&](int j0) {
+        const int nj = min(64, NV - j0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int idx = tid + q * JS_THREADS, r = idx >> 5, c4 = idx & 31;
+          if (r < nj) kvr[q] = *reinterpret_cast<const f32x4*>(kvb + (long long)(j0 + r) * 128 + 4 * c4);
+        }
+      };
+      kv_fetch(0);
       for (int j0 = 0; j0 < NV; j0 += 64) {
         const int nj = min(64, NV - j0);
         __syncthreads();
-        for (int idx = tid; idx < nj * 32; idx += JS_THREADS) {
-          const int r = idx >> 5, c4 = idx & 31;
-          *reinterpret_cast<f32x4*>(&s_kv[r * 128 + 4 * c4]) =
-              *reinterpret_cast<const f32x4*>(kvb + (long long)(j0 + r) * 128 + 4 * c4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int idx = tid + q * JS_THREADS, r = idx >> 5, c4 = idx & 31;
+          if (r < nj) *reinterpret_cast<f32x4*>(&s_kv[r * 128 + 4 * c4]) = kvr[q];
         }
         __syncthreads();
+        if (j0 + 64 < NV) kv_fetch(j0 + 64);
         if (act) {
           for (int r0 = sl; r0 < nj; r0 += 4 * NSL) {
             float sc[4];
@@ -1405,7 +1426,7 @@ __global__ __launch_bounds__(JS_THREADS) void joint_stream_kernel(const float* _
       return;
     }
     // ---- FFN of the cross-attention block ----
-    adaln_small8(s_y, s_a, gb + w.i_norm2 * 128, J, tid);
+    adaln_small8(s_y, s_a, s_gb + 1 * 128, J, tid);
     lin_tiled<64, 256>(s_a, JLD, w.fc1_w, w.fc1_b, s_h, 257, J, tid, true, s_w, pre, w.fc2_w, 256);
     lin_tiled<256, 64>(s_h, 257, w.fc2_w, w.fc2_b, s_q, JLD, J, tid, false, s_w, pre, stage == 2 ? nullptr : w.qkv_w, 64);
     __syncthreads();
@@ -1420,7 +1441,7 @@ __global__ __launch_bounds__(JS_THREADS) void joint_stream_kernel(const float* _
     }
   }
   // ---- self-attention block over the J joint tokens (8 heads of 8) ----
-  adaln_small8(s_y, s_a, gb + w.i_snorm1 * 128, J, tid);
+  adaln_small8(s_y, s_a, s_gb + 2 * 128, J, tid);
   lin_tiled<64, 192>(s_a, JLD, w.qkv_w, w.qkv_b, s_h, 193, J, tid, false, s_w, pre, w.sproj_w, 64);
   __syncthreads();
   {
@@ -1457,7 +1478,7 @@ __global__ __launch_bounds__(JS_THREADS) void joint_stream_kernel(const float* _
     s_y[i * JLD + c] += s_q[i * JLD + c];
   }
   __syncthreads();
-  adaln_small8(s_y, s_a, gb + w.i_snorm2 * 128, J, tid);
+  adaln_small8(s_y, s_a, s_gb + 3 * 128, J, tid);
   lin_tiled<64, 256>(s_a, JLD, w.sfc1_w, w.sfc1_b, s_h, 257, J, tid, true, s_w, pre, w.sfc2_w, 256);
   lin_tiled<256, 64>(s_h, 257, w.sfc2_w, w.sfc2_b, s_q, JLD, J, tid, false, s_w, pre, nullptr, 0);
   __syncthreads();
@@ -1473,8 +1494,8 @@ __global__ __launch_bounds__(JS_THREADS) void joint_stream_kernel(const float* _
     for (int idx = tid; idx < J * 3; idx += JS_THREADS) {
       const int i = idx / 3, k = idx % 3;
       float s = 0.f;
-      for (int c = 0; c < 64; ++c) s += w.coor_w[k * 64 + c] * s_y[i * JLD + c];
-      pose_out[((long long)b * J + i) * 3 + k] = (s + w.coor_b[k]) + jt[((long long)b * J + i) * 3 + k];
+      for (int c = 0; c < 64; ++c) s += s_cw[k * 64 + c] * s_y[i * JLD + c];
+      pose_out[((long long)b * J + i) * 3 + k] = (s + s_cw[192 + k]) + jt[((long long)b * J + i) * 3 + k];
     }
   }
 }
