@@ -41,29 +41,85 @@ __global__ __launch_bounds__(256) void vertex_init_gather_kernel(const float* __
 // ======================================================================================================
 #define JLD 65  // LDS row stride for [J][64] buffers
 
-// out[i][n] = act(b[n] + sum_k W[n*KIN+k] * in[i*ild + k]) for i < J, n < NOUT (all 256 threads cooperate)
-template <int KIN, int NOUT>
-__device__ __forceinline__ void lin_small(const float* in, int ild, const float* __restrict__ W, const float* __restrict__ b,
-                                          float* out, int old, int J, int tid, bool gelu) {
-  for (int idx = tid; idx < J * NOUT; idx += 256) {
-    const int i = idx / NOUT, n = idx % NOUT;
-    const float* w = W + (long long)n * KIN;
-    const float* x = in + i * ild;
-    float s = 0.f;
-#pragma unroll 8
-    for (int k4 = 0; k4 < KIN / 4; ++k4) {
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(w + 4 * k4);
-      s += wv.x * x[4 * k4] + wv.y * x[4 * k4 + 1] + wv.z * x[4 * k4 + 2] + wv.w * x[4 * k4 + 3];
-    }
-    s += b[n];
-    out[i * old + n] = gelu ? gelu_erf(s) : s;
+// ---- weight tiles for the per-clip kernels' Linear layers (joint_stream, ca_fold) --------------------------------------------------------------------------
+// A 64 x 64 tile W[n0 .. n0+63][k0 .. k0+63] of a row-major [NOUT][KIN] nn.Linear weight travels global -> registers (coalesced:
+// 16 lanes x 16 B cover a row's 256 bytes, a wave instruction four rows) -> LDS [64][JWL] (row stride 68 floats: 16-byte aligned
+// rows, conflict-free ds_read_b128 with lane = row).  Until round 4 every lane walked its OWN weight row in global memory (64 cache
+// lines per load instruction): 6,000 such instructions made 180 of the kernel's 233 us.
+#define JWL 68
+#define JS_THREADS 512
+struct JTile {
+  f32x4 r[2];  // 512 threads x 2 x 16 B = one 16 KB tile
+};
+__device__ __forceinline__ void jtile_fetch(JTile& t, const float* __restrict__ W, int ld, int n0, int k0, int tid) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = (tid >> 4) + 32 * q, c4 = tid & 15;
+    t.r[q] = *reinterpret_cast<const f32x4*>(W + (long long)(n0 + row) * ld + k0 + 4 * c4);
   }
 }
-
-// AdaLN over J tokens of 64 channels held in LDS: one wavefront per token, lane = channel.
-__device__ __forceinline__ void adaln_small(const float* in, float* out, const float* __restrict__ gb, int J, int tid) {
+__device__ __forceinline__ void jtile_store(float* s_w, const JTile& t, int tid) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = (tid >> 4) + 32 * q, c4 = tid & 15;
+    *reinterpret_cast<f32x4*>(s_w + row * JWL + 4 * c4) = t.r[q];
+  }
+}
+// out[i][n] = act(b[n] + sum_k W[n][k] in[i][k]) for i < J: 512 threads = 64 output columns (lane) x 8 token groups (wave; tokens
+// i = wave, wave + 8, ...: at most 4 for J <= 32).  The k order of every sum is 0, 1, 2, ... as in the reference's dot product.
+// `pre` holds this layer's FIRST tile on entry (fetched by the previous phase, so its latency hid under that phase's arithmetic) and
+// the NEXT layer's first tile (Wnext, ldnext; null = none) on return.
+template <int KIN, int NOUT>
+__device__ __forceinline__ void lin_tiled(const float* in, int ild, const float* __restrict__ W, const float* __restrict__ b, float* out,
+                                          int old, int J, int tid, bool gelu, float* s_w, JTile& pre, const float* __restrict__ Wnext,
+                                          int ldnext) {
+  constexpr int NT = NOUT / 64, KT = KIN / 64;
+  const int lane = tid & 63, tg = tid >> 6;
+#pragma unroll 1
+  for (int nt = 0; nt < NT; ++nt) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int n = nt * 64 + lane;
+    const float bn = b[n];  // requested here: in flight under the tile's arithmetic
+#pragma unroll 1
+    for (int kt = 0; kt < KT; ++kt) {
+      __syncthreads();  // every wave is done with the previous tile in s_w (and, first time, `in` is complete)
+      jtile_store(s_w, pre, tid);
+      __syncthreads();
+      // next tile of this layer, or the first tile of the next one: in flight under the arithmetic below
+      if (kt + 1 < KT) jtile_fetch(pre, W, KIN, nt * 64, (kt + 1) * 64, tid);
+      else if (nt + 1 < NT) jtile_fetch(pre, W, KIN, (nt + 1) * 64, 0, tid);
+      else if (Wnext) jtile_fetch(pre, Wnext, ldnext, 0, 0, tid);
+      const float* wrow = s_w + lane * JWL;
+#pragma unroll 4
+      for (int k4 = 0; k4 < 16; ++k4) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + 4 * k4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int i = tg + 8 * t;
+          if (i < J) {  // (wave-uniform)
+            const float* x = in + i * ild + kt * 64 + 4 * k4;
+            acc[t] = fmaf(wv.x, x[0], acc[t]);
+            acc[t] = fmaf(wv.y, x[1], acc[t]);
+            acc[t] = fmaf(wv.z, x[2], acc[t]);
+            acc[t] = fmaf(wv.w, x[3], acc[t]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = tg + 8 * t;
+      if (i < J) {
+        const float v = acc[t] + bn;
+        out[i * old + n] = gelu ? gelu_erf(v) : v;
+      }
+    }
+  }
+}
+// AdaLN over J tokens of 64 channels held in LDS: one wavefront per token (8 waves), lane = channel.
+__device__ __forceinline__ void adaln_small8(const float* in, float* out, const float* __restrict__ gb, int J, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
-  for (int i = wave; i < J; i += 4) {
+  for (int i = wave; i < J; i += 8) {
     const float x = in[i * JLD + lane];
     const float mean = wave_sum(x) * (1.0f / 64.0f);
     const float d = x - mean;
@@ -75,25 +131,27 @@ __device__ __forceinline__ void adaln_small(const float* in, float* out, const f
 // ======================================================================================================
 // joint_embed: jf[b][i][:] = Wj*jt + bj + jpos[i] ; xk[b][i][:] = Wj2v*jf + bj2v + j2vK[i]
 // ======================================================================================================
-__global__ __launch_bounds__(256) void joint_embed_kernel(const float* __restrict__ jt, const float* __restrict__ Wj,
-                                                          const float* __restrict__ bj, const float* __restrict__ jpos,
-                                                          const float* __restrict__ Wj2v, const float* __restrict__ bj2v,
-                                                          const float* __restrict__ j2vK, float* __restrict__ jf,
-                                                          float* __restrict__ xk, int J) {
+__global__ __launch_bounds__(JS_THREADS) void joint_embed_kernel(const float* __restrict__ jt, const float* __restrict__ Wj,
+                                                                 const float* __restrict__ bj, const float* __restrict__ jpos,
+                                                                 const float* __restrict__ Wj2v, const float* __restrict__ bj2v,
+                                                                 const float* __restrict__ j2vK, float* __restrict__ jf,
+                                                                 float* __restrict__ xk, int J) {
   __shared__ float s_jf[32 * JLD];
   __shared__ float s_xk[32 * JLD];
+  __shared__ __attribute__((aligned(16))) float s_w[64 * JWL];
   const int b = blockIdx.x, tid = threadIdx.x;
-  for (int idx = tid; idx < J * 64; idx += 256) {
+  JTile pre;
+  jtile_fetch(pre, Wj2v, 64, 0, 0, tid);
+  for (int idx = tid; idx < J * 64; idx += JS_THREADS) {
     const int i = idx >> 6, c = idx & 63;
     const float* p = jt + ((long long)b * J + i) * 3;
     const float v = ((Wj[c * 3] * p[0] + Wj[c * 3 + 1] * p[1] + Wj[c * 3 + 2] * p[2]) + bj[c]) + jpos[i * 64 + c];
     s_jf[i * JLD + c] = v;
     jf[((long long)b * J + i) * 64 + c] = v;
   }
+  lin_tiled<64, 64>(s_jf, JLD, Wj2v, bj2v, s_xk, JLD, J, tid, false, s_w, pre, nullptr, 0);
   __syncthreads();
-  lin_small<64, 64>(s_jf, JLD, Wj2v, bj2v, s_xk, JLD, J, tid, false);
-  __syncthreads();
-  for (int idx = tid; idx < J * 64; idx += 256) {
+  for (int idx = tid; idx < J * 64; idx += JS_THREADS) {
     const int i = idx >> 6, c = idx & 63;
     xk[((long long)b * J + i) * 64 + c] = s_xk[i * JLD + c] + j2vK[i * 64 + c];
   }
@@ -111,49 +169,66 @@ __global__ __launch_bounds__(256) void joint_embed_kernel(const float* __restric
 // CrossAttention.forward (CoevoDecoder.py:47-62) after AdaLN (:83); only the summation order differs.
 // gbq/gbk/gbv: this clip's [gamma|beta] (128 floats) of normq/normk/normv.
 // ======================================================================================================
-__global__ __launch_bounds__(256) void ca_fold_kernel(const float* __restrict__ xk, const float* __restrict__ xv,
-                                                      const float* __restrict__ GB, int gb_stride, int iq, int ik, int iv,
-                                                      const float* __restrict__ Wq, const float* __restrict__ bq,
-                                                      const float* __restrict__ Wk, const float* __restrict__ bk,
-                                                      const float* __restrict__ Wv, const float* __restrict__ bv,
-                                                      const float* __restrict__ Wp, float* __restrict__ Kf,
-                                                      float* __restrict__ s0, float* __restrict__ Vf, int J) {
+__global__ __launch_bounds__(JS_THREADS) void ca_fold_kernel(const float* __restrict__ xk, const float* __restrict__ xv,
+                                                             const float* __restrict__ GB, int gb_stride, int iq, int ik, int iv,
+                                                             const float* __restrict__ Wq, const float* __restrict__ bq,
+                                                             const float* __restrict__ Wk, const float* __restrict__ bk,
+                                                             const float* __restrict__ Wv, const float* __restrict__ bv,
+                                                             const float* __restrict__ Wp, float* __restrict__ Kf,
+                                                             float* __restrict__ s0, float* __restrict__ Vf, int J) {
   __shared__ float s_a[32 * JLD];
   __shared__ float s_b[32 * JLD];
   __shared__ float s_k[32 * JLD];
   __shared__ float s_v[32 * JLD];
+  __shared__ __attribute__((aligned(16))) float s_w[64 * JWL];    // Wk, Wv, then Wq (64 x 64 tiles through lin_tiled's ring of one)
+  __shared__ __attribute__((aligned(16))) float s_wp[64 * JWL];   // Wproj
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* gb = GB + (long long)b * gb_stride;
-  for (int idx = tid; idx < J * 64; idx += 256) {
+  // all four 64 x 64 weights travel as coalesced tiles (until round 4 each lane walked its own weight row in global memory)
+  JTile pre, prep;
+  jtile_fetch(pre, Wk, 64, 0, 0, tid);
+  jtile_fetch(prep, Wp, 64, 0, 0, tid);
+  const float gq = gb[iq * 128 + lane], bqv = gb[iq * 128 + 64 + lane];
+  for (int idx = tid; idx < J * 64; idx += JS_THREADS) {
     const int i = idx >> 6, c = idx & 63;
     s_a[i * JLD + c] = xk[((long long)b * J + i) * 64 + c];
     s_b[i * JLD + c] = xv[((long long)b * J + i) * 64 + c];
   }
+  jtile_store(s_wp, prep, tid);
   __syncthreads();
-  adaln_small(s_a, s_k, gb + ik * 128, J, tid);  // s_k = AdaLN_k(xk)
-  adaln_small(s_b, s_v, gb + iv * 128, J, tid);  // s_v = AdaLN_v(xv)
+  adaln_small8(s_a, s_k, gb + ik * 128, J, tid);  // s_k = AdaLN_k(xk)
+  adaln_small8(s_b, s_v, gb + iv * 128, J, tid);  // s_v = AdaLN_v(xv)
+  lin_tiled<64, 64>(s_k, JLD, Wk, bk, s_a, JLD, J, tid, false, s_w, pre, Wv, 64);  // s_a = k
+  lin_tiled<64, 64>(s_v, JLD, Wv, bv, s_b, JLD, J, tid, false, s_w, pre, Wq, 64);  // s_b = v
   __syncthreads();
-  lin_small<64, 64>(s_k, JLD, Wk, bk, s_a, JLD, J, tid, false);  // s_a = k
-  lin_small<64, 64>(s_v, JLD, Wv, bv, s_b, JLD, J, tid, false);  // s_b = v
+  jtile_store(s_w, pre, tid);  // Wq
   __syncthreads();
   // 32^-0.5 (vertx heads = 2, head_dim 32; CoevoDecoder.py:140,37-38) times log2(e): vertex_ca's softmax runs on the
   // hardware 2^x, so the folded scores are produced directly in log2 units
   const float scale = 0.17677669529663688110f * 1.44269504088896340736f;
-  const float gq = gb[iq * 128 + lane], bqv = gb[iq * 128 + 64 + lane];
   float* Kfb = Kf + (long long)b * 64 * 64;
   float* Vfb = Vf + (long long)b * 64 * 64;
   float* s0b = s0 + (long long)b * 64;
   // one wavefront per (h,i) row, lane = channel c
-  for (int row = wave; row < 64; row += 4) {
+  for (int row = wave; row < 64; row += 8) {
     const int h = row >> 5, i = row & 31;
     float kf = 0.f, vf = 0.f, sc = 0.f;
     if (i < J) {
       float M = 0.f;
-#pragma unroll 8
-      for (int d = 0; d < 32; ++d) {
-        const float kd = s_a[i * JLD + 32 * h + d];
-        M += Wq[(32 * h + d) * 64 + lane] * kd;
-        vf += s_b[i * JLD + 32 * h + d] * Wp[lane * 64 + 32 * h + d];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 wp4 = *reinterpret_cast<const f32x4*>(s_wp + lane * JWL + 32 * h + 4 * q);   // Wp[c = lane][32h + 4q ..]
+        const float* kd = s_a + i * JLD + 32 * h + 4 * q;
+        const float* vd = s_b + i * JLD + 32 * h + 4 * q;
+        const float* wq = s_w + (32 * h + 4 * q) * JWL + lane;                                   // Wq[32h + d][c = lane]
+        M += wq[0] * kd[0];
+        vf += vd[0] * wp4.x;
+        M += wq[JWL] * kd[1];
+        vf += vd[1] * wp4.y;
+        M += wq[2 * JWL] * kd[2];
+        vf += vd[2] * wp4.z;
+        M += wq[3 * JWL] * kd[3];
+        vf += vd[3] * wp4.w;
       }
       kf = scale * gq * M;
       float t = bqv * M;
@@ -1185,93 +1260,6 @@ struct JointStreamW {
   int i_normq, i_norm2, i_snorm1, i_snorm2;                     // AdaLN instance indices into GB
 };
 
-// ---- weight tiles for the joint stream's Linear layers --------------------------------------------------------------------------
-// A 64 x 64 tile W[n0 .. n0+63][k0 .. k0+63] of a row-major [NOUT][KIN] nn.Linear weight travels global -> registers (coalesced:
-// 16 lanes x 16 B cover a row's 256 bytes, a wave instruction four rows) -> LDS [64][JWL] (row stride 68 floats: 16-byte aligned
-// rows, conflict-free ds_read_b128 with lane = row).  Until round 4 every lane walked its OWN weight row in global memory (64 cache
-// lines per load instruction): 6,000 such instructions made 180 of the kernel's 233 us.
-#define JWL 68
-#define JS_THREADS 512
-struct JTile {
-  f32x4 r[2];  // 512 threads x 2 x 16 B = one 16 KB tile
-};
-__device__ __forceinline__ void jtile_fetch(JTile& t, const float* __restrict__ W, int ld, int n0, int k0, int tid) {
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int row = (tid >> 4) + 32 * q, c4 = tid & 15;
-    t.r[q] = *reinterpret_cast<const f32x4*>(W + (long long)(n0 + row) * ld + k0 + 4 * c4);
-  }
-}
-__device__ __forceinline__ void jtile_store(float* s_w, const JTile& t, int tid) {
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int row = (tid >> 4) + 32 * q, c4 = tid & 15;
-    *reinterpret_cast<f32x4*>(s_w + row * JWL + 4 * c4) = t.r[q];
-  }
-}
-// out[i][n] = act(b[n] + sum_k W[n][k] in[i][k]) for i < J: 512 threads = 64 output columns (lane) x 8 token groups (wave; tokens
-// i = wave, wave + 8, ...: at most 4 for J <= 32).  The k order of every sum is 0, 1, 2, ... as in the reference's dot product.
-// `pre` holds this layer's FIRST tile on entry (fetched by the previous phase, so its latency hid under that phase's arithmetic) and
-// the NEXT layer's first tile (Wnext, ldnext; null = none) on return.
-template <int KIN, int NOUT>
-__device__ __forceinline__ void lin_tiled(const float* in, int ild, const float* __restrict__ W, const float* __restrict__ b, float* out,
-                                          int old, int J, int tid, bool gelu, float* s_w, JTile& pre, const float* __restrict__ Wnext,
-                                          int ldnext) {
-  constexpr int NT = NOUT / 64, KT = KIN / 64;
-  const int lane = tid & 63, tg = tid >> 6;
-#pragma unroll 1
-  for (int nt = 0; nt < NT; ++nt) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const int n = nt * 64 + lane;
-    const float bn = b[n];  // requested here: in flight under the tile's arithmetic
-#pragma unroll 1
-    for (int kt = 0; kt < KT; ++kt) {
-      __syncthreads();  // every wave is done with the previous tile in s_w (and, first time, `in` is complete)
-      jtile_store(s_w, pre, tid);
-      __syncthreads();
-      // next tile of this layer, or the first tile of the next one: in flight under the arithmetic below
-      if (kt + 1 < KT) jtile_fetch(pre, W, KIN, nt * 64, (kt + 1) * 64, tid);
-      else if (nt + 1 < NT) jtile_fetch(pre, W, KIN, (nt + 1) * 64, 0, tid);
-      else if (Wnext) jtile_fetch(pre, Wnext, ldnext, 0, 0, tid);
-      const float* wrow = s_w + lane * JWL;
-#pragma unroll 4
-      for (int k4 = 0; k4 < 16; ++k4) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + 4 * k4);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int i = tg + 8 * t;
-          if (i < J) {  // (wave-uniform)
-            const float* x = in + i * ild + kt * 64 + 4 * k4;
-            acc[t] = fmaf(wv.x, x[0], acc[t]);
-            acc[t] = fmaf(wv.y, x[1], acc[t]);
-            acc[t] = fmaf(wv.z, x[2], acc[t]);
-            acc[t] = fmaf(wv.w, x[3], acc[t]);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int i = tg + 8 * t;
-      if (i < J) {
-        const float v = acc[t] + bn;
-        out[i * old + n] = gelu ? gelu_erf(v) : v;
-      }
-    }
-  }
-}
-// AdaLN over J tokens of 64 channels held in LDS: one wavefront per token (8 waves), lane = channel.
-__device__ __forceinline__ void adaln_small8(const float* in, float* out, const float* __restrict__ gb, int J, int tid) {
-  const int lane = tid & 63, wave = tid >> 6;
-  for (int i = wave; i < J; i += 8) {
-    const float x = in[i * JLD + lane];
-    const float mean = wave_sum(x) * (1.0f / 64.0f);
-    const float d = x - mean;
-    const float var = wave_sum(d * d) * (1.0f / 63.0f);
-    out[i * JLD + lane] = gb[lane] * d / (sqrtf(var) + 1e-6f) + gb[64 + lane];
-  }
-}
-
 __global__ __launch_bounds__(JS_THREADS) void joint_stream_kernel(const float* __restrict__ xq_in, const float* __restrict__ jQ,
                                                                   const float* __restrict__ kv, const float* __restrict__ GB,
                                                                   int gb_stride, JointStreamW w, const float* __restrict__ jt,
@@ -1556,7 +1544,7 @@ extern "C" int pmce_joint_embed_f32(const float* jt, const float* Wj, const floa
                                     const float* bj2v, const float* j2vK, float* jf, float* xk, int B, int J,
                                     hipStream_t stream) {
   PMCE_REQUIRE(J >= 1 && J <= 32 && B > 0, "joint_embed: J must be in 1..32");
-  hipLaunchKernelGGL(joint_embed_kernel, dim3(B), dim3(256), 0, stream, jt, Wj, bj, jpos, Wj2v, bj2v, j2vK, jf, xk, J);
+  hipLaunchKernelGGL(joint_embed_kernel, dim3(B), dim3(JS_THREADS), 0, stream, jt, Wj, bj, jpos, Wj2v, bj2v, j2vK, jf, xk, J);
   return pmce_check_launch("joint_embed");
 }
 
@@ -1565,7 +1553,7 @@ extern "C" int pmce_ca_fold_f32(const float* xk, const float* xv, const float* G
                                 const float* bv, const float* Wp, float* Kf, float* s0, float* Vf, int B, int J,
                                 hipStream_t stream) {
   PMCE_REQUIRE(J >= 1 && J <= 32 && B > 0, "ca_fold: J must be in 1..32");
-  hipLaunchKernelGGL(ca_fold_kernel, dim3(B), dim3(256), 0, stream, xk, xv, GB, gb_stride, iq, ik, iv, Wq, bq, Wk, bk, Wv, bv,
+  hipLaunchKernelGGL(ca_fold_kernel, dim3(B), dim3(JS_THREADS), 0, stream, xk, xv, GB, gb_stride, iq, ik, iv, Wq, bq, Wk, bk, Wv, bv,
                      Wp, Kf, s0, Vf, J);
   return pmce_check_launch("ca_fold");
 }

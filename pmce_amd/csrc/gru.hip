@@ -234,6 +234,174 @@ __global__ __launch_bounds__(128 * NQ) void gru_step_kernel(GruStepArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Round 4: the split-f16 step with the operand traffic cut by a third and a deeper ring.  Same tile (64 batch rows x 32 units x
+// {r, z, n}), same 8 waves = 2 row blocks x 4 K-quarters, same arithmetic and summation order as gru_step_kernel<4, true> - results
+// are bit-identical - but the two row-block waves of a K-quarter no longer stage PRIVATE copies of the quarter's 96 W_hh rows (each
+// fetched them: 1.04 MB per workgroup and step for 0.65 MB of operands, and with two 8 KB stages per wave the 16 k-tiles were 16
+// exposed round trips - the step's 21-24 us were the fill, `scripts/microbench/gru_ablate.py`).  Here a K-quarter owns ONE ring of
+// three 10 KB stages [64 h rows | 96 W rows] x 64 B; each of its two waves DMAs its own 32 h rows and HALF of the W rows (5 instead
+// of 8 instructions per k-tile), two k-tiles are in flight behind the one being multiplied, and one workgroup barrier per k-tile
+// makes the partner's half visible (8 waves, two per SIMD: the barrier is cheap next to a round trip).  120 KB of LDS.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gru_step_v2_kernel(GruStepArgs a) {
+  constexpr int NQ = 4, NS = 3;
+  constexpr int RW = 16 / NQ;                  // accumulator rows each wave finishes
+  constexpr int STAGE = (64 + 96) * 64;        // bytes per stage: 160 rows of 64 B
+  __shared__ __attribute__((aligned(16))) float smem[NQ * NS * STAGE / 4];   // 120 KB
+  const int d = blockIdx.z;
+  const int u0 = blockIdx.x * 32, m0 = blockIdx.y * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = lane & 31, hb = lane >> 5;
+  const int rb = wave & 1, kq = wave >> 1;
+  const int H = a.H, Kq = H / NQ;
+  const float* __restrict__ hp = a.hprev[d];
+  const float* __restrict__ W = a.whh[d];
+
+  const int u = u0 + n0;
+  const float* __restrict__ gi = a.gi[d];
+  float gir[RW], giz[RW], gin[RW], hpv[RW];
+#pragma unroll
+  for (int q = 0; q < RW; ++q) {
+    const int r = RW * kq + q;
+    const int m = min(m0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb, a.B - 1);
+    const float* g = gi + (long long)m * a.gi_rs + u;
+    gir[q] = g[0];
+    giz[q] = g[H];
+    gin[q] = g[2 * H];
+    hpv[q] = hp ? hp[(long long)m * a.h_rs + u] : 0.f;
+  }
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+
+  if (hp) {
+    const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hp), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 0xffffffff, 0x00020000);
+    // DMA instruction = 16 rows x 64 B (4 lanes per row).  This wave moves stage rows [32 rb, 32 rb + 32) (its h rows) and
+    // [64 + 48 rb, 64 + 48 rb + 48) (its half of the W rows; W row r' = gate * 32 + unit).  Lane L lands at row + L / 4, PHYSICAL chunk
+    // L % 4, and fetches logical chunk (L % 4) ^ ((row >> 2) & 3) (conflict-free ds_read_b128 on unpadded rows).
+    unsigned hoff[2], woff[3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = 32 * rb + 16 * i + (lane >> 2);
+      const int c = (lane & 3) ^ ((row >> 2) & 3);
+      const int m = min(m0 + row, a.B - 1);
+      hoff[i] = (unsigned)(((long long)m * a.h_rs + 4 * c) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int r2 = 48 * rb + 16 * i + (lane >> 2);  // gate = r2 >> 5, unit = r2 & 31
+      const int c = (lane & 3) ^ ((r2 >> 2) & 3);
+      woff[i] = (unsigned)(((long long)((r2 >> 5) * H + u0 + (r2 & 31)) * H + 4 * c) * 4);
+    }
+    const unsigned lds_q =
+        __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)smem) + kq * (NS * STAGE);
+    auto dma_stage = [&](int kt) {
+      const int soff = (kq * Kq + kt * 16) * 4;
+      const unsigned dst = lds_q + (kt % NS) * STAGE;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) gru_dma16(rsrc_h, hoff[i], soff, dst + (32 * rb + 16 * i) * 64);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) gru_dma16(rsrc_w, woff[i], soff, dst + (64 + 48 * rb + 16 * i) * 64);
+    };
+    const int nk = Kq / 16;
+    const float* ring = smem + kq * (NS * STAGE / 4);
+    const int swz = (n0 >> 2) & 3;  // the same for stage rows n0, 32 + n0, 64 + n0, 96 + n0, 128 + n0
+    dma_stage(0);
+    dma_stage(1);
+    for (int kt = 0; kt < nk; ++kt) {
+      // k-tile kt has landed when at most the 5 DMAs of tile kt + 1 are still in flight (in-order completion)
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // the partner's half of tile kt is in LDS; every wave is done reading tile kt - 1
+      if (kt + 2 < nk) dma_stage(kt + 2);  // into the stage tile kt - 1 occupied
+      const float* st = ring + (kt % NS) * (STAGE / 4);
+      const float* As = st + (32 * rb + n0) * 16;
+      const float* Bs = st + (64 + n0) * 16;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(As + 4 * ((2 * hb) ^ swz));      // k = 8 hb + [0, 4)
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(As + 4 * ((2 * hb + 1) ^ swz));  // k = 8 hb + [4, 8)
+      const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      gru_f16x8 ahi, alo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ahi[e] = (_Float16)xv[e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) alo[e] = (_Float16)((xv[e] - (float)ahi[e]) * 2048.0f);
+      gru_f16x8 whi[3], wlo[3], wh2[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        whi[g] = *reinterpret_cast<const gru_f16x8*>(Bs + g * 32 * 16 + 4 * (hb ^ swz));        // hi plane, k = 8 hb + [0, 8)
+        wlo[g] = *reinterpret_cast<const gru_f16x8*>(Bs + g * 32 * 16 + 4 * ((2 + hb) ^ swz));  // lo plane
+        wh2[g] = whi[g] * (_Float16)0.00048828125f;
+      }
+#pragma unroll
+      for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, whi[g], acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, wlo[g], acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, wh2[g], acc[g], 0, 0, 0);
+    }
+    __syncthreads();  // every wave is done with the rings: the reduction below reuses the memory
+    // meet the K-slices: every wave publishes the rows its partners finish, then sums the partners' copies of its own
+    float* red = smem;  // [dst kq][src slot][rb][gate][q][lane]
+#pragma unroll
+    for (int dq = 0; dq < NQ; ++dq) {
+      if (dq == kq) continue;
+      const int slot = kq < dq ? kq : kq - 1;
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int q = 0; q < RW; ++q) {
+          float v = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v = (r == RW * dq + q) ? acc[g][r] : v;
+          red[((((dq * (NQ - 1) + slot) * 2 + rb) * 3 + g) * RW + q) * 64 + lane] = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int q = 0; q < RW; ++q) {
+        float sum = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < NQ - 1; ++sl) sum += red[((((kq * (NQ - 1) + sl) * 2 + rb) * 3 + g) * RW + q) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (r == RW * kq + q) acc[g][r] += sum;
+      }
+  }
+  const float* __restrict__ bh = a.bhh[d];
+  const float bhr = bh[u], bhz = bh[H + u], bhn = bh[2 * H + u];
+  const float wd_r = a.wscale[d * 3 * H + u], wd_z = a.wscale[d * 3 * H + H + u], wd_n = a.wscale[d * 3 * H + 2 * H + u];
+  float* __restrict__ ho = a.hout[d];
+#pragma unroll
+  for (int q = 0; q < RW; ++q) {
+    float ar = 0.f, az = 0.f, an = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool sel = (r == RW * kq + q);
+      ar = sel ? acc[0][r] : ar;
+      az = sel ? acc[1][r] : az;
+      an = sel ? acc[2][r] : an;
+    }
+    ar *= wd_r;
+    az *= wd_z;
+    an *= wd_n;
+    const int r = RW * kq + q;
+    const int m = m0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
+    if (m < a.B) {
+      const float rr = sigmoidf_acc(gir[q] + (ar + bhr));
+      const float zz = sigmoidf_acc(giz[q] + (az + bhz));
+      const float nn = tanhf(gin[q] + rr * (an + bhn));
+      ho[(long long)m * a.h_rs + u] = (1.0f - zz) * nn + zz * hpv[q];
+    }
+  }
+}
+
 static int gru_step_any(const float* gi0, const float* gi1, const float* whh0, const float* whh1, const float* wscale,
                         const float* bhh0, const float* bhh1, const float* hp0, const float* hp1, float* ho0, float* ho1,
                         long long gi_rs, long long h_rs, int B, int H, int ndir, hipStream_t stream) {
@@ -247,7 +415,10 @@ static int gru_step_any(const float* gi0, const float* gi1, const float* whh0, c
   a.gi_rs = gi_rs; a.h_rs = h_rs; a.B = B; a.H = H; a.wscale = wscale;
   PMCE_REQUIRE((long long)B * h_rs * 4 < (1ll << 32) && 3ll * H * H * 4 < (1ll << 32), "gru_step: h or W_hh spans 4 GiB or more");
   static const int nq = pmce_env_int("PMCE_GRU_NQ", 4);  // tuning knob, read once
-  if (wscale)
+  static const int v2 = pmce_env_int("PMCE_GRU_V2", 1);  // A/B knob, read once: 0 = the round-2 kernel with private rings
+  if (wscale && v2)
+    hipLaunchKernelGGL(gru_step_v2_kernel, dim3(H / 32, (B + 63) / 64, ndir), dim3(512), 0, stream, a);
+  else if (wscale)
     hipLaunchKernelGGL((gru_step_kernel<4, true>), dim3(H / 32, (B + 63) / 64, ndir), dim3(512), 0, stream, a);
   else if (nq == 2)
     hipLaunchKernelGGL((gru_step_kernel<2>), dim3(H / 32, (B + 63) / 64, ndir), dim3(256), 0, stream, a);
