@@ -219,6 +219,15 @@ int pmce_gemm_nt_split_f16_rowmap(const float* A, const float* Wp, const float* 
 int pmce_split_rows_scaled_f16(const float* A, long long M, int K, long long lda, float* Ap, float* rscale, pmce_stream_t stream);
 int pmce_gemm_nt_split_f16_rs(const float* Ap, const float* rscale, const float* Wp, const float* wscale, const float* bias, float* C,
                               int M, int N, int K, long long ldc, int c_div, long long c_lo, long long c_hi, pmce_stream_t stream);
+/* The BLOCKED weight layout (round 4; what the model packs and multiplies): pmce_gemm_pack_split_f16_blk writes the same planes as
+ * pmce_gemm_pack_split_f16 as [ceil(N/64)][K/16][64 rows][16 hi | 16 lo] (Wp: ceil(N/64)*64*K floats of storage), so that what a tile
+ * fetches per k-tile is contiguous 4 KB pieces instead of 64-byte pieces one weight row apart.  pmce_gemm_nt_split_f16_blk is every
+ * product form above on such a weight: rscale != null -> A row-scaled (as _rs), c_div > 0 -> mapped output rows (ldc == N), else as
+ * _ex.  Results are bit-identical to the row-major forms (same arithmetic, same k order). */
+int pmce_gemm_pack_split_f16_blk(const float* W, int N, int K, int ldw, float* Wp, float* wscale, pmce_stream_t stream);
+int pmce_gemm_nt_split_f16_blk(const float* A, const float* rscale, const float* Wblk, const float* wscale, const float* bias,
+                               const float* R, float* C, int M, int N, int K, long long lda, long long ldc, int act, int a_packed,
+                               int c_packed, int c_div, long long c_lo, long long c_hi, pmce_stream_t stream);
 /* a_packed != 0: A is not fp32 but already split, [M][K/16][hi 16 f16 | lo*2^11 16 f16] (the layout the lifter's own
  * producers write; pmce_split_rows_f16 makes it from fp32 rows). */
 int pmce_split_rows_f16(const float* A, long long M, int K, long long lda, float* Ap, pmce_stream_t stream);

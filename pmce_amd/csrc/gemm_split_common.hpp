@@ -8,6 +8,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 struct SplitParams {
   const float* A;       // fp32 [M][lda], or packed planes [M][K/16][16 hi | 16 lo*2^11] f16 (APACK)
   const float* W;       // packed planes [N][K/16][16 hi | 16 lo] f16 of W[n] * 2^s(n)
+  int wblk;             // W is in the BLOCKED layout [N/64][K/16][64 rows][16 hi | 16 lo] (pmce_gemm_pack_split_f16_blk): a tile's k-slice is
+                        // contiguous 4 KB pieces instead of 64-byte pieces one weight row (K * 4 bytes) apart
   const float* wscale;  // [N]: 2^-s(n), one power of two per OUTPUT row of W (pmce_gemm_pack_split_f16)
   const float* bias;    // [N] or null
   const float* rscale;  // [M] or null: 2^e(m) per ROW of a packed A that was stored as A[m] * 2^-e(m) (pmce_split_rows_scaled_f16): the

@@ -108,17 +108,23 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
       const int g = wave + 4 * q;
       if (g < GA)
         doff[q] = ((unsigned)min(mb + 16 * g + drow, p.M - 1) * p.lda + dchunk) * 4u;
-      else
-        doff[q] = ((unsigned)min(nb + 16 * (g - GA) + drow, p.N - 1) * (unsigned)p.K + dchunk) * 4u;
+      else {
+        const unsigned r = (unsigned)min(nb + 16 * (g - GA) + drow, p.N - 1);
+        doff[q] = p.wblk ? ((r >> 6) * (unsigned)(p.K / 16) * 1024u + (r & 63u) * 16u + dchunk) * 4u   // 64-row block, 64-byte rows
+                         : (r * (unsigned)p.K + dchunk) * 4u;
+      }
     }
   };
   const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)lds;
   const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+  const int kstep_w = p.wblk ? 4096 : 64;  // bytes from one k-tile of a W row (block) to the next
   auto issue = [&](int kt, int stage) {
-    const int ko = kt * 64;  // bytes
+    const int ko = kt * 64, kw = kt * kstep_w;  // bytes
 #pragma unroll
-    for (int q = 0; q < DPW; ++q)
-      sdma16((wave + 4 * q) < GA ? rsrc_a : rsrc_w, doff[q], ko, lds_wave + stage * (SF * 4) + q * 4096);
+    for (int q = 0; q < DPW; ++q) {
+      const bool is_a = (wave + 4 * q) < GA;
+      sdma16(is_a ? rsrc_a : rsrc_w, doff[q], is_a ? ko : kw, lds_wave + stage * (SF * 4) + q * 4096);
+    }
   };
 
   // issue-side cursor (runs NS-1 k-tiles ahead of the compute side, across tile boundaries)
@@ -462,13 +468,13 @@ static int pick_split_tile(int M, int N) {
 
 static int gemm_split_any(const float* A, const float* Wp, const float* wscale, const float* bias, const float* R, float* C, int M,
                           int N, int K, long long lda, long long ldc, int act, int a_packed, int c_packed, int c_div,
-                          long long c_lo, long long c_hi, hipStream_t stream, const float* rscale = nullptr) {
+                          long long c_lo, long long c_hi, hipStream_t stream, const float* rscale = nullptr, int w_blocked = 0) {
   PMCE_REQUIRE(A && Wp && wscale && C, "gemm_split: null pointer");
   PMCE_REQUIRE(M > 0 && N > 0 && K >= 32 && K % 16 == 0, "gemm_split: need M,N>0, K>=32 and K%%16==0 (got M=%d N=%d K=%d)", M, N, K);
   PMCE_REQUIRE(act == 0 || act == 1, "gemm_split: act must be 0 or 1");
   PMCE_REQUIRE(lda >= K && lda % 4 == 0 && ldc >= N, "gemm_split: lda=%lld (>=K, multiple of 4) / ldc=%lld (>=N)", lda, ldc);
   PMCE_REQUIRE(!a_packed || lda == K, "gemm_split: a packed A has lda == K");
-  PMCE_REQUIRE((long long)M * lda * 4 < (1ll << 32) && (long long)N * K * 4 < (1ll << 32) && (long long)M * ldc < (1ll << 32),
+  PMCE_REQUIRE((long long)M * lda * 4 < (1ll << 32) && ((long long)N + 63) / 64 * 64 * K * 4 < (1ll << 32) && (long long)M * ldc < (1ll << 32),
                "gemm_split: an operand spans 4 GiB or more (split the batch)");
   PMCE_REQUIRE(ldc < (1ll << 21), "gemm_split: ldc=%lld (the tile epilogue addresses a 256-row window of C / R with 32-bit byte offsets)", ldc);
   PMCE_REQUIRE(c_div == 0 || R == nullptr, "gemm_split: a C row map cannot be combined with a residual");
@@ -477,7 +483,7 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
   PMCE_REQUIRE(!rscale || (a_packed && !c_packed && act == 0 && R == nullptr && K >= 64),
                "gemm_split: a row-scaled A is a packed A with K >= 64; no activation, residual or packed result");
   SplitParams p;
-  p.A = A; p.W = Wp; p.wscale = wscale; p.bias = bias; p.R = R; p.C = C; p.rscale = rscale;
+  p.A = A; p.W = Wp; p.wscale = wscale; p.bias = bias; p.R = R; p.C = C; p.rscale = rscale; p.wblk = w_blocked;
   p.M = M; p.N = N; p.K = K; p.lda = (unsigned)lda; p.ldc = (unsigned)ldc;
   p.c_div = c_div; p.c_lo = c_lo; p.c_hi = c_hi;
   p.oflow = pmce_overflow_sink();
@@ -511,6 +517,16 @@ extern "C" int pmce_gemm_nt_split_f16_rowmap(const float* A, const float* Wp, co
   return gemm_split_any(A, Wp, wscale, bias, nullptr, C, M, N, K, lda, N, 0, 0, 0, c_div, c_lo, c_hi, stream);
 }
 
+// Every form above on a weight in the BLOCKED layout (pmce_gemm_pack_split_f16_blk): rscale != null -> A is row-scaled (as _rs),
+// c_div > 0 -> mapped output rows (as _rowmap; ldc == N then), else as _ex.  What the model's launch sequences call.
+extern "C" int pmce_gemm_nt_split_f16_blk(const float* A, const float* rscale, const float* Wblk, const float* wscale, const float* bias,
+                                          const float* R, float* C, int M, int N, int K, long long lda, long long ldc, int act,
+                                          int a_packed, int c_packed, int c_div, long long c_lo, long long c_hi, hipStream_t stream) {
+  PMCE_REQUIRE(c_div >= 0 && (c_div == 0 || ldc == N), "gemm_split_blk: a row map needs ldc == N");
+  return gemm_split_any(A, Wblk, wscale, bias, R, C, M, N, K, lda, ldc, act, rscale ? 1 : a_packed, c_packed, c_div, c_lo, c_hi, stream,
+                        rscale, 1);
+}
+
 // Raw inputs (any finite fp32 magnitude): Ap / rscale from pmce_split_rows_scaled_f16.  C[m][n] = 2^e(m) 2^-s(n) (Ahi Whi + Ahi Wlo +
 // Alo Whi) + bias[n]; c_div > 0 maps the output rows like pmce_gemm_nt_split_f16_rowmap (ldc = N then).
 extern "C" int pmce_gemm_nt_split_f16_rs(const float* Ap, const float* rscale, const float* Wp, const float* wscale, const float* bias,
@@ -526,7 +542,7 @@ extern "C" int pmce_gemm_nt_split_f16_rs(const float* Ap, const float* rscale, c
 // row's max|W| * 2^s lies in [2^14, 2^15): hi = rne16(W 2^s), lo = rne16(W 2^s - hi) - both normal f16 for every weight within
 // 2^-17 of the row's largest (smaller ones lose bits that are 2^-28 of the row's largest product).  One wave per row.
 __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ W, int N, int K, int ldw, _Float16* __restrict__ Wp,
-                                                         float* __restrict__ wscale) {
+                                                         float* __restrict__ wscale, int blocked) {
   const int lane = threadIdx.x & 63;
   for (long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); n < N; n += (long long)gridDim.x * 4) {
     const float* __restrict__ row = W + n * ldw;
@@ -538,13 +554,15 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
     e = max(-110, min(e, 125));                  // keeps 2^(15-e) and 2^(e-15) normal fp32 numbers
     const float up = m > 0.f ? ldexpf(1.f, 15 - e) : 1.f, down = m > 0.f ? ldexpf(1.f, e - 15) : 1.f;
     if (lane == 0) wscale[n] = down;
-    _Float16* __restrict__ out = Wp + n * K * 2;
+    // row-major: 32 f16 per (row, k-tile), a row's k-tiles adjacent; blocked: [n / 64][k-tile][n % 64][32 f16]
+    _Float16* __restrict__ out = blocked ? Wp + ((n >> 6) * (long long)(K / 16) * 64 + (n & 63)) * 32 : Wp + n * K * 2;
+    const long long kt_stride = blocked ? 64 * 32 : 32;
     for (int k = lane; k < K; k += 64) {
       const float ws = row[k] * up;
       const _Float16 hi = (_Float16)ws;
       const _Float16 lo = (_Float16)(ws - (float)hi);
-      out[(k / 16) * 32 + (k % 16)] = hi;       // 32 f16 per (row, k-tile)
-      out[(k / 16) * 32 + 16 + (k % 16)] = lo;
+      out[(k / 16) * kt_stride + (k % 16)] = hi;
+      out[(k / 16) * kt_stride + 16 + (k % 16)] = lo;
     }
   }
 }
@@ -552,8 +570,19 @@ extern "C" int pmce_gemm_pack_split_f16(const float* W, int N, int K, int ldw, f
   PMCE_REQUIRE(W && Wp && wscale, "gemm_pack_split: null pointer");
   PMCE_REQUIRE(N > 0 && K > 0 && K % 16 == 0 && ldw >= K, "gemm_pack_split: need N>0, K%%16==0, ldw>=K (N=%d K=%d ldw=%d)", N, K, ldw);
   const int blocks = (N + 3) / 4 < 4096 ? (N + 3) / 4 : 4096;
-  hipLaunchKernelGGL(split_pack_kernel, dim3(blocks), dim3(256), 0, stream, W, N, K, ldw, reinterpret_cast<_Float16*>(Wp), wscale);
+  hipLaunchKernelGGL(split_pack_kernel, dim3(blocks), dim3(256), 0, stream, W, N, K, ldw, reinterpret_cast<_Float16*>(Wp), wscale, 0);
   return pmce_check_launch("gemm_pack_split_f16");
+}
+// The same planes in the BLOCKED layout [ceil(N/64)][K/16][64][16 hi | 16 lo] (Wp: ceil(N/64)*64*K floats of storage; rows past N are
+// not written and never contribute): what a tile fetches per k-tile is then contiguous 4 KB pieces.  A streamed weight (one that is
+// read once per launch from HBM: the final product's 278 MB, the GRU and AdaLN projections) otherwise arrives as 64-byte pieces one
+// weight row apart - a different DRAM page per piece.
+extern "C" int pmce_gemm_pack_split_f16_blk(const float* W, int N, int K, int ldw, float* Wp, float* wscale, hipStream_t stream) {
+  PMCE_REQUIRE(W && Wp && wscale, "gemm_pack_split_blk: null pointer");
+  PMCE_REQUIRE(N > 0 && K > 0 && K % 16 == 0 && ldw >= K, "gemm_pack_split_blk: need N>0, K%%16==0, ldw>=K (N=%d K=%d ldw=%d)", N, K, ldw);
+  const int blocks = (N + 3) / 4 < 4096 ? (N + 3) / 4 : 4096;
+  hipLaunchKernelGGL(split_pack_kernel, dim3(blocks), dim3(256), 0, stream, W, N, K, ldw, reinterpret_cast<_Float16*>(Wp), wscale, 1);
+  return pmce_check_launch("gemm_pack_split_f16_blk");
 }
 
 // A[M][lda] fp32 -> Ap[M][K/16][2][16] f16: hi = rne16(a), lo = rne16((a - hi) * 2^11)

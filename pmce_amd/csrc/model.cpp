@@ -121,6 +121,7 @@ struct pmce_model {
   // beyond f16's 65504 turns into inf / nan there, and so does fp32 overflow), checked by every entry point BEFORE it launches.
   std::shared_ptr<unsigned> oflow;  // shared by handles cloned onto the same weights (pipeline lanes): one model, one flag
   bool strict_overflow = false;     // pmce_model_set_overflow_policy: refuse further calls while the word is set
+  bool wblk = true;                 // the products' packed weights in the blocked layout (PMCE_SPLIT_WBLK=0 at create: row-major, an A/B knob)
   // regressor (optional)
   const int* jr_indptr = nullptr;
   const int* jr_indices = nullptr;
@@ -356,7 +357,8 @@ int gemm(const float* A, const float* W, const float* bias, const float* R, floa
 int lgemm(const pmce_model* m, const float* A, const float* W, const SplitW& sw, const float* bias, const float* R, float* Cc,
           int M, int N, int K, long long lda, long long ldc, int act, hipStream_t s, int a_packed = 0, int c_packed = 0) {
   if (m->split_now && sw.wp)
-    return pmce_gemm_nt_split_f16_ex(A, sw.wp, sw.scale, bias, R, Cc, M, N, K, lda, ldc, act, a_packed, c_packed, s);
+    return m->wblk ? pmce_gemm_nt_split_f16_blk(A, nullptr, sw.wp, sw.scale, bias, R, Cc, M, N, K, lda, ldc, act, a_packed, c_packed, 0, 0, 0, s)
+                   : pmce_gemm_nt_split_f16_ex(A, sw.wp, sw.scale, bias, R, Cc, M, N, K, lda, ldc, act, a_packed, c_packed, s);
   PMCE_REQUIRE(!a_packed && !c_packed, "lgemm: pre-split operands need the split-f16 form");
   return gemm(A, W, bias, R, Cc, M, N, K, lda, ldc, act, s);
 }
@@ -410,13 +412,20 @@ int prep_features(pmce_model* m, const float* img_feat, int nframes, LifterWs& w
   return PMCE_OK;
 }
 
+// a product on the row-scaled feature planes (optionally with mapped output rows)
+int rs_gemm(const pmce_model* m, const float* FS, const float* FR, const SplitW& sw, const float* bias, float* Cc, int M, int N,
+            long long ldc, int c_div, long long c_lo, long long c_hi, hipStream_t s) {
+  return m->wblk ? pmce_gemm_nt_split_f16_blk(FS, FR, sw.wp, sw.scale, bias, nullptr, Cc, M, N, F, F, ldc, 0, 1, 0, c_div, c_lo, c_hi, s)
+                 : pmce_gemm_nt_split_f16_rs(FS, FR, sw.wp, sw.scale, bias, Cc, M, N, F, ldc, c_div, c_lo, c_hi, s);
+}
+
 // embedding + SpatialBlocks[0] over `nframes` frames; leaves the block output (before norm_s) in w.X
 int lifter_frames(pmce_model* m, const float* pose2d, const float* img_feat, int nframes, LifterWs& w, hipStream_t stream) {
   const int J = m->J, C = m->C;
   const long long M = (long long)nframes * J;
   PMCE_REQUIRE(M < (1ll << 31), "lifter: too many tokens");
   if (m->split_now && m->s_ie.wp)
-    RUN(P_GEMM_LIFTER, pmce_gemm_nt_split_f16_rs(w.FS, w.FR, m->s_ie.wp, m->s_ie.scale, m->w.ie_b, w.E, nframes, C, F, C, 0, 0, 0, stream));
+    RUN(P_GEMM_LIFTER, rs_gemm(m, w.FS, w.FR, m->s_ie, m->w.ie_b, w.E, nframes, C, C, 0, 0, 0, stream));
   else
     RUN(P_GEMM_LIFTER, lgemm(m, img_feat, m->w.ie_w, m->s_ie, m->w.ie_b, nullptr, w.E,
                             nframes, C, F, F, C, 0, stream));
@@ -519,8 +528,7 @@ int gru_part(pmce_model* m, const float* img_feat, const LifterWs& lw, int B, De
   // layer 0 input projections for both directions in one product: rows (b,t) of img_feat -> rows (t,b) of GI0
   // (split mode: from the row-scaled planes of prep_features)
   if (m->split_now && m->s_wih0.wp)
-    RUN(P_GEMM_GRU_IN, pmce_gemm_nt_split_f16_rs(lw.FS, lw.FR, m->s_wih0.wp, m->s_wih0.scale, m->w.bih0, w.GI0, B * T, 6 * GH, F, 6 * GH,
-                                                 T, (long long)B * 6 * GH, 6 * GH, stream));
+    RUN(P_GEMM_GRU_IN, rs_gemm(m, lw.FS, lw.FR, m->s_wih0, m->w.bih0, w.GI0, B * T, 6 * GH, 6 * GH, T, (long long)B * 6 * GH, 6 * GH, stream));
   else
     RUN(P_GEMM_GRU_IN, pmce_gemm_nt_f32(img_feat, m->w.wih0, m->w.bih0, nullptr, w.GI0, B * T,
                                         6 * GH, F, F, F, 6 * GH, 0, 0, 0, 0, T, (long long)B * 6 * GH, 6 * GH, 1, 0, 0, 0, 0,
@@ -703,7 +711,7 @@ namespace {
 // the packing the host side does: runs on `stream` - the stream the caller produced the fp32 weights on (a torch side stream is
 // non-blocking: the null stream would NOT be ordered behind it) - and waits for that stream only.
 struct SplitItem { const float* w; int n, k; SplitW* dst; };
-size_t split_item_floats(int n, int k) { return (((size_t)n * k + 63) & ~(size_t)63) + (((size_t)n + 63) & ~(size_t)63); }  // planes + 2^-s per row
+size_t split_item_floats(int n, int k) { return ((((size_t)n + 63) & ~(size_t)63) * k) + (((size_t)n + 63) & ~(size_t)63); }  // planes (rows padded to the 64-row blocks of the blocked layout) + 2^-s per row
 // bytes of the planes of a model with / without lifter and decoder
 size_t split_bytes_for(int C, int depth, bool lifter, bool decoder) {
   size_t f = 0;
@@ -773,9 +781,12 @@ int build_split_weights(pmce_model* m, hipStream_t stream) {
   float* p = m->split_arena.get();
   for (auto& it : items) {
     float* wp = p;
-    float* sc = p + (((size_t)it.n * it.k + 63) & ~(size_t)63);
+    float* sc = p + ((((size_t)it.n + 63) & ~(size_t)63) * it.k);
     p = wp + split_item_floats(it.n, it.k);
-    PMCE_TRY(pmce_gemm_pack_split_f16(it.w, it.n, it.k, it.k, wp, sc, stream));
+    // the products' weights in the blocked layout (a tile's k-slice contiguous); the recurrent weights row-major (gru_step's addressing)
+    const bool recurrent = it.dst == &m->s_whh0 || it.dst == &m->s_whh1;
+    if (m->wblk && !recurrent) PMCE_TRY(pmce_gemm_pack_split_f16_blk(it.w, it.n, it.k, it.k, wp, sc, stream));
+    else PMCE_TRY(pmce_gemm_pack_split_f16(it.w, it.n, it.k, it.k, wp, sc, stream));
     it.dst->wp = wp;
     it.dst->scale = sc;
   }
@@ -822,6 +833,7 @@ int pmce_model_create(int num_joint, int embed_dim, int depth, pmce_model** out)
   m->attn_f16 = pmce_env_int("PMCE_ATTN_F16", 1) != 0;
   m->split_overlap = pmce_env_int("PMCE_SPLIT_OVERLAP", 1) != 0;
   m->strict_overflow = pmce_env_int("PMCE_STRICT_OVERFLOW", 0) != 0;
+  m->wblk = pmce_env_int("PMCE_SPLIT_WBLK", 1) != 0;
   build_names(m);
   *out = m;
   return PMCE_OK;
@@ -1149,7 +1161,7 @@ int pmce_stream_precompute(pmce_model* m, const float* pose2d_frames, const floa
                               nullptr, 1, 1, x0, nullptr, nullptr, 0.f, nullptr, stream));
   // window-independent GRU work: layer-0 input projections of both directions, once per frame (CoevoDecoder.py:216-221)
   if (m->split_now && m->s_wih0.wp)
-    RUN(P_GEMM_GRU_IN, pmce_gemm_nt_split_f16_rs(lw.FS, lw.FR, m->s_wih0.wp, m->s_wih0.scale, m->w.bih0, gi0, L, 6 * GH, F, 6 * GH, 0, 0, 0, stream));
+    RUN(P_GEMM_GRU_IN, rs_gemm(m, lw.FS, lw.FR, m->s_wih0, m->w.bih0, gi0, L, 6 * GH, 6 * GH, 0, 0, 0, stream));
   else
     RUN(P_GEMM_GRU_IN, lgemm(m, feat_frames, m->w.wih0, m->s_wih0, m->w.bih0, nullptr, gi0, L, 6 * GH, F, F, 6 * GH,
                              0, stream));

@@ -46,6 +46,30 @@ def pack_split_f16(W):
     return Wp, wscale
 
 
+def pack_split_f16_blk(W):
+    """The same planes in the blocked layout [ceil(N/64)][K/16][64][16 hi | 16 lo] (what the model packs); -> (Wblk, wscale, N)."""
+    lib = _lib.load()
+    W = _c(W)
+    N, K = W.shape
+    Np = (N + 63) // 64 * 64
+    Wp = torch.zeros(Np, K, device=W.device, dtype=torch.float32)
+    ws = torch.empty(N, device=W.device, dtype=torch.float32)
+    _lib.check(lib.pmce_gemm_pack_split_f16_blk(P(W), N, K, K, P(Wp), P(ws), _st()), "gemm_pack_split_f16_blk")
+    return Wp, ws, N
+
+
+def gemm_nt_split_blk(A, Wblk, wscale, N, bias=None, residual=None, act=0, a_packed=False, c_packed=False, rscale=None, rowmap=None, out=None):
+    """Every form of the three-product GEMM on a blocked weight (pmce_gemm_nt_split_f16_blk)."""
+    lib = _lib.load()
+    M, K = A.shape
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    cd, lo, hi = rowmap if rowmap else (0, 0, 0)
+    _lib.check(lib.pmce_gemm_nt_split_f16_blk(P(A), P(rscale), P(Wblk), P(wscale), P(bias), P(residual), P(out), M, N, K, K, N, act,
+                                              1 if a_packed else 0, 1 if c_packed else 0, cd, lo, hi, _st()), "gemm_nt_split_blk")
+    return out
+
+
 def split_rows_f16(A):
     """A[M,K] fp32 -> the packed (hi | lo*2^11) f16 planes, as an [M,K] float32-typed buffer."""
     lib = _lib.load()

@@ -20,7 +20,7 @@ extern "C" int pmce_diag_gemm_nt_split_f16(int kind, const float* A, const float
   PMCE_REQUIRE(M > 0 && N > 0 && K >= 32 && K % 16 == 0 && lda >= K && ldc >= N, "diag gemm_split: bad shape");
   PMCE_REQUIRE(!c_packed || (a_packed && act == 1 && R == nullptr && N % 32 == 0 && ldc == N), "diag gemm_split: bad packed-result request");
   SplitParams p;
-  p.A = A; p.W = Wp; p.wscale = wscale; p.bias = bias; p.R = R; p.C = C; p.rscale = nullptr;
+  p.A = A; p.W = Wp; p.wscale = wscale; p.bias = bias; p.R = R; p.C = C; p.rscale = nullptr; p.wblk = 0;
   p.M = M; p.N = N; p.K = K; p.lda = (unsigned)lda; p.ldc = (unsigned)ldc;
   p.c_div = 0; p.c_lo = 0; p.c_hi = 0;
   p.oflow = nullptr;

@@ -694,3 +694,36 @@ def test_gemm_split_row_scaled_inputs_of_any_magnitude():
     ok = torch.ones(M, dtype=torch.bool, device=dev())
     ok[100] = ok[200] = False
     assert torch.equal(out3[ok], out[ok])
+
+
+@pytest.mark.parametrize("M,N,K,act,res,a_packed,cpk", [
+    (256, 20670, 3360, 0, False, False, False),     # the final product (ragged last 64-row block of W, ragged N tile)
+    (2304, 3072, 2048, 0, False, False, False),     # layer-1 GRU projection
+    (69632, 1536, 512, 0, False, True, False),      # qkv at B = 256, C = 512
+    (69632, 512, 1024, 0, True, True, False),       # fc2 + residual
+    (4352, 1024, 512, 1, False, True, True),        # fc1: GELU, packed result
+    (300, 200, 64, 1, True, False, False),          # ragged everything, 64x64-ish
+])
+def test_gemm_split_blocked_weight_layout_is_bit_identical(M, N, K, act, res, a_packed, cpk):
+    """The blocked weight layout the model packs ([N/64][K/16][64][16 hi | 16 lo]: a tile's k-slice is contiguous) against the
+    row-major one: same planes, same arithmetic, same k order -> the same bits; also with a row-scaled A and mapped output rows."""
+    from pmce_amd import ops
+    A = rnd("blk.A", (M, K)).to(dev())
+    W = rnd("blk.W", (N, K), scale=K ** -0.5).to(dev())
+    b = rnd("blk.b", (N,)).to(dev())
+    R = rnd("blk.R", (M, N)).to(dev()) if res else None
+    Wp, ws = ops.pack_split_f16(W)
+    Wb, wsb, _ = ops.pack_split_f16_blk(W)
+    assert torch.equal(ws, wsb)
+    Ain = ops.split_rows_f16(A) if a_packed else A
+    want = ops.gemm_nt_split(Ain, Wp, ws, b, R, act, a_packed=a_packed, c_packed=cpk)
+    got = ops.gemm_nt_split_blk(Ain, Wb, wsb, N, b, R, act, a_packed=a_packed, c_packed=cpk)
+    assert torch.equal(want.view(torch.int32), got.view(torch.int32))
+    if not (act or res or cpk) and M % 16 == 0:
+        Ap, rs = ops.split_rows_scaled_f16(A * 1e5)
+        T_ = 16
+        want = torch.empty(M, N, device=dev())
+        got = torch.empty(M, N, device=dev())
+        ops.gemm_nt_split_rs(Ap, rs, Wp, ws, b, out=want, rowmap=(T_, (M // T_) * N, N))
+        ops.gemm_nt_split_blk(Ap, Wb, wsb, N, b, rscale=rs, rowmap=(T_, (M // T_) * N, N), out=got)
+        assert torch.equal(want, got)
