@@ -459,13 +459,13 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
     clk = torch.zeros(2, dtype=torch.int64, device=dev)
     lib = _lib.load()
     if gemm_mode == "split_f16":       # the split kernel's workgroups report their residence in shader clocks and 100 MHz ticks
-        lib.pmce_gemm_split_set_clock_probe(ctypes.c_void_p(clk.data_ptr()))
+        lib.pmce_model_set_clock_probe(model._ensure_packed().handle, ctypes.c_void_p(clk.data_ptr()))
     model.profile(True)
     nprof = 3
     for _ in range(nprof):
         run1()
     torch.cuda.synchronize()
-    lib.pmce_gemm_split_set_clock_probe(None)
+    lib.pmce_model_set_clock_probe(model._ensure_packed().handle, None)
     prof = model.profile_read()
     model.profile(False)
     clk_ghz = float(clk[0].item()) / float(clk[1].item()) * 0.1 if int(clk[1].item()) > 0 else None

@@ -20,7 +20,7 @@
  *     pmce_model_profile_read (waits for the recorded events);
  *   - mutable state outside the handles: the thread-local error string and, while a model entry point runs, the thread-local
  *     pointer to that model's overflow word - one process per GPU or several host threads with their own streams are both fine -
- *     and the process-wide TUNING AIDS pmce_gemm_set_tuning, pmce_gemm_split_set_tuning / _set_skew / _set_clock_probe (relaxed atomics
+ *     and the process-wide TUNING AIDS pmce_gemm_set_tuning, pmce_gemm_split_set_tuning / _set_skew (relaxed atomics
  *     read at launch time: meant for benchmarks and tests, not to be flipped while forwards are being enqueued elsewhere).
  * Fixed structural constants of the path: T = 16 frames, F = 2048 image-feature channels, V = 431 coarse
  * vertices, 6890 mesh vertices, D = 64 decoder channels, GRU hidden 1024, 8 lifter heads.  J <= 32,
@@ -110,6 +110,11 @@ int pmce_model_set_split_min_batch(pmce_model* m, int clips);
  * PMCE_STRICT_OVERFLOW=1 at create): while the word is set every entry point returns PMCE_ERR_OVERFLOW before launching
  * anything.  Pipeline lanes created with pmce_model_share_split_weights share the source's word. */
 int pmce_model_set_overflow_policy(pmce_model* m, int strict);
+/* Measurement aid (bench.py), per MODEL: while set (null = off), every launch of the split GEMM made by an entry point of this model
+ * adds, per workgroup, the shader clocks and the 100 MHz wall ticks its first wave was resident to device_two_words[0] / [1]: their
+ * ratio x 0.1 is the shader clock in GHz the chip sustained under the kernel (MI355X is power-limited there: 1.6 - 1.8 GHz, not the
+ * 2.4 GHz of the peak figures). */
+int pmce_model_set_clock_probe(pmce_model* m, unsigned long long* device_two_words);
 int pmce_model_overflowed(const pmce_model* m);
 int pmce_model_clear_overflow(pmce_model* m);
 /* Bytes of caller-provided workspace needed for a batch of B clips. */
@@ -233,10 +238,6 @@ int pmce_gemm_nt_split_f16_blk(const float* A, const float* rscale, const float*
 int pmce_split_rows_f16(const float* A, long long M, int K, long long lda, float* Ap, pmce_stream_t stream);
 /* Tuning aid only: force the tile configuration of pmce_gemm_nt_split_f16 (0: 128x256, 1: 128x128, 2: 64x128; -1 automatic). */
 int pmce_gemm_split_set_tuning(int tile);
-/* Measurement aid (bench.py): while set (null = off), every launch of the 4-wave split kernel adds, per workgroup, the shader
- * clocks and the 100 MHz wall ticks its first wave was resident to device_two_words[0] / [1]: their ratio x 0.1 is the shader clock
- * in GHz the chip sustained under the kernel (MI355X is power-limited there: 1.6 - 1.8 GHz, not the 2.4 GHz of the peak figures). */
-int pmce_gemm_split_set_clock_probe(unsigned long long* device_two_words);
 /* Tuning aid only: start delay of every CU's second workgroup in units of 4096 cycles (-1: half a tile of matrix time). */
 int pmce_gemm_split_set_skew(int units);
 /* PoseEstimation.py:78-81 — x[tok] = joint_embed(pose2d) + imgfeat_embed(img_feat)[b,t] + spatial_pos[j]. */

@@ -51,6 +51,7 @@ PROTOTYPES = {
     "pmce_model_share_split_weights": [C.c_void_p, C.c_void_p],
     "pmce_model_set_split_min_batch": [C.c_void_p, _i],
     "pmce_model_set_overflow_policy": [C.c_void_p, _i],
+    "pmce_model_set_clock_probe": [C.c_void_p, C.c_void_p],
     "pmce_model_overflowed": [C.c_void_p],
     "pmce_model_clear_overflow": [C.c_void_p],
     "pmce_model_profile_read": [C.c_void_p, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_longlong)],
@@ -70,7 +71,6 @@ PROTOTYPES = {
     "pmce_seq_attention_split_f16": [_f, _f, _i, _i, _i, _i, _l, _l, _l, _s],
     "pmce_gemm_nt_split_f16_rowmap": [_f, _f, _f, _f, _f, _i, _i, _i, _l, _i, _l, _l, _s],
     "pmce_gemm_split_set_tuning": [_i],
-    "pmce_gemm_split_set_clock_probe": [C.c_void_p],
     "pmce_gemm_split_set_skew": [_i],
     "pmce_embed_tokens_f32": [_f, _f, _f, _f, _f, _f, _l, _i, _i, _s],
     "pmce_ln_chain_f32": [_f, _l, _i, _f, _f, _fl, _f, _i, _i, _f, _f, _f, _fl, _f, _s],

@@ -1,5 +1,5 @@
 // Host-side error slot + version for libpmce_hip.so (no global mutable state besides a thread-local string and the thread-local
-// overflow sink of the call in progress).
+// overflow / clock-probe sinks of the call in progress).
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -8,9 +8,12 @@
 
 static thread_local char g_err[512] = "";
 static thread_local unsigned* g_overflow_sink = nullptr;
+static thread_local unsigned long long* g_clock_sink = nullptr;
 
 unsigned* pmce_overflow_sink(void) { return g_overflow_sink; }
 void pmce_set_overflow_sink(unsigned* w) { g_overflow_sink = w; }
+unsigned long long* pmce_clock_sink(void) { return g_clock_sink; }
+void pmce_set_clock_sink(unsigned long long* w) { g_clock_sink = w; }
 
 void pmce_set_error(const char* fmt, ...) {
   va_list ap;

@@ -20,6 +20,10 @@ int pmce_check_launch(const char* what);
 // set by the model entry points for the duration of a call (model.cpp), null for stand-alone operator calls.
 unsigned* pmce_overflow_sink(void);
 void pmce_set_overflow_sink(unsigned* device_visible_word);
+// Likewise the clock probe of a model (pmce_model_set_clock_probe): two device words the split GEMM's workgroups add their residence
+// to (shader clocks, 100 MHz ticks) while one of that model's entry points runs on this thread; null = off.
+unsigned long long* pmce_clock_sink(void);
+void pmce_set_clock_sink(unsigned long long* device_two_words);
 
 // opt a kernel into > 64 KB of dynamic LDS, once per device (the attribute is per device: a process-wide flag would leave
 // the second GPU of a process without it).  `done` is the call site's static bit mask of devices already set.

@@ -402,11 +402,6 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
 // ---- launch ---------------------------------------------------------------------------------------------------------------
 static std::atomic<int> g_split_tile{pmce_env_int("PMCE_SPLIT_TILE", -1)};
 static std::atomic<int> g_split_skew{pmce_env_int("PMCE_SPLIT_SKEW", -1)};
-static std::atomic<unsigned long long*> g_split_clk{nullptr};
-extern "C" int pmce_gemm_split_set_clock_probe(unsigned long long* device_two_words) {
-  g_split_clk.store(device_two_words, std::memory_order_relaxed);
-  return PMCE_OK;
-}
 extern "C" int pmce_gemm_split_set_skew(int units) {
   g_split_skew.store(units, std::memory_order_relaxed);
   return PMCE_OK;
@@ -487,7 +482,7 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
   p.M = M; p.N = N; p.K = K; p.lda = (unsigned)lda; p.ldc = (unsigned)ldc;
   p.c_div = c_div; p.c_lo = c_lo; p.c_hi = c_hi;
   p.oflow = pmce_overflow_sink();
-  p.clk = g_split_clk.load(std::memory_order_relaxed);
+  p.clk = pmce_clock_sink();  // (thread-local: set while an entry point of a model with a clock probe runs)
   {  // half a tile of matrix time: nk iterations x 3*TM*TN instructions x 32 cycles (TM*TN = 8 or 4), / 2, in 4096-cycle units
     const int knob = g_split_skew.load(std::memory_order_relaxed);
     p.skew = knob >= 0 ? knob : (K / 16) * 12 * 32 / 4096 + 1;

@@ -121,6 +121,7 @@ struct pmce_model {
   // beyond f16's 65504 turns into inf / nan there, and so does fp32 overflow), checked by every entry point BEFORE it launches.
   std::shared_ptr<unsigned> oflow;  // shared by handles cloned onto the same weights (pipeline lanes): one model, one flag
   bool strict_overflow = false;     // pmce_model_set_overflow_policy: refuse further calls while the word is set
+  unsigned long long* clk = nullptr;  // pmce_model_set_clock_probe: two device words (null = off)
   bool wblk = true;                 // the products' packed weights in the blocked layout (PMCE_SPLIT_WBLK=0 at create: row-major, an A/B knob)
   // regressor (optional)
   const int* jr_indptr = nullptr;
@@ -969,6 +970,11 @@ int pmce_model_clear_overflow(pmce_model* m) {
   *reinterpret_cast<volatile unsigned*>(m->oflow.get()) = 0u;
   return PMCE_OK;
 }
+int pmce_model_set_clock_probe(pmce_model* m, unsigned long long* device_two_words) {
+  PMCE_REQUIRE(m, "model_set_clock_probe: null model");
+  m->clk = device_two_words;
+  return PMCE_OK;
+}
 int pmce_model_set_overflow_policy(pmce_model* m, int strict) {
   PMCE_REQUIRE(m, "model_set_overflow_policy: null model");
   m->strict_overflow = strict != 0;
@@ -1015,8 +1021,11 @@ long long pmce_model_workspace_offset(const pmce_model* m, int batch, const char
 }
 
 namespace {
-struct SinkGuard {  // the launchers of this thread report to the model's flag only while one of its entry points runs
-  ~SinkGuard() { pmce_set_overflow_sink(nullptr); }
+struct SinkGuard {  // the launchers of this thread report to the model's flag (and clock probe) only while one of its entry points runs
+  ~SinkGuard() {
+    pmce_set_overflow_sink(nullptr);
+    pmce_set_clock_sink(nullptr);
+  }
 };
 }  // namespace
 
@@ -1037,6 +1046,7 @@ static int check_ws(pmce_model* m, int batch, void* ws, size_t ws_bytes) {
   }
   m->split_now = m->split_gemm && batch >= m->split_min_batch;  // arithmetic (and with it the stream schedule) of this call
   pmce_set_overflow_sink(m->oflow.get());  // (thread-local; the entry point clears it again through its SinkGuard)
+  pmce_set_clock_sink(m->clk);
   return PMCE_OK;
 }
 
