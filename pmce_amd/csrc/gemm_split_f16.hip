@@ -449,6 +449,24 @@ static const SplitTile kSplitTiles[] = {{128, 256, 1.0}, {128, 128, 1.12}, {64, 
 static int pick_split_tile(int M, int N) {
   const int forced = g_split_tile.load(std::memory_order_relaxed);
   if (forced >= 0 && forced < 3) return forced;
+  // Small grids (fewer 128x256 tiles than CUs): the launch is ONE round of workgroups, each bound by its own serial chain per
+  // k-tile (wait -> barrier -> DMA issue -> fragment reads -> 24 / 12 / 6 dependent matrix instructions per wave): 0.9 / 0.66 / 0.43 us
+  // per iteration for the three shapes whatever the number of tiles (profiles/r04_c_*: the AdaLN product's 24 workgroups iterate as
+  // fast as the GRU projection's 216).  Take the shape with the shortest chain whose tiles still run in one round (two workgroups per
+  // CU interleave, three of the smallest shape fit).
+  if ((long long)((M + 127) / 128) * ((N + 255) / 256) < 256) {
+    static const double t_iter[3] = {0.9, 0.66, 0.43};
+    static const int slots[3] = {512, 512, 768};
+    int best = 0;
+    double best_cost = 1e300;
+    for (int i = 0; i < 3; ++i) {
+      const SplitTile& t = kSplitTiles[i];
+      const long long tiles = (long long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
+      const double cost = (double)((tiles + slots[i] - 1) / slots[i]) * t_iter[i];
+      if (cost < best_cost - 1e-12) { best_cost = cost; best = i; }
+    }
+    return best;
+  }
   int best = 0;
   double best_cost = 1e300;
   for (int i = 0; i < 3; ++i) {
