@@ -45,12 +45,18 @@ struct SplitCfg {
 
 // RS: A is packed AND row-scaled (raw inputs of any fp32 magnitude: imgfeat_embed, the GRU layer-0 input projection) - the
 // accumulators start at zero and the epilogue computes acc * 2^-s(n) * 2^e(m) + bias[n].
-template <int TM, int TN, int ACT, bool RES, bool APACK, bool OPACK = false, bool RS = false>
+// KSUB = 2 (round 4; the 64x128 tile on small grids): a stage holds TWO consecutive 16-wide k-tiles, each in the layout of a KSUB = 1
+// stage, fetched together and multiplied behind ONE wait and ONE barrier.  A launch of a few hundred small tiles is bound by a
+// workgroup's serial chain per k-tile (wait -> barrier -> DMA issue -> fragment reads -> 6 dependent matrix instructions per wave: 0.43 us
+// whatever the grid, profiles/r04_c_*); two k-tiles per trip halve the trips.  Same arithmetic and k order: bit-identical results.
+template <int TM, int TN, int ACT, bool RES, bool APACK, bool OPACK = false, bool RS = false, int KSUB = 1>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
   static_assert(!RS || (APACK && !OPACK && !RES), "a row-scaled A is a packed A; no packed result, no residual");
   using Cfg = SplitCfg<TM, TN>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, WM = 32 * TM, WN = 32 * TN;
-  constexpr int NS = Cfg::NS, SF = Cfg::STAGE_FLOATS, DPW = Cfg::DPW;
+  constexpr int SUBF = Cfg::STAGE_FLOATS;                         // one 16-wide k-tile of the stage
+  constexpr int NS = KSUB == 1 ? Cfg::NS : 3, SF = KSUB * SUBF, DPW = KSUB * Cfg::DPW;
+  static_assert(KSUB == 1 || KSUB == 2, "one or two k-tiles per stage (four measured: no further gain)");
   constexpr int GA = BM / 16;  // 16-row groups of the A part of a stage (a multiple of 4: every wave's first GA/4 DMAs are A's)
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
   const bool probe = p.clk != nullptr && tid == 0;
   const long long pc0 = probe ? (long long)__builtin_readcyclecounter() : 0, pw0 = probe ? (long long)wall_clock64() : 0;
   const int my_tiles = (chunk_len - bx + gx - 1) / gx;
-  const int nk = p.K / 16;
+  const int nk = p.K / (16 * KSUB);  // stages per tile
   const int total = my_tiles * nk;
   // The two workgroups of a CU start together and their tiles take the same time: left alone they reach their epilogues
   // (a burst of stores with the matrix pipe idle) at the same moment, tile after tile.  The second workgroup of each CU (the
@@ -101,10 +107,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
   // chunk L & 3, which holds logical chunk (L & 3) ^ ((row >> 2) & 3) = (L & 3) ^ ((L >> 4) & 3). ----
   const int drow = lane >> 2;
   const unsigned dchunk = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) * 4);  // floats
-  unsigned doff[DPW];
+  constexpr int DPS = Cfg::DPW;  // DMA instructions per wave per 16-wide k-tile
+  unsigned doff[DPS];
   auto set_ptrs = [&](int mb, int nb) {
 #pragma unroll
-    for (int q = 0; q < DPW; ++q) {
+    for (int q = 0; q < DPS; ++q) {
       const int g = wave + 4 * q;
       if (g < GA)
         doff[q] = ((unsigned)min(mb + 16 * g + drow, p.M - 1) * p.lda + dchunk) * 4u;
@@ -119,11 +126,14 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
   const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
   const int kstep_w = p.wblk ? 4096 : 64;  // bytes from one k-tile of a W row (block) to the next
   auto issue = [&](int kt, int stage) {
-    const int ko = kt * 64, kw = kt * kstep_w;  // bytes
 #pragma unroll
-    for (int q = 0; q < DPW; ++q) {
-      const bool is_a = (wave + 4 * q) < GA;
-      sdma16(is_a ? rsrc_a : rsrc_w, doff[q], is_a ? ko : kw, lds_wave + stage * (SF * 4) + q * 4096);
+    for (int sub = 0; sub < KSUB; ++sub) {
+      const int ko = (kt * KSUB + sub) * 64, kw = (kt * KSUB + sub) * kstep_w;  // bytes
+#pragma unroll
+      for (int q = 0; q < DPS; ++q) {
+        const bool is_a = (wave + 4 * q) < GA;
+        sdma16(is_a ? rsrc_a : rsrc_w, doff[q], is_a ? ko : kw, lds_wave + stage * (SF * 4) + sub * (SUBF * 4) + q * 4096);
+      }
     }
   };
 
@@ -192,8 +202,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
           for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
       }
     }
-    const float* sA = lds + stage * SF;
-    {
+#pragma unroll
+    for (int sub = 0; sub < KSUB; ++sub) {
+    const float* sA = lds + stage * SF + sub * SUBF;
     f16x8 ahi[TM], alo[TM], whi[TN], wlo[TN], wh2[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -411,16 +422,38 @@ extern "C" int pmce_gemm_split_set_tuning(int tile) {
   return PMCE_OK;
 }
 
-template <int TM, int TN, int ACT, bool RES, bool APACK, bool OPACK = false, bool RS = false>
+template <int TM, int TN, int ACT, bool RES, bool APACK, bool OPACK = false, bool RS = false, int KSUB = 1>
 static int launch_one(const SplitParams& p, int grid, hipStream_t stream) {
   using Cfg = SplitCfg<TM, TN>;
   static std::atomic<unsigned long long> done{0};
-  constexpr int LDS = Cfg::LDS_BYTES + (RS ? 2048 : 0);  // + two slices of BM row scales
-  PMCE_TRY(pmce_opt_in_lds(reinterpret_cast<const void*>(&gemm_split_kernel<TM, TN, ACT, RES, APACK, OPACK, RS>), LDS, done,
+  constexpr int LDS = (KSUB == 1 ? Cfg::LDS_BYTES : 3 * KSUB * Cfg::STAGE_FLOATS * 4 + 4096) + (RS ? 2048 : 0);  // + two slices of BM row scales
+  PMCE_TRY(pmce_opt_in_lds(reinterpret_cast<const void*>(&gemm_split_kernel<TM, TN, ACT, RES, APACK, OPACK, RS, KSUB>), LDS, done,
                            "gemm_split_f16"));
-  hipLaunchKernelGGL((gemm_split_kernel<TM, TN, ACT, RES, APACK, OPACK, RS>), dim3(grid), dim3(256), LDS, stream, p);
+  hipLaunchKernelGGL((gemm_split_kernel<TM, TN, ACT, RES, APACK, OPACK, RS, KSUB>), dim3(grid), dim3(256), LDS, stream, p);
   return PMCE_OK;
 }
+// the 64x128 tile with two k-tiles per stage (small grids): the operand / epilogue combinations the model's products use
+template <int KSUB>
+static int launch_small_k32(SplitParams& p, int act, bool apack, bool opack, hipStream_t stream) {
+  using Cfg = SplitCfg<1, 2>;
+  p.ntm = (p.M + Cfg::BM - 1) / Cfg::BM;
+  p.ntn = (p.N + Cfg::BN - 1) / Cfg::BN;
+  int g = p.ntm * p.ntn;
+  if (g > 512) g = 512;
+  g = (g + 7) & ~7;
+  const bool res = p.R != nullptr;
+  if (p.rscale) return launch_one<1, 2, 0, false, true, false, true, KSUB>(p, g, stream);
+  if (opack) return launch_one<1, 2, 1, false, true, true, false, KSUB>(p, g, stream);
+  if (apack) return res ? launch_one<1, 2, 0, true, true, false, false, KSUB>(p, g, stream)
+                        : launch_one<1, 2, 0, false, true, false, false, KSUB>(p, g, stream);
+  return launch_one<1, 2, 0, false, false, false, false, KSUB>(p, g, stream);
+}
+static bool small_k32_form_exists(int act, bool apack, bool opack, bool res, bool rs) {
+  if (rs || opack) return true;
+  if (apack) return act == 0;
+  return act == 0 && !res;
+}
+static const int g_split_k32 = pmce_env_int("PMCE_SPLIT_K32", 1);  // A/B knob, read once at load
 template <int TM, int TN>
 static int launch_cfg(SplitParams& p, int act, bool apack, bool opack, hipStream_t stream) {
   using Cfg = SplitCfg<TM, TN>;
@@ -505,7 +538,14 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
     const int knob = g_split_skew.load(std::memory_order_relaxed);
     p.skew = knob >= 0 ? knob : (K / 16) * 12 * 32 / 4096 + 1;
   }
-  switch (pick_split_tile(M, N)) {
+  const int tile = pick_split_tile(M, N);
+  if (tile == 2 && g_split_k32 && g_split_tile.load(std::memory_order_relaxed) < 0 && K % 32 == 0 && K >= 128 &&
+      (long long)((M + 63) / 64) * ((N + 127) / 128) <= 512 &&
+      small_k32_form_exists(act, a_packed != 0, c_packed != 0, R != nullptr, rscale != nullptr)) {
+    PMCE_TRY(launch_small_k32<2>(p, act, a_packed != 0, c_packed != 0, stream));  // small grid: two k-tiles per trip
+    return pmce_check_launch("gemm_nt_split_f16 (64x128, two k-tiles per stage)");
+  }
+  switch (tile) {
     case 0: PMCE_TRY((launch_cfg<2, 4>(p, act, a_packed != 0, c_packed != 0, stream))); break;
     case 1: PMCE_TRY((launch_cfg<2, 2>(p, act, a_packed != 0, c_packed != 0, stream))); break;
     default: PMCE_TRY((launch_cfg<1, 2>(p, act, a_packed != 0, c_packed != 0, stream))); break;
