@@ -323,6 +323,18 @@ int pmce_vertex_ca_mlp_ex_f32(const float* xq, const float* vt, const float* Wv3
                               const float* s0, const float* Vf, const float* bp, const float* GB, int gb_stride, int inst,
                               const float* W1, const float* b1, const float* W2, const float* b2, float* yout, float* scratch,
                               int B, int J, int split_f16, pmce_stream_t stream);
+/* _pk forms: with split_f16 != 0 and ffn_img != NULL every workgroup COPIES the FFN's f16 form into LDS from an image made once
+ * (pmce_ffn_pack_f16 from the same W1 [256,64] / W2 [64,256]: pmce_ffn_image_floats() floats, 16-byte aligned) instead of converting
+ * W1 / W2 itself; the same bits as the _ex forms (ffn_img == NULL is exactly those).  pmce_model_finalize makes the six images. */
+int pmce_ffn_image_floats(void);
+int pmce_ffn_pack_f16(const float* W1, const float* W2, float* ffn_img, pmce_stream_t stream);
+int pmce_adaln_mlp_pk_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* W1, const float* b1,
+                          const float* W2, const float* b2, float* yout, const float* Wc, const float* bc, const float* vt_in,
+                          float* vt_out, int B, int split_f16, const float* ffn_img, pmce_stream_t stream);
+int pmce_vertex_ca_mlp_pk_f32(const float* xq, const float* vt, const float* Wv3, const float* Eq, const float* Kf,
+                              const float* s0, const float* Vf, const float* bp, const float* GB, int gb_stride, int inst,
+                              const float* W1, const float* b1, const float* W2, const float* b2, float* yout, float* scratch,
+                              int B, int J, int split_f16, const float* ffn_img, pmce_stream_t stream);
 
 /* qkv = Linear(64->192)(AdaLN(x)) on [B,431,64] (CoevoDecoder.py:103,120). */
 int pmce_adaln_qkv_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* Wqkv, const float* bqkv,

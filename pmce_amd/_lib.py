@@ -86,6 +86,10 @@ PROTOTYPES = {
     "pmce_adaln_mlp_f32": [_f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _s],
     "pmce_adaln_mlp_ex_f32": [_f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],
     "pmce_vertex_ca_mlp_ex_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _s],
+    "pmce_ffn_image_floats": [],
+    "pmce_ffn_pack_f16": [_f, _f, _f, _s],
+    "pmce_adaln_mlp_pk_f32": [_f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f, _s],
+    "pmce_vertex_ca_mlp_pk_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _s],
     "pmce_vertex_ca_mlp_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _s],
     "pmce_adaln_qkv_f32": [_f, _f, _i, _i, _f, _f, _f, _i, _s],
     "pmce_vertex_sa_f32": [_f, _f, _f, _f, _f, _i, _s],

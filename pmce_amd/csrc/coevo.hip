@@ -552,6 +552,33 @@ __device__ __forceinline__ void stage_ffn(float* sW1, float* sW2, float* sSc, co
   }
 }
 
+// The f16 form's LDS image of an FFN, made ONCE per model (pmce_ffn_pack_f16: [sW1 | sW2] as stage_ffn<true> writes them, then the four
+// scales): staging a workgroup's 137 KB is then a plain copy instead of three passes over the fp32 weights (two for the scales, one
+// converting) - a launch of the two FFN-carrying kernels is 1.75 wave tiles per wave slot, so that staging was a third of its time.
+#define FFN_IMG_FLOATS (256 * LDW64 + 64 * LDW256 + 32)
+template <bool F16>
+__device__ __forceinline__ void stage_ffn_any(float* sW1, float* sW2, float* sSc, const float* W1, const float* W2,
+                                              const float* __restrict__ img, int tid, int nthreads) {
+  if constexpr (F16) {
+    if (img) {
+      for (int i = tid; i < (256 * LDW64 + 64 * LDW256) / 4; i += nthreads)
+        reinterpret_cast<f32x4*>(sW1)[i] = reinterpret_cast<const f32x4*>(img)[i];
+      if (tid < 4) sSc[tid] = img[256 * LDW64 + 64 * LDW256 + tid];
+      return;
+    }
+  }
+  stage_ffn<F16>(sW1, sW2, sSc, W1, W2, tid, nthreads);
+}
+__global__ __launch_bounds__(512) void ffn_pack_kernel(const float* __restrict__ W1, const float* __restrict__ W2, float* __restrict__ img) {
+  stage_ffn<true>(img, img + 256 * LDW64, img + 256 * LDW64 + 64 * LDW256, W1, W2, threadIdx.x, 512);
+}
+extern "C" int pmce_ffn_pack_f16(const float* W1, const float* W2, float* img, hipStream_t stream) {
+  PMCE_REQUIRE(W1 && W2 && img && (reinterpret_cast<uintptr_t>(img) & 15) == 0, "ffn_pack: null or unaligned pointer");
+  hipLaunchKernelGGL(ffn_pack_kernel, dim3(1), dim3(512), 0, stream, W1, W2, img);
+  return pmce_check_launch("ffn_pack_f16");
+}
+extern "C" int pmce_ffn_image_floats(void) { return FFN_IMG_FLOATS; }
+
 // ======================================================================================================
 // adaln_mlp:  y = x + fc2(gelu(fc1(AdaLN(x))))   (hidden 256), optionally followed by the coordinate head
 //   vt_out = Wc*y + bc + vt_in  (proj_vertx_feat2coor + residual, CoevoDecoder.py:189).
@@ -564,7 +591,8 @@ __global__ __launch_bounds__(512) void adaln_mlp_kernel(const float* __restrict_
                                                         const float* __restrict__ b1, const float* __restrict__ W2,
                                                         const float* __restrict__ b2, float* __restrict__ yout,
                                                         const float* __restrict__ Wc, const float* __restrict__ bc,
-                                                        const float* __restrict__ vt_in, float* __restrict__ vt_out, int B) {
+                                                        const float* __restrict__ vt_in, float* __restrict__ vt_out, int B,
+                                                        const float* __restrict__ ffn_img) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sW1 = smem;                    // [256][68]
   float* sW2 = sW1 + 256 * LDW64;       // [64][260]
@@ -572,7 +600,7 @@ __global__ __launch_bounds__(512) void adaln_mlp_kernel(const float* __restrict_
   float* sB2 = sB1 + 256;               // [64]
   float* sSc = sB2 + 64;                // [4 + 16] scales of the f16 form + reduction scratch
   const int tid = threadIdx.x;
-  stage_ffn<F16>(sW1, sW2, sSc, W1, W2, tid, 512);
+  stage_ffn_any<F16>(sW1, sW2, sSc, W1, W2, ffn_img, tid, 512);
   if (tid < 256) sB1[tid] = b1[tid];
   if (tid < 64) sB2[tid] = b2[tid];
   __syncthreads();
@@ -646,7 +674,7 @@ __global__ __launch_bounds__(448) void vertex_ca_mlp_kernel(const float* __restr
                                                             const float* __restrict__ GB, int gb_stride, int inst,
                                                             const float* __restrict__ W1, const float* __restrict__ b1,
                                                             const float* __restrict__ W2, const float* __restrict__ b2,
-                                                            float* __restrict__ yout, int B, int J) {
+                                                            float* __restrict__ yout, int B, int J, const float* __restrict__ ffn_img) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sW1 = smem;                    // [256][68]
   float* sW2 = sW1 + 256 * LDW64;       // [64][260]
@@ -657,7 +685,7 @@ __global__ __launch_bounds__(448) void vertex_ca_mlp_kernel(const float* __restr
   float* sV = sS0 + 64;                 // [64][CAM_VLD]   Vf[c][h*24 + i], i < 24
   float* sK = sV + 64 * CAM_VLD;        // [2*J][68]       Kf[h*J + i][c], i < J
   const int tid = threadIdx.x;
-  stage_ffn<F16>(sW1, sW2, sSc, W1, W2, tid, 448);
+  stage_ffn_any<F16>(sW1, sW2, sSc, W1, W2, ffn_img, tid, 448);
   if (tid < 256) sB1[tid] = b1[tid];
   if (tid < 64) sB2[tid] = b2[tid];
   const int lane = tid & 63, wave = tid >> 6;
@@ -1567,10 +1595,26 @@ extern "C" int pmce_vertex_ca_f32(const float* xq, const float* vt, const float*
   return pmce_check_launch("vertex_ca");
 }
 
+extern "C" int pmce_adaln_mlp_pk_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* W1,
+                                     const float* b1, const float* W2, const float* b2, float* yout, const float* Wc,
+                                     const float* bc, const float* vt_in, float* vt_out, int B, int split_f16,
+                                     const float* ffn_img, hipStream_t stream);
+extern "C" int pmce_vertex_ca_mlp_pk_f32(const float* xq, const float* vt, const float* Wv3, const float* Eq, const float* Kf,
+                                         const float* s0, const float* Vf, const float* bp, const float* GB, int gb_stride,
+                                         int inst, const float* W1, const float* b1, const float* W2, const float* b2,
+                                         float* yout, float* scratch, int B, int J, int split_f16, const float* ffn_img,
+                                         hipStream_t stream);
 extern "C" int pmce_adaln_mlp_ex_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* W1,
                                      const float* b1, const float* W2, const float* b2, float* yout, const float* Wc,
                                      const float* bc, const float* vt_in, float* vt_out, int B, int split_f16,
                                      hipStream_t stream) {
+  return pmce_adaln_mlp_pk_f32(xin, GB, gb_stride, inst, W1, b1, W2, b2, yout, Wc, bc, vt_in, vt_out, B, split_f16, nullptr, stream);
+}
+// ffn_img: the FFN's pre-made LDS image of the f16 form (pmce_ffn_pack_f16; null = made by every workgroup from W1 / W2)
+extern "C" int pmce_adaln_mlp_pk_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* W1,
+                                     const float* b1, const float* W2, const float* b2, float* yout, const float* Wc,
+                                     const float* bc, const float* vt_in, float* vt_out, int B, int split_f16,
+                                     const float* ffn_img, hipStream_t stream) {
   PMCE_REQUIRE(xin && GB && W1 && b1 && W2 && b2 && (yout || vt_out), "adaln_mlp: null pointer");
   PMCE_REQUIRE(!vt_out || (Wc && bc && vt_in), "adaln_mlp: coordinate head needs Wc, bc, vt_in");
   const size_t lds = (size_t)(256 * LDW64 + 64 * LDW256 + 256 + 64 + 32) * sizeof(float);
@@ -1578,11 +1622,11 @@ extern "C" int pmce_adaln_mlp_ex_f32(const float* xin, const float* GB, int gb_s
   if (split_f16) {
     PMCE_TRY(pmce_opt_in_lds((const void*)adaln_mlp_kernel<true>, (int)lds, attr_s, "adaln_mlp"));
     hipLaunchKernelGGL(adaln_mlp_kernel<true>, dim3(mlp_grid(B)), dim3(512), lds, stream, xin, GB, gb_stride, inst, W1, b1, W2, b2,
-                       yout, Wc, bc, vt_in, vt_out, B);
+                       yout, Wc, bc, vt_in, vt_out, B, ffn_img);
   } else {
     PMCE_TRY(pmce_opt_in_lds((const void*)adaln_mlp_kernel<false>, (int)lds, attr, "adaln_mlp"));
     hipLaunchKernelGGL(adaln_mlp_kernel<false>, dim3(mlp_grid(B)), dim3(512), lds, stream, xin, GB, gb_stride, inst, W1, b1, W2, b2,
-                       yout, Wc, bc, vt_in, vt_out, B);
+                       yout, Wc, bc, vt_in, vt_out, B, nullptr);
   }
   return pmce_check_launch("adaln_mlp");
 }
@@ -1596,14 +1640,22 @@ extern "C" int pmce_vertex_ca_mlp_ex_f32(const float* xq, const float* vt, const
                                          const float* s0, const float* Vf, const float* bp, const float* GB, int gb_stride,
                                          int inst, const float* W1, const float* b1, const float* W2, const float* b2,
                                          float* yout, float* scratch, int B, int J, int split_f16, hipStream_t stream) {
+  return pmce_vertex_ca_mlp_pk_f32(xq, vt, Wv3, Eq, Kf, s0, Vf, bp, GB, gb_stride, inst, W1, b1, W2, b2, yout, scratch, B, J, split_f16,
+                                   nullptr, stream);
+}
+extern "C" int pmce_vertex_ca_mlp_pk_f32(const float* xq, const float* vt, const float* Wv3, const float* Eq, const float* Kf,
+                                         const float* s0, const float* Vf, const float* bp, const float* GB, int gb_stride,
+                                         int inst, const float* W1, const float* b1, const float* W2, const float* b2,
+                                         float* yout, float* scratch, int B, int J, int split_f16, const float* ffn_img,
+                                         hipStream_t stream) {
   PMCE_REQUIRE((xq || (vt && Wv3 && Eq)) && Kf && s0 && Vf && bp && GB && W1 && b1 && W2 && b2 && yout,
                "vertex_ca_mlp: null pointer");
   PMCE_REQUIRE(J >= 1 && J <= 32 && B > 0, "vertex_ca_mlp: J must be in 1..32");
   if (J > 23) {  // one clip's folded operands no longer fit beside the FFN weights: the two-launch form
     PMCE_REQUIRE(scratch, "vertex_ca_mlp: J > 23 needs a [B,431,64] scratch buffer");
     PMCE_TRY(pmce_vertex_ca_f32(xq, vt, Wv3, Eq, Kf, s0, Vf, bp, scratch, B, J, stream));
-    return pmce_adaln_mlp_ex_f32(scratch, GB, gb_stride, inst, W1, b1, W2, b2, yout, nullptr, nullptr, nullptr, nullptr, B, split_f16,
-                                 stream);
+    return pmce_adaln_mlp_pk_f32(scratch, GB, gb_stride, inst, W1, b1, W2, b2, yout, nullptr, nullptr, nullptr, nullptr, B, split_f16,
+                                 ffn_img, stream);
   }
   const size_t lds = (size_t)(256 * LDW64 + 64 * LDW256 + 256 + 64 + 32 + 64 + 64 * CAM_VLD + 2 * J * LDW64) * sizeof(float);
   static std::atomic<unsigned long long> attr{0}, attr_s{0};
@@ -1611,11 +1663,11 @@ extern "C" int pmce_vertex_ca_mlp_ex_f32(const float* xq, const float* vt, const
   if (split_f16) {
     PMCE_TRY(pmce_opt_in_lds((const void*)vertex_ca_mlp_kernel<true>, 163840, attr_s, "vertex_ca_mlp"));
     hipLaunchKernelGGL(vertex_ca_mlp_kernel<true>, dim3(g), dim3(448), lds, stream, xq, vt, Wv3, Eq, Kf, s0, Vf, bp, GB, gb_stride,
-                       inst, W1, b1, W2, b2, yout, B, J);
+                       inst, W1, b1, W2, b2, yout, B, J, ffn_img);
   } else {
     PMCE_TRY(pmce_opt_in_lds((const void*)vertex_ca_mlp_kernel<false>, 163840, attr, "vertex_ca_mlp"));
     hipLaunchKernelGGL(vertex_ca_mlp_kernel<false>, dim3(g), dim3(448), lds, stream, xq, vt, Wv3, Eq, Kf, s0, Vf, bp, GB, gb_stride,
-                       inst, W1, b1, W2, b2, yout, B, J);
+                       inst, W1, b1, W2, b2, yout, B, J, nullptr);
   }
   return pmce_check_launch("vertex_ca_mlp");
 }

@@ -196,9 +196,20 @@ def cross_attn_vertex(xq, xk, xv, g, sd, p):
     return out
 
 
-def cross_attn_block_vertex(xq, xk, xv, g, sd, p, split_f16=False):
+def ffn_image(fc1_w, fc2_w):
+    """The LDS image of a 64->256->64 FFN's f16 form (pmce_ffn_pack_f16): what pmce_model_finalize makes per decoder FFN."""
+    lib = _lib.load()
+    fc1_w, fc2_w = _c(fc1_w), _c(fc2_w)
+    assert tuple(fc1_w.shape) == (256, 64) and tuple(fc2_w.shape) == (64, 256)
+    img = torch.empty(lib.pmce_ffn_image_floats(), device=fc1_w.device)
+    _lib.check(lib.pmce_ffn_pack_f16(P(fc1_w), P(fc2_w), P(img), _st()), "ffn_pack_f16")
+    return img
+
+
+def cross_attn_block_vertex(xq, xk, xv, g, sd, p, split_f16=False, packed=False):
     """The whole vertex-stream CrossAttentionBlock in one launch (CoevoDecoder.py:82-87), p = '...vertx_CA_FFN':
-    xq + CA(...) then + Mlp(AdaLN_2(.)).  Bit-identical to cross_attn_vertex followed by adaln_mlp."""
+    xq + CA(...) then + Mlp(AdaLN_2(.)).  Bit-identical to cross_attn_vertex followed by adaln_mlp.
+    packed (with split_f16): the FFN's f16 form from a pre-made image (ffn_image) instead of converted per workgroup."""
     lib = _lib.load()
     xq, xk, xv = _c(xq), _c(xk), _c(xv)
     B, Nq, _ = xq.shape
@@ -217,14 +228,15 @@ def cross_attn_block_vertex(xq, xk, xv, g, sd, p, split_f16=False):
     m = [_c(sd[p + k]) for k in (".mlp.fc1.weight", ".mlp.fc1.bias", ".mlp.fc2.weight", ".mlp.fc2.bias")]
     out = torch.empty_like(xq)
     scratch = torch.empty_like(xq) if J > 23 else None
-    _lib.check(lib.pmce_vertex_ca_mlp_ex_f32(P(xq), None, None, None, P(Kf), P(s0), P(Vf), P(w["proj.bias"]), P(GB), GB.shape[1],
+    img = ffn_image(m[0], m[2]) if packed else None
+    _lib.check(lib.pmce_vertex_ca_mlp_pk_f32(P(xq), None, None, None, P(Kf), P(s0), P(Vf), P(w["proj.bias"]), P(GB), GB.shape[1],
                                              3, P(m[0]), P(m[1]), P(m[2]), P(m[3]), P(out), P(scratch), B, J,
-                                             1 if split_f16 else 0, _st()), "vertex_ca_mlp")
+                                             1 if split_f16 else 0, P(img), _st()), "vertex_ca_mlp")
     return out
 
 
-def adaln_mlp(x, g, sd, p_norm, p_mlp, coor=None, vt_in=None, want_features=True, split_f16=False):
-    """x + Mlp(AdaLN(x)) on [B,431,64]; optional coordinate head (Wc[3,64], bc[3]) + vt_in residual."""
+def adaln_mlp(x, g, sd, p_norm, p_mlp, coor=None, vt_in=None, want_features=True, split_f16=False, packed=False):
+    """x + Mlp(AdaLN(x)) on [B,431,64]; optional coordinate head (Wc[3,64], bc[3]) + vt_in residual.  packed: see cross_attn_block_vertex."""
     lib = _lib.load()
     x = _c(x)
     B = x.shape[0]
@@ -237,8 +249,9 @@ def adaln_mlp(x, g, sd, p_norm, p_mlp, coor=None, vt_in=None, want_features=True
         Wc, bc = _c(coor[0]), _c(coor[1])
         vt_in = _c(vt_in)
         vt_out = torch.empty_like(vt_in)
-    _lib.check(lib.pmce_adaln_mlp_ex_f32(P(x), P(GB), GB.shape[1], 0, P(w[0]), P(w[1]), P(w[2]), P(w[3]), P(y), P(Wc), P(bc),
-                                         P(vt_in), P(vt_out), B, 1 if split_f16 else 0, _st()), "adaln_mlp")
+    img = ffn_image(w[0], w[2]) if packed else None
+    _lib.check(lib.pmce_adaln_mlp_pk_f32(P(x), P(GB), GB.shape[1], 0, P(w[0]), P(w[1]), P(w[2]), P(w[3]), P(y), P(Wc), P(bc),
+                                         P(vt_in), P(vt_out), B, 1 if split_f16 else 0, P(img), _st()), "adaln_mlp")
     return y, vt_out
 
 

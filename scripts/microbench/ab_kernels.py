@@ -23,6 +23,12 @@ for B in [int(a) for a in sys.argv[1:]] or [1, 256]:
     for _ in range(5):
         model.forward_with_joints(p, f)
     torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(20):
+        model.forward_with_joints(p, f)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / 20
     model.profile(True)
     n = 10
     for _ in range(n):
@@ -31,5 +37,6 @@ for B in [int(a) for a in sys.argv[1:]] or [1, 256]:
     prof = model.profile_read()
     model.profile(False)
     out[f"B{B}"] = {k: round(v[0] / n * 1e3, 1) for k, v in prof.items() if v[1] > 0 and (only is None or k in only)}
+    out[f"B{B}"]["wall_us"] = round(wall * 1e6, 1)          # un-instrumented forwards back to back (side streams, graphs as configured)
     out[f"B{B}"]["sum_us"] = round(sum(v[0] for v in prof.values()) / n * 1e3, 1)
 print(json.dumps(out))

@@ -355,6 +355,8 @@ def test_cross_attn_block_vertex_fused(golden):
         e_or, e_two = maxabs(fused, ref3), maxabs(fused, two)
         fused16 = ops.cross_attn_block_vertex(xq3.to(dev()), xk3.to(dev()), xk3.to(dev()), g3.to(dev()), sdd, p, split_f16=True)
         e_16 = maxabs(fused16, ref3)          # the FFN in the three-product f16 form
+        packed16 = ops.cross_attn_block_vertex(xq3.to(dev()), xk3.to(dev()), xk3.to(dev()), g3.to(dev()), sdd, p, split_f16=True, packed=True)
+        assert torch.equal(packed16, fused16), "the FFN from its pre-made LDS image must give the bits of the per-workgroup conversion"
         print(f"fused CrossAttentionBlock J={J}: vs oracle {e_or:.2e} (f16-split FFN {e_16:.2e}); vs vertex_ca + adaln_mlp {e_two:.2e}")
         assert e_or < 2e-5 and e_two < 5e-6 and e_16 < 2e-5
     print(f"fused CrossAttentionBlock vs reference fixture {e_ref:.2e}")
@@ -385,6 +387,10 @@ def test_adaln_mlp(golden):
     e3, e4 = maxabs(y16, ref), maxabs(vt16, ref_vt)
     print(f"adaln_mlp, FFN in the three-product f16 form: features {e3:.2e}, coords {e4:.2e}")
     assert e3 < 2e-5 and e4 < 2e-5
+    y16p, vt16p = ops.adaln_mlp(x.to(dev()), g.to(dev()), sdd, p + ".norm2", p + ".mlp",
+                                coor=(sdd[BLK + ".proj_vertx_feat2coor.weight"], sdd[BLK + ".proj_vertx_feat2coor.bias"]),
+                                vt_in=vt.to(dev()), split_f16=True, packed=True)
+    assert torch.equal(y16p, y16) and torch.equal(vt16p, vt16), "pre-made FFN image (pmce_ffn_pack_f16) vs per-workgroup conversion"
 
 
 def test_mfma_reads_f16_subnormals():
