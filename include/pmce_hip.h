@@ -339,6 +339,12 @@ int pmce_vertex_ca_mlp_pk_f32(const float* xq, const float* vt, const float* Wv3
 /* qkv = Linear(64->192)(AdaLN(x)) on [B,431,64] (CoevoDecoder.py:103,120). */
 int pmce_adaln_qkv_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* Wqkv, const float* bqkv,
                        float* qkv, int B, pmce_stream_t stream);
+/* The same product in the three-product f16 form (fp32 in, fp32 out; what a model in split_f16 mode runs): qkv_img =
+ * pmce_qkv_pack_f16(Wqkv [192,64]) - pmce_qkv_image_floats() floats, 16-byte aligned, made once per weight. */
+int pmce_qkv_image_floats(void);
+int pmce_qkv_pack_f16(const float* Wqkv, float* qkv_img, pmce_stream_t stream);
+int pmce_adaln_qkv_split_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* qkv_img, const float* bqkv,
+                             float* qkv, int B, pmce_stream_t stream);
 /* y = x + proj(softmax(q k^T/sqrt(32)) v), 2 heads, 431x431 per clip (CoevoDecoder.py:118-131,103). */
 int pmce_vertex_sa_f32(const float* xin, const float* qkv, const float* Wp, const float* bp, float* yout, int B,
                        pmce_stream_t stream);

@@ -92,6 +92,9 @@ PROTOTYPES = {
     "pmce_vertex_ca_mlp_pk_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _s],
     "pmce_vertex_ca_mlp_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _s],
     "pmce_adaln_qkv_f32": [_f, _f, _i, _i, _f, _f, _f, _i, _s],
+    "pmce_qkv_image_floats": [],
+    "pmce_qkv_pack_f16": [_f, _f, _s],
+    "pmce_adaln_qkv_split_f32": [_f, _f, _i, _i, _f, _f, _f, _i, _s],
     "pmce_vertex_sa_f32": [_f, _f, _f, _f, _f, _i, _s],
     "pmce_vertex_sa_ex_f32": [_f, _f, _f, _f, _f, _i, _i, _s],
     "pmce_tokens_kv_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _f, _f, _f, _i, _s],

@@ -829,14 +829,25 @@ __global__ __launch_bounds__(448) void vertex_ca_mlp_kernel(const float* __restr
 // ======================================================================================================
 // adaln_qkv: qkv[tok][0:192] = Wqkv * AdaLN(x) + bqkv   (vertex self-attention input, CoevoDecoder.py:103,120)
 // ======================================================================================================
+// F16 (split mode): the product in the three-product f16 form of the FFN above - the weight as (hi, lo) fragments of W * 2^s from an image
+// made once (pmce_qkv_pack_f16: stage_weight_split's layout, then {2^s, 2^-s}); 72 matrix instructions of 32 cycles per 32-token
+// tile instead of 192 of 64.
+#define QKV_IMG_FLOATS (192 * LDW64 + 32)
+template <bool F16>
 __global__ __launch_bounds__(256) void adaln_qkv_kernel(const float* __restrict__ xin, const float* __restrict__ GB,
                                                         int gb_stride, int inst, const float* __restrict__ Wqkv,
                                                         const float* __restrict__ bqkv, float* __restrict__ qkv, int B) {
   __shared__ __attribute__((aligned(16))) float sW[192 * LDW64];
   __shared__ __attribute__((aligned(16))) float sT[4 * 32 * 32];  // per-wave output transpose tile: [token][8 chunks of 4 channels], chunk ^ (token & 7)
   __shared__ float sB[192];
+  __shared__ float sSc[2];
   const int tid = threadIdx.x;
-  stage_weight<64>(sW, Wqkv, 192, tid, 256);
+  if constexpr (F16) {  // Wqkv = the image
+    for (int i = tid; i < 192 * LDW64 / 4; i += 256) reinterpret_cast<f32x4*>(sW)[i] = reinterpret_cast<const f32x4*>(Wqkv)[i];
+    if (tid < 2) sSc[tid] = Wqkv[192 * LDW64 + tid];
+  } else {
+    stage_weight<64>(sW, Wqkv, 192, tid, 256);
+  }
   if (tid < 192) sB[tid] = bqkv[tid];
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
@@ -869,11 +880,35 @@ __global__ __launch_bounds__(256) void adaln_qkv_kernel(const float* __restrict_
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       f32x16 acc[3];
+      if constexpr (F16) {
+        const float down = sSc[1];
+        tl_f16x8 ahi[4], alo[4];
 #pragma unroll
-      for (int nt = 0; nt < 3; ++nt)
+        for (int s = 0; s < 4; ++s) split_slots8(a + 8 * s, ahi[s], alo[s]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] = sB[(3 * half + nt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb];
-      tl_gemm<8, 3, LDW64>(sW + 3 * half * 32 * LDW64, a, acc, n0, hb);
+        for (int nt = 0; nt < 3; ++nt) {
+          f32x16 m, c;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) m[r] = c[r] = 0.f;
+          const float* w = sW + ((3 * half + nt) * 32 + n0) * LDW64 + hb * 8;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const tl_f16x8 whi = *reinterpret_cast<const tl_f16x8*>(w + s * 16), wlo = *reinterpret_cast<const tl_f16x8*>(w + s * 16 + 4);
+            m = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, ahi[s], m, 0, 0, 0);
+            m = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, ahi[s], m, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, alo[s], c, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            acc[nt][r] = fmaf(fmaf(c[r], 0.00048828125f, m[r]), down, sB[(3 * half + nt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb]);
+        }
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[nt][r] = sB[(3 * half + nt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb];
+        tl_gemm<8, 3, LDW64>(sW + 3 * half * 32 * LDW64, a, acc, n0, hb);
+      }
 #pragma unroll
       for (int nt = 0; nt < 3; ++nt) {
 #pragma unroll
@@ -1681,8 +1716,31 @@ extern "C" int pmce_vertex_ca_mlp_f32(const float* xq, const float* vt, const fl
 extern "C" int pmce_adaln_qkv_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* Wqkv,
                                   const float* bqkv, float* qkv, int B, hipStream_t stream) {
   PMCE_REQUIRE(xin && GB && Wqkv && bqkv && qkv && B > 0, "adaln_qkv: null pointer");
-  hipLaunchKernelGGL(adaln_qkv_kernel, dim3(tl_grid(B, 2)), dim3(256), 0, stream, xin, GB, gb_stride, inst, Wqkv, bqkv, qkv, B);
+  hipLaunchKernelGGL(adaln_qkv_kernel<false>, dim3(tl_grid(B, 2)), dim3(256), 0, stream, xin, GB, gb_stride, inst, Wqkv, bqkv, qkv, B);
   return pmce_check_launch("adaln_qkv");
+}
+// The same product in the three-product f16 form (fp32 in, fp32 out): qkv_img = pmce_qkv_pack_f16(Wqkv), made once per weight.
+__global__ __launch_bounds__(256) void qkv_pack_kernel(const float* __restrict__ W, float* __restrict__ img) {
+  __shared__ float red[16];
+  float up, down;
+  weight_scale(W, 192 * 64, red, threadIdx.x, 256, up, down);
+  stage_weight_split<64>(img, W, 192, up, threadIdx.x, 256);
+  if (threadIdx.x == 0) {
+    img[192 * LDW64] = up;
+    img[192 * LDW64 + 1] = down;
+  }
+}
+extern "C" int pmce_qkv_image_floats(void) { return QKV_IMG_FLOATS; }
+extern "C" int pmce_qkv_pack_f16(const float* Wqkv, float* img, hipStream_t stream) {
+  PMCE_REQUIRE(Wqkv && img && (reinterpret_cast<uintptr_t>(img) & 15) == 0, "qkv_pack: null or unaligned pointer");
+  hipLaunchKernelGGL(qkv_pack_kernel, dim3(1), dim3(256), 0, stream, Wqkv, img);
+  return pmce_check_launch("qkv_pack_f16");
+}
+extern "C" int pmce_adaln_qkv_split_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* qkv_img,
+                                        const float* bqkv, float* qkv, int B, hipStream_t stream) {
+  PMCE_REQUIRE(xin && GB && qkv_img && bqkv && qkv && B > 0, "adaln_qkv_split: null pointer");
+  hipLaunchKernelGGL(adaln_qkv_kernel<true>, dim3(tl_grid(B, 2)), dim3(256), 0, stream, xin, GB, gb_stride, inst, qkv_img, bqkv, qkv, B);
+  return pmce_check_launch("adaln_qkv_split");
 }
 
 extern "C" int pmce_vertex_sa_ex_f32(const float* xin, const float* qkv, const float* Wp, const float* bp, float* yout, int B,

@@ -115,6 +115,7 @@ struct pmce_model {
   bool split_overlap = true;
   bool ffn_f16 = true;
   const float* ffn_img[3][2] = {};     // per vertex block: the LDS images of the two FFNs' f16 form (vca, vsa), in the split arena
+  const float* qkv_img[3] = {};        // per vertex block: the self-attention qkv weight's f16 form (adaln_qkv)
   bool attn_f16 = true;  // the lifter's attention on the f16 matrix pipe in split mode (PMCE_ATTN_F16=0: the vector-pipe kernel, an A/B knob)
   bool split_now = false;  // decision for the call in progress (set by check_ws, the first thing every entry point does)
   // Sticky "a product of this model produced a non-finite value" word: 4 bytes of pinned host memory the device can write
@@ -610,8 +611,10 @@ int vertex_block(pmce_model* m, int k, const float* vt_cur, float* vt_next, int 
     RUN(P_ADALN_MLP, pmce_adaln_mlp_pk_f32(w.F1, w.GB, gbs, ib + 3, v.vca_fc1_w, v.vca_fc1_b, v.vca_fc2_w, v.vca_fc2_b, w.F2, nullptr,
                                            nullptr, nullptr, nullptr, B, pkf(m), m->ffn_img[k - 1][0], stream));
   }
-  RUN(P_ADALN_QKV, pmce_adaln_qkv_f32(w.F2, w.GB, gbs, ib + 4, v.vsa_qkv_w, v.vsa_qkv_b, w.QKV, B,
-                                      stream));
+  if (pkf(m) && m->qkv_img[k - 1])
+    RUN(P_ADALN_QKV, pmce_adaln_qkv_split_f32(w.F2, w.GB, gbs, ib + 4, m->qkv_img[k - 1], v.vsa_qkv_b, w.QKV, B, stream));
+  else
+    RUN(P_ADALN_QKV, pmce_adaln_qkv_f32(w.F2, w.GB, gbs, ib + 4, v.vsa_qkv_w, v.vsa_qkv_b, w.QKV, B, stream));
   RUN(P_VERTEX_SA, pmce_vertex_sa_ex_f32(w.F2, w.QKV, v.vsa_proj_w, v.vsa_proj_b, w.F1, B, pkf(m), stream));
   RUN(P_ADALN_MLP, pmce_adaln_mlp_pk_f32(w.F1, w.GB, gbs, ib + 5, v.vsa_fc1_w, v.vsa_fc1_b,
                                          v.vsa_fc2_w, v.vsa_fc2_b, nullptr,
@@ -715,6 +718,7 @@ namespace {
 struct SplitItem { const float* w; int n, k; SplitW* dst; };
 size_t split_item_floats(int n, int k) { return ((((size_t)n + 63) & ~(size_t)63) * k) + (((size_t)n + 63) & ~(size_t)63); }  // planes (rows padded to the 64-row blocks of the blocked layout) + 2^-s per row
 size_t ffn_img_floats() { return ((size_t)pmce_ffn_image_floats() + 63) & ~(size_t)63; }  // one FFN's LDS image (coevo.hip), 256-byte granules
+size_t qkv_img_floats() { return ((size_t)pmce_qkv_image_floats() + 63) & ~(size_t)63; }
 // bytes of the planes of a model with / without lifter and decoder
 size_t split_bytes_for(int C, int depth, bool lifter, bool decoder) {
   size_t f = 0;
@@ -724,7 +728,7 @@ size_t split_bytes_for(int C, int depth, bool lifter, bool decoder) {
   }
   if (decoder)
     f += split_item_floats(6 * GH, F) + split_item_floats(6 * GH, 2 * GH) + 2 * split_item_floats(6 * GH, GH) +
-         split_item_floats(N_ADA * 128, 2 * GH) + split_item_floats(NVF * 3, FINAL_K) + 6 * ffn_img_floats();
+         split_item_floats(N_ADA * 128, 2 * GH) + split_item_floats(NVF * 3, FINAL_K) + 6 * ffn_img_floats() + 3 * qkv_img_floats();
   return f * sizeof(float);
 }
 int build_split_weights(pmce_model* m, hipStream_t stream) {
@@ -738,6 +742,7 @@ int build_split_weights(pmce_model* m, hipStream_t stream) {
     for (auto& b : kind) b = LifterBlockSplit{};
   m->s_ie = m->s_wih0 = m->s_wih1 = m->s_whh0 = m->s_whh1 = m->s_ada = m->s_final = SplitW{};
   for (auto& b : m->ffn_img) b[0] = b[1] = nullptr;
+  for (auto& q : m->qkv_img) q = nullptr;
   if (!m->split_gemm) return PMCE_OK;
   const int C = m->C;
   std::vector<SplitItem> items;
@@ -765,7 +770,7 @@ int build_split_weights(pmce_model* m, hipStream_t stream) {
   size_t floats = 0;
   for (auto& it : items) floats += split_item_floats(it.n, it.k);
   const bool ffn_images = m->has_decoder && m->ffn_f16 && pmce_env_int("PMCE_FFN_IMAGE", 1) != 0;
-  if (m->has_decoder) floats += 6 * ffn_img_floats();  // (reserved whether or not they are made: pmce_model_split_bytes does not depend on env knobs)
+  if (m->has_decoder) floats += 6 * ffn_img_floats() + 3 * qkv_img_floats();  // (reserved whether or not they are made: pmce_model_split_bytes does not depend on env knobs)
   if (m->caller_arena) {  // the caller's memory (its allocator, its lifetime): pmce_model_set_split_arena
     if (m->caller_arena_bytes < floats * sizeof(float)) {
       pmce_set_error("model_finalize: the split arena holds %zu bytes, the planes need %zu (pmce_model_split_bytes)", m->caller_arena_bytes,
@@ -805,6 +810,11 @@ int build_split_weights(pmce_model* m, hipStream_t stream) {
       PMCE_TRY(pmce_ffn_pack_f16(v.vsa_fc1_w, v.vsa_fc2_w, p, stream));
       m->ffn_img[k][1] = p;
       p += ffn_img_floats();
+      if (pmce_env_int("PMCE_QKV_F16", 1) != 0) {
+        PMCE_TRY(pmce_qkv_pack_f16(v.vsa_qkv_w, p, stream));
+        m->qkv_img[k] = p;
+      }
+      p += qkv_img_floats();
     }
   if (hipStreamSynchronize(stream) != hipSuccess) {
     pmce_set_error("model_finalize: packing the split weights failed");
@@ -972,7 +982,7 @@ int pmce_model_share_split_weights(pmce_model* dst, const pmce_model* src) {
     for (int i = 0; i < 8; ++i) dst->sblk[k][i] = src->sblk[k][i];
   dst->s_ie = src->s_ie; dst->s_wih0 = src->s_wih0; dst->s_wih1 = src->s_wih1; dst->s_whh0 = src->s_whh0; dst->s_whh1 = src->s_whh1;
   dst->s_ada = src->s_ada; dst->s_final = src->s_final;
-  for (int k = 0; k < 3; ++k) dst->ffn_img[k][0] = src->ffn_img[k][0], dst->ffn_img[k][1] = src->ffn_img[k][1];
+  for (int k = 0; k < 3; ++k) dst->ffn_img[k][0] = src->ffn_img[k][0], dst->ffn_img[k][1] = src->ffn_img[k][1], dst->qkv_img[k] = src->qkv_img[k];
   dst->split_gemm = true;
   dst->split_adopted = true;
   dst->oflow = src->oflow;  // lanes of one model report to one word

@@ -263,8 +263,15 @@ def vertex_self_attn(x, g, sd, p, split_f16=False):
     B = x.shape[0]
     GB = adaln_params(g, sd, [p + ".norm1"])
     qkv = torch.empty(B, 431, 192, device=x.device)
-    _lib.check(lib.pmce_adaln_qkv_f32(P(x), P(GB), GB.shape[1], 0, P(_c(sd[p + ".attn.qkv.weight"])),
-                                      P(_c(sd[p + ".attn.qkv.bias"])), P(qkv), B, _st()), "adaln_qkv")
+    Wqkv = _c(sd[p + ".attn.qkv.weight"])
+    if split_f16:   # as a model in split_f16 mode: the qkv product in the three-product f16 form too, from the weight's pre-made image
+        img = torch.empty(lib.pmce_qkv_image_floats(), device=x.device)
+        _lib.check(lib.pmce_qkv_pack_f16(P(Wqkv), P(img), _st()), "qkv_pack_f16")
+        _lib.check(lib.pmce_adaln_qkv_split_f32(P(x), P(GB), GB.shape[1], 0, P(img), P(_c(sd[p + ".attn.qkv.bias"])), P(qkv), B, _st()),
+                   "adaln_qkv_split")
+    else:
+        _lib.check(lib.pmce_adaln_qkv_f32(P(x), P(GB), GB.shape[1], 0, P(Wqkv),
+                                          P(_c(sd[p + ".attn.qkv.bias"])), P(qkv), B, _st()), "adaln_qkv")
     y = torch.empty_like(x)
     _lib.check(lib.pmce_vertex_sa_ex_f32(P(x), P(qkv), P(_c(sd[p + ".attn.proj.weight"])), P(_c(sd[p + ".attn.proj.bias"])),
                                          P(y), B, int(split_f16), _st()), "vertex_sa")
