@@ -833,8 +833,9 @@ __global__ __launch_bounds__(448) void vertex_ca_mlp_kernel(const float* __restr
 // made once (pmce_qkv_pack_f16: stage_weight_split's layout, then {2^s, 2^-s}); 72 matrix instructions of 32 cycles per 32-token
 // tile instead of 192 of 64.
 #define QKV_IMG_FLOATS (192 * LDW64 + 32)
+// (the f16 form fits 2 workgroups per CU - 234 registers; the fp32 form's 192 64-cycle instructions per tile are scheduled over 497)
 template <bool F16>
-__global__ __launch_bounds__(256) void adaln_qkv_kernel(const float* __restrict__ xin, const float* __restrict__ GB,
+__global__ __launch_bounds__(256, F16 ? 2 : 1) void adaln_qkv_kernel(const float* __restrict__ xin, const float* __restrict__ GB,
                                                         int gb_stride, int inst, const float* __restrict__ Wqkv,
                                                         const float* __restrict__ bqkv, float* __restrict__ qkv, int B) {
   __shared__ __attribute__((aligned(16))) float sW[192 * LDW64];
