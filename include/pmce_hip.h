@@ -233,6 +233,15 @@ int pmce_gemm_pack_split_f16_blk(const float* W, int N, int K, int ldw, float* W
 int pmce_gemm_nt_split_f16_blk(const float* A, const float* rscale, const float* Wblk, const float* wscale, const float* bias,
                                const float* R, float* C, int M, int N, int K, long long lda, long long ldc, int act, int a_packed,
                                int c_packed, int c_div, long long c_lo, long long c_hi, pmce_stream_t stream);
+/* A product with N = 256 and a residual, followed by the LayerNorm chain of its consumer, in ONE launch (round 4; proj -> norm2 and
+ * fc2 -> norm_s / norm_t -> next norm1 of a C = 256 lifter block, reference PoseEstimation.py:26-28,84-85,91-92,101-106): with
+ * x = Ap W^T + bias + R,   y1 = ln1_w ? LN(x; ln1_w, ln1_b, ln1_eps) : x,   out1 = y1 (fp32 [M,256]; may alias R; may be NULL),
+ * out2 = LN(y1; ln2_w, ln2_b, ln2_eps) written pre-split (the next product's packed A; may be NULL).  Ap pre-split [M,K]; Wp from
+ * pmce_gemm_pack_split_f16 (w_blocked = 0) or _blk (1).  The same as pmce_gemm_nt_split_f16_blk + pmce_ln_chain_ex_f32 up to the
+ * summation order of the row statistics (two-pass fp32 in both). */
+int pmce_gemm_nt_split_f16_ln(const float* Ap, const float* Wp, int w_blocked, const float* wscale, const float* bias, const float* R,
+                              int M, int K, const float* ln1_w, const float* ln1_b, float ln1_eps, float* out1, const float* ln2_w,
+                              const float* ln2_b, float ln2_eps, float* out2, pmce_stream_t stream);
 /* a_packed != 0: A is not fp32 but already split, [M][K/16][hi 16 f16 | lo*2^11 16 f16] (the layout the lifter's own
  * producers write; pmce_split_rows_f16 makes it from fp32 rows). */
 int pmce_split_rows_f16(const float* A, long long M, int K, long long lda, float* Ap, pmce_stream_t stream);

@@ -64,6 +64,7 @@ PROTOTYPES = {
     "pmce_gemm_nt_split_f16_rs": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _l, _i, _l, _l, _s],
     "pmce_gemm_pack_split_f16_blk": [_f, _i, _i, _i, _f, _f, _s],
     "pmce_gemm_nt_split_f16_blk": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _l, _l, _i, _i, _i, _i, _l, _l, _s],
+    "pmce_gemm_nt_split_f16_ln": [_f, _f, _i, _f, _f, _f, _i, _i, _f, _f, _fl, _f, _f, _f, _fl, _f, _s],
     "pmce_gemm_nt_split_f16_ex": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _l, _l, _i, _i, _i, _s],
     "pmce_ln_chain_ex_f32": [_f, _l, _i, _f, _f, _fl, _f, _i, _i, _f, _f, _f, _fl, _f, _i, _s],
     "pmce_seq_attention_ex_f32": [_f, _f, _i, _i, _i, _i, _l, _l, _l, _i, _s],

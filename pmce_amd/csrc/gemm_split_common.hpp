@@ -24,6 +24,12 @@ struct SplitParams {
   int skew;  // start delay of the second workgroup per CU, in units of 4096 cycles
   unsigned long long* clk;  // optional probe {shader clocks, 100 MHz ticks}: each workgroup's first wave adds its kernel residence (null = off)
   unsigned* oflow;  // device-visible word set to 1 when a result is not finite (an activation beyond f16's 65504, or fp32 overflow); may be null
+  // LayerNorm epilogue (LNEP instantiation; N == 256 == the tile's width, so a workgroup owns whole rows): with x = the product + bias + R,
+  //   y1 = ln1_w ? LN(x; ln1_w, ln1_b, ln1_eps) : x ;  out1 = y1 (fp32, if out1) ;  out2 = LN(y1; ln2_w, ln2_b, ln2_eps) pre-split (if out2)
+  // - what pmce_ln_chain does to the product's result in a launch of its own.  C is not written.
+  const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+  float ln1_eps, ln2_eps;
+  float *out1, *out2;
 };
 
 // LDS-DMA: 64 lanes x 16 B from per-lane buffer offsets into LDS at M0 + lane*16 (see gemm_f32.hip)

@@ -49,9 +49,26 @@ struct SplitCfg {
 // stage, fetched together and multiplied behind ONE wait and ONE barrier.  A launch of a few hundred small tiles is bound by a
 // workgroup's serial chain per k-tile (wait -> barrier -> DMA issue -> fragment reads -> 6 dependent matrix instructions per wave: 0.43 us
 // whatever the grid, profiles/r04_c_*); two k-tiles per trip halve the trips.  Same arithmetic and k order: bit-identical results.
-template <int TM, int TN, int ACT, bool RES, bool APACK, bool OPACK = false, bool RS = false, int KSUB = 1>
+// LNEP (round 4; the N = 256 products of a C = 256 lifter block, proj and fc2): the tile is 64 x 256 - whole rows - and the epilogue is
+// the LayerNorm chain that followed the product as a launch of its own (lifter.hip ln_chain: norm2 after proj; the shared post-norm
+// and the next block's norm1 after fc2): the residual stream and the pre-split LN output leave the accumulators directly, the fp32
+// row is never re-read.  Row statistics: two-pass (mean, then centred squares) like ln_chain; a row's 256 columns sit in the two
+// column waves of its row half - 32 lanes x 4 blocks each - so a statistic is 3 in-lane adds, a 32-lane all-reduce (4 DPP rotations
+// inside the rows of 16 + one swizzle across them; every lane ends with the same bits) and one exchange of 16 floats per lane half
+// with the partner wave through LDS.
+__device__ __forceinline__ float half32_allsum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401f));                     // lane ^ 16
+  return v;
+}
+
+template <int TM, int TN, int ACT, bool RES, bool APACK, bool OPACK = false, bool RS = false, int KSUB = 1, bool LNEP = false>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
   static_assert(!RS || (APACK && !OPACK && !RES), "a row-scaled A is a packed A; no packed result, no residual");
+  static_assert(!LNEP || (TM == 1 && TN == 4 && ACT == 0 && RES && !OPACK && !RS && KSUB == 1), "the LayerNorm epilogue: 64 x 256 tile, residual form");
   using Cfg = SplitCfg<TM, TN>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, WM = 32 * TM, WN = 32 * TN;
   constexpr int SUBF = Cfg::STAGE_FLOATS;                         // one 16-wide k-tile of the stage
@@ -242,6 +259,123 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
       // ---- epilogue of the finished tile, straight from the accumulators ----
       kt = 0;
       bool bad = false;  // this lane produced a non-finite value (an operand beyond the f16 range, or fp32 overflow)
+      if constexpr (LNEP) {
+        // rows of this lane: m_base + 32 wm + 4 hb + (r & 3) + 8 (r >> 2); columns 128 wn + 32 j + n0 (n_base = 0, N = ldc = 256)
+        float* sX = lds + NS * SF + 1024;  // exchange slots [pass][wm][wn][hb][16]
+        const int rows_left = min(p.M - m_base, BM);
+        const unsigned row_bytes = 256u * 4u;
+        const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R + (size_t)m_base * 256), 0,
+                                                                                 (unsigned)rows_left * row_bytes, 0x00020000);
+        unsigned lane_off = (unsigned)(wm * 32 + 4 * hb) * row_bytes + (unsigned)(wn * 128 + n0) * 4u;
+        asm volatile("" : "+v"(lane_off));  // (keeps the 16 + 64 offsets derived from it out of the k-loop's registers: made here, per tile)
+        auto voff = [&](int r) __attribute__((always_inline)) { return lane_off + (unsigned)((r & 3) + 8 * (r >> 2)) * row_bytes; };
+        // x = product * 2^-s + R (the bias came in through the accumulators); rows past M read zeros and are never stored
+        {  // (the residual of block j + 1 is requested before block j is used: two 16-register sets, as in the plain epilogue)
+          float rv[2][16];
+          auto res_load = [&](int j, float (&dst)[16]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_r, voff(r), j * 128, 0));
+          };
+          res_load(0, rv[0]);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            if (j + 1 < TN) res_load(j + 1, rv[(j + 1) & 1]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float v = acc[0][j][r] * w_down[j] + rv[j & 1][r];
+              bad = bad || nonfinite(v);
+              acc[0][j][r] = v;
+            }
+          }
+        }
+        int pass = 0;
+        // sum over the row of f(element) for this lane's 16 rows: both column waves end with the same 16 totals
+        auto row_totals = [&](float (&t)[16]) __attribute__((always_inline)) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t[r] = half32_allsum(t[r]);
+          float* slot = sX + (((pass * 2 + wm) * 2 + wn) * 2 + hb) * 16;
+          if (n0 == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(slot + 4 * q) = f32x4{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+          }
+          __syncthreads();
+          const float* other = sX + (((pass * 2 + wm) * 2 + (wn ^ 1)) * 2 + hb) * 16;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(other + 4 * q);
+            t[4 * q] += o.x; t[4 * q + 1] += o.y; t[4 * q + 2] += o.z; t[4 * q + 3] += o.w;
+          }
+          ++pass;
+        };
+        // acc <- LN(acc; w, b, eps) over the 256 columns of each row
+        auto layer_norm = [&](const float* __restrict__ w, const float* __restrict__ b, float eps) __attribute__((always_inline)) {
+          float t[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t[r] = (acc[0][0][r] + acc[0][1][r]) + (acc[0][2][r] + acc[0][3][r]);
+          row_totals(t);
+          float mean[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mean[r] = t[r] * (1.0f / 256.0f);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float q2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const float d = acc[0][j][r] - mean[r];
+              acc[0][j][r] = d;
+              q2 = fmaf(d, d, q2);
+            }
+            t[r] = q2;
+          }
+          row_totals(t);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t[r] = 1.0f / sqrtf(t[r] * (1.0f / 256.0f) + eps);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float wv = w[wn * 128 + j * 32 + n0], bv = b[wn * 128 + j * 32 + n0];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][j][r] = fmaf(acc[0][j][r] * t[r], wv, bv);
+          }
+        };
+        if (p.ln1_w) layer_norm(p.ln1_w, p.ln1_b, p.ln1_eps);
+        if (p.out1) {
+          const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(p.out1 + (size_t)m_base * 256, 0, (unsigned)rows_left * row_bytes, 0x00020000);
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float y = acc[0][j][r];  // (a bit_cast applied to the vector component itself reads component 0 every time)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rsrc_o, voff(r), j * 128, 2);
+            }
+        }
+        if (p.out2) {
+          layer_norm(p.ln2_w, p.ln2_b, p.ln2_eps);
+          // pre-split [row][K/16][16 hi | 16 lo*2^11] f16 in the bytes of the fp32 row, as the OPACK epilogue writes it
+          const bool odd = lane & 1;
+          const int colf = (n0 >> 4) * 32 + (odd ? 16 + ((n0 - 1) & 15) : (n0 & 15));
+          unsigned lane_pk = (unsigned)(wm * 32 + 4 * hb) * row_bytes + (unsigned)(wn * 128) * 4u + (unsigned)colf * 2u;
+          asm volatile("" : "+v"(lane_pk));
+          const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(p.out2 + (size_t)m_base * 256, 0, (unsigned)rows_left * row_bytes, 0x00020000);
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float x = pinned(acc[0][j][r]);
+              const _Float16 h = (_Float16)x;
+              bad = bad || nonfinite((float)h);
+              const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
+              const unsigned w = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+              const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);  // lane ^ 1
+              const unsigned outw = odd ? ((nbr >> 16) | (w & 0xffff0000u)) : ((w & 0xffffu) | (nbr << 16));
+              const unsigned vo = lane_pk + (unsigned)((r & 3) + 8 * (r >> 2)) * row_bytes + (unsigned)(j * 32) * 4u;
+              __builtin_amdgcn_raw_buffer_store_b32(outw, rsrc_x, vo, 0, 2);
+            }
+        }
+        report_nonfinite(p.oflow, bad);
+        li += gx;
+        if (li < chunk_len) tile_coords(chunk_start + li, m_base, n_base);
+        continue;
+      }
       if constexpr (RS) {
         // Row-scaled A: C[m][n] = acc * 2^-s(n) * 2^e(m) + bias[n].  2^e of the tile's rows landed with the tile's first k-tile
         // (c_par has moved on to the next tile's parity since).  Row-major over the accumulators - one row scale at a time serves
@@ -422,14 +556,15 @@ extern "C" int pmce_gemm_split_set_tuning(int tile) {
   return PMCE_OK;
 }
 
-template <int TM, int TN, int ACT, bool RES, bool APACK, bool OPACK = false, bool RS = false, int KSUB = 1>
+template <int TM, int TN, int ACT, bool RES, bool APACK, bool OPACK = false, bool RS = false, int KSUB = 1, bool LNEP = false>
 static int launch_one(const SplitParams& p, int grid, hipStream_t stream) {
   using Cfg = SplitCfg<TM, TN>;
   static std::atomic<unsigned long long> done{0};
-  constexpr int LDS = (KSUB == 1 ? Cfg::LDS_BYTES : 3 * KSUB * Cfg::STAGE_FLOATS * 4 + 4096) + (RS ? 2048 : 0);  // + two slices of BM row scales
-  PMCE_TRY(pmce_opt_in_lds(reinterpret_cast<const void*>(&gemm_split_kernel<TM, TN, ACT, RES, APACK, OPACK, RS, KSUB>), LDS, done,
+  // + two slices of BM row scales (RS) / the LayerNorm epilogue's exchange slots (LNEP)
+  constexpr int LDS = (KSUB == 1 ? Cfg::LDS_BYTES : 3 * KSUB * Cfg::STAGE_FLOATS * 4 + 4096) + (RS || LNEP ? 2048 : 0);
+  PMCE_TRY(pmce_opt_in_lds(reinterpret_cast<const void*>(&gemm_split_kernel<TM, TN, ACT, RES, APACK, OPACK, RS, KSUB, LNEP>), LDS, done,
                            "gemm_split_f16"));
-  hipLaunchKernelGGL((gemm_split_kernel<TM, TN, ACT, RES, APACK, OPACK, RS, KSUB>), dim3(grid), dim3(256), LDS, stream, p);
+  hipLaunchKernelGGL((gemm_split_kernel<TM, TN, ACT, RES, APACK, OPACK, RS, KSUB, LNEP>), dim3(grid), dim3(256), LDS, stream, p);
   return PMCE_OK;
 }
 // the 64x128 tile with two k-tiles per stage (small grids): the operand / epilogue combinations the model's products use
@@ -532,6 +667,7 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
   p.A = A; p.W = Wp; p.wscale = wscale; p.bias = bias; p.R = R; p.C = C; p.rscale = rscale; p.wblk = w_blocked;
   p.M = M; p.N = N; p.K = K; p.lda = (unsigned)lda; p.ldc = (unsigned)ldc;
   p.c_div = c_div; p.c_lo = c_lo; p.c_hi = c_hi;
+  p.ln1_w = p.ln1_b = p.ln2_w = p.ln2_b = nullptr; p.ln1_eps = p.ln2_eps = 0.f; p.out1 = p.out2 = nullptr;
   p.oflow = pmce_overflow_sink();
   p.clk = pmce_clock_sink();  // (thread-local: set while an entry point of a model with a clock probe runs)
   {  // half a tile of matrix time: nk iterations x 3*TM*TN instructions x 32 cycles (TM*TN = 8 or 4), / 2, in 4096-cycle units
@@ -588,6 +724,42 @@ extern "C" int pmce_gemm_nt_split_f16_rs(const float* Ap, const float* rscale, c
   PMCE_REQUIRE(rscale, "gemm_split_rs: null rscale");
   PMCE_REQUIRE(c_div >= 0 && (c_div == 0 || ldc == N), "gemm_split_rs: a row map needs ldc == N");
   return gemm_split_any(Ap, Wp, wscale, bias, nullptr, C, M, N, K, K, ldc, 0, 1, 0, c_div, c_lo, c_hi, stream, rscale);
+}
+
+// A product with N = 256 and a residual whose result feeds a LayerNorm chain (the proj and fc2 products of a C = 256 lifter block,
+// reference PoseEstimation.py:26-28,84-85,91-92,101-106): with x = Ap W^T + bias + R,
+//   y1 = ln1_w ? LN(x; ln1_w, ln1_b, ln1_eps) : x ;   out1 = y1 (fp32 [M,256], may alias R; may be null)
+//   out2 = LN(y1; ln2_w, ln2_b, ln2_eps) written PRE-SPLIT (the next product's A; may be null)
+// - pmce_gemm_nt_split_f16_blk followed by pmce_ln_chain_ex_f32(out2_split = 1) in one launch (64 x 256 tiles: a workgroup owns whole
+// rows).  Ap pre-split [M,K]; W packed (w_blocked: the blocked layout); statistics two-pass in fp32 like pmce_ln_chain (a different
+// summation order: the results agree to the last bits, not bit for bit).
+extern "C" int pmce_gemm_nt_split_f16_ln(const float* Ap, const float* Wp, int w_blocked, const float* wscale, const float* bias,
+                                         const float* R, int M, int K, const float* ln1_w, const float* ln1_b, float ln1_eps, float* out1,
+                                         const float* ln2_w, const float* ln2_b, float ln2_eps, float* out2, hipStream_t stream) {
+  PMCE_REQUIRE(Ap && Wp && wscale && R && (out1 || out2), "gemm_split_ln: null pointer");
+  PMCE_REQUIRE(M > 0 && K >= 32 && K % 16 == 0, "gemm_split_ln: need M>0, K>=32 and K%%16==0 (got M=%d K=%d)", M, K);
+  PMCE_REQUIRE((!ln1_w) == (!ln1_b) && (!out2 || (ln2_w && ln2_b)), "gemm_split_ln: a LayerNorm needs weight and bias");
+  PMCE_REQUIRE((long long)M * K * 4 < (1ll << 32) && (long long)M * 256 * 4 < (1ll << 32), "gemm_split_ln: an operand spans 4 GiB or more (split the batch)");
+  SplitParams p;
+  p.A = Ap; p.W = Wp; p.wscale = wscale; p.bias = bias; p.R = R; p.C = nullptr; p.rscale = nullptr; p.wblk = w_blocked;
+  p.M = M; p.N = 256; p.K = K; p.lda = (unsigned)K; p.ldc = 256u;
+  p.c_div = 0; p.c_lo = 0; p.c_hi = 0;
+  p.oflow = pmce_overflow_sink();
+  p.clk = pmce_clock_sink();
+  {
+    const int knob = g_split_skew.load(std::memory_order_relaxed);
+    p.skew = knob >= 0 ? knob : (K / 16) * 12 * 32 / 4096 + 1;
+  }
+  p.ln1_w = ln1_w; p.ln1_b = ln1_b; p.ln1_eps = ln1_eps; p.out1 = out1;
+  p.ln2_w = ln2_w; p.ln2_b = ln2_b; p.ln2_eps = ln2_eps; p.out2 = out2;
+  p.ntm = (M + 63) / 64;
+  p.ntn = 1;
+  int g = p.ntm > 512 ? 512 : p.ntm;
+  g = (g + 7) & ~7;
+  // (two k-tiles per stage on small grids, as the plain 64 x 128 tile has them, were measured and change nothing here: at M = 272 the
+  // launch is its prologue and the epilogue's dependent chain, not the 16 trips of its k-loop)
+  PMCE_TRY((launch_one<1, 4, 0, true, true, false, false, 1, true>(p, g, stream)));
+  return pmce_check_launch("gemm_nt_split_f16_ln");
 }
 
 // ---- operand packing ------------------------------------------------------------------------------------------------------

@@ -114,6 +114,7 @@ struct pmce_model {
   // other.  PMCE_SPLIT_OVERLAP=0 at create restores the strictly serial schedule of the split mode (diagnostic).
   bool split_overlap = true;
   bool ffn_f16 = true;
+  bool ln_fused = true;                // C = 256, split mode: LayerNorm in the epilogue of the N = 256 products (PMCE_LN_FUSED=0: launches of their own)
   const float* ffn_img[3][2] = {};     // per vertex block: the LDS images of the two FFNs' f16 form (vca, vsa), in the split arena
   const float* qkv_img[3] = {};        // per vertex block: the self-attention qkv weight's f16 form (adaln_qkv)
   bool attn_f16 = true;  // the lifter's attention on the f16 matrix pipe in split mode (PMCE_ATTN_F16=0: the vector-pipe kernel, an A/B knob)
@@ -375,8 +376,30 @@ inline int pkf(const pmce_model* m) { return m->split_now && m->ffn_f16 ? 1 : 0;
 // Everything up to and including SpatialBlocks[0] is PER FRAME (its attention runs over the J joints of one frame,
 // PoseEstimation.py:78-85), so it is written over `nframes` frames: B*16 for independent clips, L for a streamed sequence.
 
-// attention + MLP of one block (pre-norm input in w.XN, residual stream in w.X); kind 0 spatial, 1 temporal
-int lifter_block_body(pmce_model* m, int kind, int i, long long M, int nframes, int B, LifterWs& w, hipStream_t stream) {
+// the LayerNorm chain that follows a block (lifter_post_norm): norm_s / norm_t, then the next block's norm1
+struct PostNorm { const float *w1, *b1, *w2, *b2; };
+PostNorm post_norm_of(const pmce_model* m, int kind, int i) {
+  PostNorm pn;
+  pn.w1 = kind == 0 ? m->w.ns_w : m->w.nt_w;
+  pn.b1 = kind == 0 ? m->w.ns_b : m->w.nt_b;
+  pn.w2 = pn.b2 = nullptr;
+  if (kind == 0) {
+    pn.w2 = m->w.blk[1][i].norm1_w;
+    pn.b2 = m->w.blk[1][i].norm1_b;
+  } else if (i + 1 < m->depth) {
+    pn.w2 = m->w.blk[0][i + 1].norm1_w;
+    pn.b2 = m->w.blk[0][i + 1].norm1_b;
+  }
+  return pn;
+}
+// C = 256 in split mode: the N = 256 products own whole rows (64 x 256 tiles), so the LayerNorm that follows them runs in their epilogue
+// (pmce_gemm_nt_split_f16_ln) instead of a launch of its own that re-reads the row.  (C = 512: a 512-wide tile does not fit)
+inline bool ln_in_product(const pmce_model* m) { return m->split_now && m->ln_fused && m->C == 256; }
+
+// attention + MLP of one block (pre-norm input in w.XN, residual stream in w.X); kind 0 spatial, 1 temporal.  post != nullptr: the
+// block's post-norm chain (without a position embedding) is part of this call - fused into fc2 where ln_in_product, a launch otherwise.
+int lifter_block_body(pmce_model* m, int kind, int i, long long M, int nframes, int B, LifterWs& w, hipStream_t stream,
+                      const PostNorm* post = nullptr) {
   const int J = m->J, C = m->C;
   const LifterBlockW& bw = m->w.blk[kind][i];
   const LifterBlockSplit& sw = m->sblk[kind][i];
@@ -392,15 +415,29 @@ int lifter_block_body(pmce_model* m, int kind, int i, long long M, int nframes, 
     if (mfma_attn) RUN(P_SEQ_ATTN, pmce_seq_attention_split_f16(w.QKV, w.AO, B * J, T, C, J, 1, (long long)T * J, J, stream));
     else RUN(P_SEQ_ATTN, pmce_seq_attention_ex_f32(w.QKV, w.AO, B * J, T, C, J, 1, (long long)T * J, J, pk(m), stream));
   }
-  RUN(P_GEMM_LIFTER, lgemm(m, w.AO, bw.proj_w, sw.proj, bw.proj_b, w.X, w.X, (int)M, C,
-                          C, C, C, 0, stream, pk(m)));
-  RUN(P_LN, pmce_ln_chain_ex_f32(w.X, M, C, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, bw.norm2_w,
-                                 bw.norm2_b, 1e-6f, w.XN, pk(m), stream));
+  const bool fuse = ln_in_product(m) && sw.proj.wp && sw.fc2.wp;
+  if (fuse) {  // x += proj(attn); XN = norm2(x)
+    RUN(P_GEMM_LIFTER, pmce_gemm_nt_split_f16_ln(w.AO, sw.proj.wp, m->wblk, sw.proj.scale, bw.proj_b, w.X, (int)M, C, nullptr, nullptr, 0.f,
+                                                 w.X, bw.norm2_w, bw.norm2_b, 1e-6f, w.XN, stream));
+  } else {
+    RUN(P_GEMM_LIFTER, lgemm(m, w.AO, bw.proj_w, sw.proj, bw.proj_b, w.X, w.X, (int)M, C,
+                            C, C, C, 0, stream, pk(m)));
+    RUN(P_LN, pmce_ln_chain_ex_f32(w.X, M, C, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, bw.norm2_w,
+                                   bw.norm2_b, 1e-6f, w.XN, pk(m), stream));
+  }
   float* Hid = w.QKV;
   RUN(P_GEMM_LIFTER, lgemm(m, w.XN, bw.fc1_w, sw.fc1, bw.fc1_b, nullptr, Hid, (int)M,
                           2 * C, C, C, 2 * C, 1, stream, pk(m), pk(m)));
+  if (fuse && post) {  // x = norm_s/t(x + fc2(h)); XN = next norm1(x)
+    RUN(P_GEMM_LIFTER, pmce_gemm_nt_split_f16_ln(Hid, sw.fc2.wp, m->wblk, sw.fc2.scale, bw.fc2_b, w.X, (int)M, 2 * C, post->w1, post->b1, 1e-6f,
+                                                 w.X, post->w2, post->b2, 1e-6f, post->w2 ? w.XN : nullptr, stream));
+    return PMCE_OK;
+  }
   RUN(P_GEMM_LIFTER, lgemm(m, Hid, bw.fc2_w, sw.fc2, bw.fc2_b, w.X, w.X, (int)M, C,
                           2 * C, 2 * C, C, 0, stream, pk(m)));
+  if (post)
+    RUN(P_LN, pmce_ln_chain_ex_f32(w.X, M, C, post->w1, post->b1, 1e-6f, nullptr, J, T, w.X, post->w2, post->b2, 1e-6f,
+                                   post->w2 ? w.XN : nullptr, pk(m), stream));
   return PMCE_OK;
 }
 
@@ -465,9 +502,9 @@ int lifter_rest(pmce_model* m, float* pose3d, int B, LifterWs& w, hipStream_t st
   const int J = m->J, C = m->C;
   const long long M = (long long)B * T * J;
   for (int i = 0; i < m->depth; ++i) {
-    for (int kind = (i == 0 ? 1 : 0); kind < 2; ++kind) {
-      PMCE_TRY(lifter_block_body(m, kind, i, M, B * T, B, w, stream));
-      PMCE_TRY(lifter_post_norm(m, kind, i, M, w, stream));
+    for (int kind = (i == 0 ? 1 : 0); kind < 2; ++kind) {  // (SpatialBlocks[0] - the one whose post-norm adds the position embedding - is lifter_frames')
+      const PostNorm pn = post_norm_of(m, kind, i);
+      PMCE_TRY(lifter_block_body(m, kind, i, M, B * T, B, w, stream, &pn));
     }
   }
   RUN(P_HEAD, pmce_lifter_head_f32(w.X, m->w.reg0_w, m->w.reg0_b,
@@ -856,6 +893,7 @@ int pmce_model_create(int num_joint, int embed_dim, int depth, pmce_model** out)
   m->split_gemm = pmce_env_int("PMCE_SPLIT_F16", 1) != 0;
   m->split_min_batch = pmce_env_int("PMCE_SPLIT_MIN_BATCH", 1);
   m->ffn_f16 = pmce_env_int("PMCE_FFN_F16", 1) != 0;
+  m->ln_fused = pmce_env_int("PMCE_LN_FUSED", 1) != 0;
   m->attn_f16 = pmce_env_int("PMCE_ATTN_F16", 1) != 0;
   m->split_overlap = pmce_env_int("PMCE_SPLIT_OVERLAP", 1) != 0;
   m->strict_overflow = pmce_env_int("PMCE_STRICT_OVERFLOW", 0) != 0;

@@ -70,6 +70,20 @@ def gemm_nt_split_blk(A, Wblk, wscale, N, bias=None, residual=None, act=0, a_pac
     return out
 
 
+def gemm_nt_split_ln(Ap, Wp, wscale, bias, residual, ln1=None, ln2=None, blocked=True, want_out1=True):
+    """pmce_gemm_nt_split_f16_ln: x = Ap W^T + bias + residual (N = 256); y1 = LN(x; ln1) or x; returns (y1 fp32 or None,
+    LN(y1; ln2) pre-split or None).  ln1 / ln2 = (weight, bias, eps)."""
+    lib = _lib.load()
+    M, K = Ap.shape
+    out1 = torch.empty(M, 256, device=Ap.device) if want_out1 else None
+    out2 = torch.empty(M, 256, device=Ap.device) if ln2 is not None else None
+    w1, b1, e1 = (_c(ln1[0]), _c(ln1[1]), float(ln1[2])) if ln1 is not None else (None, None, 0.0)
+    w2, b2, e2 = (_c(ln2[0]), _c(ln2[1]), float(ln2[2])) if ln2 is not None else (None, None, 0.0)
+    _lib.check(lib.pmce_gemm_nt_split_f16_ln(P(Ap), P(Wp), 1 if blocked else 0, P(wscale), P(bias), P(residual), M, K, P(w1), P(b1), e1, P(out1),
+                                             P(w2), P(b2), e2, P(out2), _st()), "gemm_nt_split_ln")
+    return out1, out2
+
+
 def split_rows_f16(A):
     """A[M,K] fp32 -> the packed (hi | lo*2^11) f16 planes, as an [M,K] float32-typed buffer."""
     lib = _lib.load()

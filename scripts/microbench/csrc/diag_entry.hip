@@ -23,6 +23,7 @@ extern "C" int pmce_diag_gemm_nt_split_f16(int kind, const float* A, const float
   p.A = A; p.W = Wp; p.wscale = wscale; p.bias = bias; p.R = R; p.C = C; p.rscale = nullptr; p.wblk = 0;
   p.M = M; p.N = N; p.K = K; p.lda = (unsigned)lda; p.ldc = (unsigned)ldc;
   p.c_div = 0; p.c_lo = 0; p.c_hi = 0;
+  p.ln1_w = p.ln1_b = p.ln2_w = p.ln2_b = nullptr; p.ln1_eps = p.ln2_eps = 0.f; p.out1 = p.out2 = nullptr;
   p.oflow = nullptr;
   p.clk = nullptr;
   p.skew = (K / 16) * 12 * 32 / 4096 + 1;

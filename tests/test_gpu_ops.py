@@ -733,3 +733,72 @@ def test_gemm_split_blocked_weight_layout_is_bit_identical(M, N, K, act, res, a_
         ops.gemm_nt_split_rs(Ap, rs, Wp, ws, b, out=want, rowmap=(T_, (M // T_) * N, N))
         ops.gemm_nt_split_blk(Ap, Wb, wsb, N, b, rscale=rs, rowmap=(T_, (M // T_) * N, N), out=got)
         assert torch.equal(want, got)
+
+
+def _unsplit_rows(P16, M, K):
+    """[M,K] float32-typed buffer of packed (hi | lo*2^11) f16 planes -> the fp32 values hi + lo * 2^-11 (exact in fp64)."""
+    h = P16.contiguous().view(torch.float16).view(M, K // 16, 2, 16).double()
+    return (h[:, :, 0, :] + h[:, :, 1, :] / 2048.0).reshape(M, K)
+
+
+@pytest.mark.parametrize("M,K,case", [
+    (69632, 256, "norm2"),       # proj of a C = 256 block at B = 256: x += proj(attn); XN = norm2(x)
+    (4001, 512, "post"),         # fc2: x = norm_s(x + fc2(h)); XN = next norm1(x); ragged last tile
+    (272, 512, "post_last"),     # the last block: no second LayerNorm; B = 1
+    (100, 256, "in_place"),      # out1 aliases the residual (what the model does)
+])
+def test_gemm_split_layernorm_epilogue(M, K, case):
+    """pmce_gemm_nt_split_f16_ln (the N = 256 products of a C = 256 lifter block with the LayerNorm chain of their consumer in the
+    epilogue) against the two launches it replaces (product, then pmce_ln_chain) and against fp64: the fp32 outputs to a few ulp of the
+    row scale, the pre-split output through its reconstructed value (hi + lo * 2^-11)."""
+    from pmce_amd import ops
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(256, K, generator=g) * K ** -0.5
+    b = torch.randn(256, generator=g)
+    R = torch.randn(M, 256, generator=g) * 2.0 + 0.3            # (a mean the statistics have to remove)
+    ln = lambda: (1.0 + 0.2 * torch.randn(256, generator=g), 0.1 * torch.randn(256, generator=g), 1e-6)
+    ln1 = None if case == "norm2" else ln()
+    ln2 = None if case == "post_last" else ln()
+    d = lambda t: None if t is None else tuple(x.to(dev()) if torch.is_tensor(x) else x for x in t)
+    Ap = ops.split_rows_f16(A.to(dev()))
+    Wb, ws, _ = ops.pack_split_f16_blk(W.to(dev()))
+    Rd = R.to(dev())
+    # the two launches
+    x = ops.gemm_nt_split_blk(Ap, Wb, ws, 256, b.to(dev()), residual=Rd, a_packed=True)
+    w1, b1 = (d(ln1)[0], d(ln1)[1]) if ln1 else (None, None)
+    w2, b2 = (d(ln2)[0], d(ln2)[1]) if ln2 else (None, None)
+    ref1, ref2 = ops.ln_chain(x, w1, b1, 1e-6, w2=w2, b2=b2, eps2=1e-6, out2_split=True)
+    # the one launch
+    if case == "in_place":
+        lib = ops._lib.load()
+        Rin = Rd.clone()
+        out2 = torch.empty(M, 256, device=dev())
+        ops._lib.check(lib.pmce_gemm_nt_split_f16_ln(ops.P(Ap), ops.P(Wb), 1, ops.P(ws), ops.P(b.to(dev())), ops.P(Rin), M, K, ops.P(w1), ops.P(b1), 1e-6,
+                                                     ops.P(Rin), ops.P(w2), ops.P(b2), 1e-6, ops.P(out2), ops._st()), "ln")
+        out1 = Rin
+    else:
+        out1, out2 = ops.gemm_nt_split_ln(Ap, Wb, ws, b.to(dev()), Rd, d(ln1), d(ln2))
+    torch.cuda.synchronize()
+    # fp64 reference of the whole chain
+    x64 = A.double() @ W.double().T + b.double() + R.double()
+    def LN(v, p):
+        mu = v.mean(1, keepdim=True)
+        var = ((v - mu) ** 2).mean(1, keepdim=True)
+        return (v - mu) / torch.sqrt(var + p[2]) * p[0].double() + p[1].double()
+    y1 = LN(x64, ln1) if ln1 else x64
+    e1 = (out1.double().cpu() - y1).abs().max().item()
+    e1_two = (ref1.double().cpu() - y1).abs().max().item()
+    print(f"{case} M={M} K={K}: out1 vs fp64 {e1:.2e} (two launches {e1_two:.2e})", end="")
+    assert e1 < 2.0 * e1_two + 2e-6
+    if ln2:
+        y2 = LN(y1, ln2)
+        got2, two2 = _unsplit_rows(out2.cpu(), M, 256), _unsplit_rows(ref2.cpu(), M, 256)
+        e2, e2_two = (got2 - y2).abs().max().item(), (two2 - y2).abs().max().item()
+        print(f"; pre-split out2 vs fp64 {e2:.2e} (two launches {e2_two:.2e})", end="")
+        assert e2 < 2.0 * e2_two + 2e-6
+        # as an operand: the same planes pmce_ln_chain writes wherever the two fp32 LayerNorm values agree (they differ by summation order only)
+        h = out2.cpu().contiguous().view(torch.float16).view(M, 16, 2, 16)[:, :, 0, :].reshape(M, 256)
+        h_two = ref2.cpu().contiguous().view(torch.float16).view(M, 16, 2, 16)[:, :, 0, :].reshape(M, 256)
+        assert (h != h_two).float().mean().item() < 1e-3
+    print()
