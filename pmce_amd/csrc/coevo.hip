@@ -1215,6 +1215,241 @@ __global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict_
   }
 }
 
+// The same attention with TWO query tiles per wave (one workgroup per clip instead of two): staging a key tile (global loads, split, LDS
+// writes), its barrier and its fragment reads are paid per (workgroup, key tile) whatever the number of queries a wave owns - 0.8 of
+// the 2.2 us a key tile costs (profiles/r04_g_vertex_sa_ablation.txt) - and 2 B workgroups on 256 CUs are two rounds from B = 129 on.
+// Every query tile's arithmetic is the one-tile kernel's in the same order (bit-identical results: a clip does not depend on the batch
+// it came in); the launcher takes this form where the one-tile form would need more than one round.
+__global__ __launch_bounds__(448) void vertex_sa2_kernel(const float* __restrict__ xin, const float* __restrict__ qkv,
+                                                        const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                        float* __restrict__ yout) {
+  __shared__ __attribute__((aligned(16))) float sK[2][32 * SA_KLD];
+  constexpr bool F16 = true;
+  constexpr int QT = 2;
+  __shared__ __attribute__((aligned(16))) float sVv[2][64 * SA_VTLD];
+  __shared__ __attribute__((aligned(16))) float sWp[64 * LDW64];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n0 = lane & 31, hb = lane >> 5;
+  const float* qkv_b = qkv + (long long)b * NV * 192;
+  stage_weight<64>(sWp, Wp, 64, tid, 448);
+
+  // staging assignment: 32 rows x 32 float4 (16 of k, 16 of v) = 1024 float4 per key tile.  fp32 form: thread -> (row, float4) in
+  // order.  f16 form: waves 0, 1 stage V - a thread takes 4 consecutive keys x 4 channels and writes, per channel, the 4 keys of
+  // its fragment group as one 8-byte (hi) and one 8-byte (lo) store into the transposed tile; waves 2 .. 6 stage K (512 float4
+  // over 320 threads), each float4 = 4 channels of one key = half a fragment group.
+  f32x4 pre[F16 ? 4 : 3];
+  const int vg = (tid >> 3) & 7, vq = (tid & 7) + 8 * (tid >> 6);  // V role: key group (keys 4 vg .. +3), channel quad
+  auto gload = [&](int jt) {
+    if constexpr (!F16) {
+#pragma unroll
+      for (int it = 0; it < 3; ++it) {
+        const int idx = tid + it * 448;
+        if (idx < 1024) {
+          const int rr = idx >> 5, c4 = idx & 31;
+          const int j = jt * 32 + rr;
+          pre[it] = (j < NV) ? *reinterpret_cast<const f32x4*>(qkv_b + (long long)j * 192 + 64 + 4 * c4)
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    } else if (wave < 2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = jt * 32 + 4 * vg + k;
+        pre[k] = (j < NV) ? *reinterpret_cast<const f32x4*>(qkv_b + (long long)j * 192 + 128 + 4 * vq) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int idx = tid - 128 + it * 320;
+        if (idx < 512) {
+          const int j = jt * 32 + (idx >> 4);
+          pre[it] = (j < NV) ? *reinterpret_cast<const f32x4*>(qkv_b + (long long)j * 192 + 64 + 4 * (idx & 15))
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+    if constexpr (!F16) {
+#pragma unroll
+      for (int it = 0; it < 3; ++it) {
+        const int idx = tid + it * 448;
+        if (idx < 1024) {
+          const int rr = idx >> 5, c4 = idx & 31;
+          if (c4 < 16)
+            *reinterpret_cast<f32x4*>(&sK[buf][rr * SA_KLD + 4 * c4]) = pre[it];
+          else
+            *reinterpret_cast<f32x4*>(&sVv[buf][rr * SA_VLD + 4 * (c4 - 16)]) = pre[it];
+        }
+      }
+    } else if (wave < 2) {
+      // V^T: key group vg -> k-step vg / 4, lane half (vg % 4) & 1, elements 4 ((vg % 4) >> 1) .. +3 of the 8-key fragment
+      const int ks = vg >> 2, g = vg & 3;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        tl_f16x4 hi, lo;
+        split4_plain(pre[0][i], pre[1][i], pre[2][i], pre[3][i], hi, lo);
+        _Float16* d = reinterpret_cast<_Float16*>(&sVv[buf][(4 * vq + i) * SA_VTLD + (ks * 2 + (g & 1)) * 8]) + (g >> 1) * 4;
+        *reinterpret_cast<tl_f16x4*>(d) = hi;
+        *reinterpret_cast<tl_f16x4*>(d + 8) = lo;
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int idx = tid - 128 + it * 320;
+        if (idx < 512) {
+          const int rr = idx >> 4, c4 = idx & 15;
+          tl_f16x4 hi, lo;
+          split4_plain(pre[it][0], pre[it][1], pre[it][2], pre[it][3], hi, lo);
+          // K: channels 4 c4 .. +3 of key rr -> head c4 / 8, k-step (c4 % 8) / 4, group c4 % 4 (stage_weight_split's order)
+          const int h = c4 >> 3, ks = (c4 >> 2) & 1, g = c4 & 3;
+          _Float16* d = reinterpret_cast<_Float16*>(&sK[buf][rr * SA_KLD + ((h * 2 + ks) * 2 + (g & 1)) * 8]) + (g >> 1) * 4;
+          *reinterpret_cast<tl_f16x4*>(d) = hi;
+          *reinterpret_cast<tl_f16x4*>(d + 8) = lo;
+        }
+      }
+    }
+  };
+
+  // wave w owns query tiles 2 w and 2 w + 1 (14 tiles = the clip): every per-tile quantity below is the one-tile kernel's, twice
+  bool valid[QT];
+  long long tok[QT];
+  tl_f16x8 qhi[QT][2][2], qlo[QT][2][2];  // [tile][head][k-step]
+  const float scale = 0.17677669529663688110f * 1.44269504088896340736f * 1024.0f;
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int v = (wave * QT + t) * 32 + n0;
+    valid[t] = v < NV;
+    tok[t] = (long long)b * NV + (valid[t] ? v : NV - 1);
+    float q[32];
+    load_slots(qkv + tok[t] * 192, q, hb);
+#pragma unroll
+    for (int s = 0; s < 32; ++s) q[s] *= scale;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) split_slots8_plain(q + 16 * h + 8 * ks, qhi[t][h][ks], qlo[t][h][ks]);
+  }
+  f32x16 O[QT][2];
+  float mrun[QT][2], lrun[QT][2], off[QT][2];
+#pragma unroll
+  for (int t = 0; t < QT; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      mrun[t][h] = -INFINITY;
+      lrun[t][h] = 0.f;
+      off[t][h] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[t][h][r] = 0.f;
+    }
+  constexpr float kQs = 0.0009765625f;
+  constexpr float kLazy = 8.0f * 1024.0f;
+
+  // tile jt + 1 is written to LDS at the TOP of iteration jt (from the registers iteration jt - 1 loaded), tile jt + 2 is fetched
+  // right after: the staging arithmetic runs under the fragment reads' latency instead of in front of the barrier
+  gload(0);
+  lstore(0);
+  if (NTILE > 1) gload(1);
+  __syncthreads();
+  for (int jt = 0; jt < NTILE; ++jt) {
+    const int buf = jt & 1;
+    // a head's 8 fragments serve BOTH query tiles; the next key tile is staged once the first head's reads are under way
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      tl_f16x8 kf[2][2], vf[2][2];  // [k-step][hi | lo]
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const float* kp = &sK[buf][n0 * SA_KLD + ((h * 2 + ks) * 2 + hb) * 8];
+        kf[ks][0] = *reinterpret_cast<const tl_f16x8*>(kp);
+        kf[ks][1] = *reinterpret_cast<const tl_f16x8*>(kp + 4);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const float* vp = &sVv[buf][(32 * h + n0) * SA_VTLD + (ks * 2 + hb) * 8];
+        vf[ks][0] = *reinterpret_cast<const tl_f16x8*>(vp);
+        vf[ks][1] = *reinterpret_cast<const tl_f16x8*>(vp + 4);
+      }
+      if (h == 0) {
+        asm volatile("" ::: "memory");
+        if (jt + 1 < NTILE) lstore(buf ^ 1);
+        if (jt + 2 < NTILE) gload(jt + 2);
+      }
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][0], qhi[t][h][ks], S, 0, 0, 0);
+          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][1], qhi[t][h][ks], S, 0, 0, 0);
+          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][0], qlo[t][h][ks], S, 0, 0, 0);
+        }
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
+          const float sv = (j < NV) ? S[r] : -INFINITY;
+          S[r] = sv;
+          mt = fmaxf(mt, sv);
+        }
+        if (__builtin_amdgcn_ballot_w64(mt > mrun[t][h] + kLazy) != 0) {
+          const float mn = fmaxf(mrun[t][h], pair_max(mt));
+          const float corr = __builtin_amdgcn_exp2f((mrun[t][h] - mn) * kQs);
+          mrun[t][h] = mn;
+          off[t][h] = fmaf(mn, -kQs, 6.0f);
+          lrun[t][h] *= corr;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) O[t][h][r] *= corr;
+        }
+        float pr[16], sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pr[r] = __builtin_amdgcn_exp2f(fmaf(S[r], kQs, off[t][h]));
+          sum += pr[r];
+        }
+        lrun[t][h] += sum;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          tl_f16x8 phi, plo;
+          split_slots8_plain(pr + 8 * ks, phi, plo);
+          O[t][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[ks][0], phi, O[t][h], 0, 0, 0);
+          O[t][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[ks][1], phi, O[t][h], 0, 0, 0);
+          O[t][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[ks][0], plo, O[t][h], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    float att[32];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float inv = 1.0f / pair_sum(lrun[t][h]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) att[16 * h + r] = O[t][h][r] * inv;
+    }
+    float x[32];
+    load_slots(xin + tok[t] * 64, x, hb);
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = bp[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb] + x[16 * nt + r];
+    tl_gemm<8, 2, LDW64>(sWp, att, acc, n0, hb);
+    if (valid[t]) {
+      float y[32];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[16 * nt + r] = acc[nt][r];
+      store_slots(yout + tok[t] * 64, y, hb);
+    }
+  }
+}
+
 // ======================================================================================================
 // tokens_kv (joint<-vertex direction, live in coevoblock3 only):
 //   kv[tok][0:64]   = Wk * AdaLN_k(xk) + bk     xk = proj_v2j_dim(vf) + v2j_K_embed   (CoevoDecoder.py:183)
@@ -1747,7 +1982,9 @@ extern "C" int pmce_adaln_qkv_split_f32(const float* xin, const float* GB, int g
 extern "C" int pmce_vertex_sa_ex_f32(const float* xin, const float* qkv, const float* Wp, const float* bp, float* yout, int B,
                                      int split_f16, hipStream_t stream) {
   PMCE_REQUIRE(xin && qkv && Wp && bp && yout && B > 0, "vertex_sa: null pointer");
-  if (split_f16) hipLaunchKernelGGL(vertex_sa_kernel<true>, dim3(2, B), dim3(448), 0, stream, xin, qkv, Wp, bp, yout);
+  static const int two_tiles = pmce_env_int("PMCE_SA_TWO_TILES", 1);  // A/B knob, read once
+  if (split_f16 && two_tiles && B > 128) hipLaunchKernelGGL(vertex_sa2_kernel, dim3(1, B), dim3(448), 0, stream, xin, qkv, Wp, bp, yout);
+  else if (split_f16) hipLaunchKernelGGL(vertex_sa_kernel<true>, dim3(2, B), dim3(448), 0, stream, xin, qkv, Wp, bp, yout);
   else hipLaunchKernelGGL(vertex_sa_kernel<false>, dim3(2, B), dim3(448), 0, stream, xin, qkv, Wp, bp, yout);
   return pmce_check_launch("vertex_sa");
 }

@@ -430,6 +430,22 @@ def test_vertex_self_attn(golden, split_f16):
     assert e3 < 3e-5
 
 
+def test_vertex_self_attn_two_query_tiles_per_wave_is_bit_identical():
+    """From B = 129 on the f16-form self-attention runs one workgroup per clip with two query tiles per wave (vertex_sa2_kernel) instead of
+    two workgroups per clip: every query tile's arithmetic is the same in the same order, so a clip's result does not depend on the batch
+    it came in - bit for bit."""
+    from pmce_amd import ops
+    sd = cached_state_dict(17, 256)
+    p = BLK + ".vertx_SA_FFN"
+    sdd = sd_dev(sd, p)
+    B = 131
+    g, x = rnd("sa2.g", (B, 2048), 0.8).to(dev()), rnd("sa2.x", (B, 431, 64), 1.5).to(dev())
+    y_big, _ = ops.vertex_self_attn(x, g, sdd, p, split_f16=True)
+    for lo in (0, 64, 127):
+        y_small, _ = ops.vertex_self_attn(x[lo:lo + 4].contiguous(), g[lo:lo + 4].contiguous(), sdd, p, split_f16=True)
+        assert torch.equal(y_big[lo:lo + 4], y_small), lo
+
+
 @pytest.mark.parametrize("stage", [1, 2, 3])
 def test_joint_stream(golden, stage):
     from oracle import pmce_oracle as O
