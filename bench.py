@@ -162,6 +162,8 @@ def gemm_class_bytes(name, B, J, C, depth=3, T=16, F=2048, streaming=False):
     M = B * T * J
     if name == "gemm_lifter":
         per_block = (M * C + 3 * M * C + 3 * C * C) + (M * C + 2 * M * C + C * C) + (M * C + 2 * M * C + 2 * C * C) + (2 * M * C + 2 * M * C + 2 * C * C)
+        if C == 256:   # proj and fc2 also write their consumer's pre-split LayerNorm output (pmce_gemm_nt_split_f16_ln: the ln_chain launches' result)
+            per_block += 2 * M * C
         if streaming:
             return 4.0 * (2 * depth - 1) * per_block
         return 4.0 * (B * T * F + B * T * C + F * C + 2 * depth * per_block)
