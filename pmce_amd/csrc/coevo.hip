@@ -1051,7 +1051,7 @@ __global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict_
   // 32^-0.5 * log2(e): scores are kept in log2 units so the softmax uses the native v_exp_f32 (2^x); the f16 form carries 2^10 more
   const float scale = 0.17677669529663688110f * 1.44269504088896340736f * (F16 ? 1024.0f : 1.0f);
 #pragma unroll
-  for (int s = 0; s < 32; ++s) q[s] *= scale;
+  for (int s = 0; s < 32; ++s) q[s] = pinned(q[s] * scale);  // ONE fp32 value for both planes, whatever the code around it (common.hpp)
   tl_f16x8 qhi[2][2], qlo[2][2];  // [head][k-step]
   if constexpr (F16) {
 #pragma unroll
@@ -1228,6 +1228,7 @@ __global__ __launch_bounds__(448) void vertex_sa2_kernel(const float* __restrict
   constexpr int QT = 2;
   __shared__ __attribute__((aligned(16))) float sVv[2][64 * SA_VTLD];
   __shared__ __attribute__((aligned(16))) float sWp[64 * LDW64];
+  __shared__ __attribute__((aligned(16))) float sQ[7 * 8 * 64 * 4];  // the second query tile's 8 q fragments per wave (56 KB)
   const int b = blockIdx.y, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int n0 = lane & 31, hb = lane >> 5;
@@ -1313,9 +1314,12 @@ __global__ __launch_bounds__(448) void vertex_sa2_kernel(const float* __restrict
   };
 
   // wave w owns query tiles 2 w and 2 w + 1 (14 tiles = the clip): every per-tile quantity below is the one-tile kernel's, twice
+  // The first tile's q fragments stay in registers; the second tile's (32 registers) live in LDS, 16 bytes per lane and fragment, and are
+  // read just before their products - with both in registers the kernel spilled 22 (the one-workgroup-per-CU LDS budget has the room).
   bool valid[QT];
   long long tok[QT];
-  tl_f16x8 qhi[QT][2][2], qlo[QT][2][2];  // [tile][head][k-step]
+  tl_f16x8 qhi[2][2], qlo[2][2];  // tile 0: [head][k-step]
+  tl_f16x8* sQw = reinterpret_cast<tl_f16x8*>(sQ) + wave * 8 * 64 + lane;  // fragment f of this lane: sQw[f * 64]
   const float scale = 0.17677669529663688110f * 1.44269504088896340736f * 1024.0f;
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
@@ -1325,11 +1329,20 @@ __global__ __launch_bounds__(448) void vertex_sa2_kernel(const float* __restrict
     float q[32];
     load_slots(qkv + tok[t] * 192, q, hb);
 #pragma unroll
-    for (int s = 0; s < 32; ++s) q[s] *= scale;
+    for (int s = 0; s < 32; ++s) q[s] = pinned(q[s] * scale);  // ONE fp32 value for both planes, whatever the code around it (common.hpp)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) split_slots8_plain(q + 16 * h + 8 * ks, qhi[t][h][ks], qlo[t][h][ks]);
+      for (int ks = 0; ks < 2; ++ks) {
+        if (t == 0) {
+          split_slots8_plain(q + 16 * h + 8 * ks, qhi[h][ks], qlo[h][ks]);
+        } else {
+          tl_f16x8 fh, fl;
+          split_slots8_plain(q + 16 * h + 8 * ks, fh, fl);
+          sQw[((h * 2 + ks) * 2 + 0) * 64] = fh;
+          sQw[((h * 2 + ks) * 2 + 1) * 64] = fl;
+        }
+      }
   }
   f32x16 O[QT][2];
   float mrun[QT][2], lrun[QT][2], off[QT][2];
@@ -1382,9 +1395,11 @@ __global__ __launch_bounds__(448) void vertex_sa2_kernel(const float* __restrict
         for (int r = 0; r < 16; ++r) S[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][0], qhi[t][h][ks], S, 0, 0, 0);
-          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][1], qhi[t][h][ks], S, 0, 0, 0);
-          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][0], qlo[t][h][ks], S, 0, 0, 0);
+          const tl_f16x8 qh = t == 0 ? qhi[h][ks] : sQw[((h * 2 + ks) * 2 + 0) * 64];
+          const tl_f16x8 ql = t == 0 ? qlo[h][ks] : sQw[((h * 2 + ks) * 2 + 1) * 64];
+          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][0], qh, S, 0, 0, 0);
+          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][1], qh, S, 0, 0, 0);
+          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][0], ql, S, 0, 0, 0);
         }
         float mt = -INFINITY;
 #pragma unroll
