@@ -762,6 +762,7 @@ def _unsplit_rows(P16, M, K):
     (4001, 512, "post"),         # fc2: x = norm_s(x + fc2(h)); XN = next norm1(x); ragged last tile
     (272, 512, "post_last"),     # the last block: no second LayerNorm; B = 1
     (100, 256, "in_place"),      # out1 aliases the residual (what the model does)
+    (777, 64, "row_major_w"),    # the row-major packed weight (PMCE_SPLIT_WBLK=0 models), a short K
 ])
 def test_gemm_split_layernorm_epilogue(M, K, case):
     """pmce_gemm_nt_split_f16_ln (the N = 256 products of a C = 256 lifter block with the LayerNorm chain of their consumer in the
@@ -782,6 +783,9 @@ def test_gemm_split_layernorm_epilogue(M, K, case):
     Rd = R.to(dev())
     # the two launches
     x = ops.gemm_nt_split_blk(Ap, Wb, ws, 256, b.to(dev()), residual=Rd, a_packed=True)
+    blocked = case != "row_major_w"
+    if not blocked:
+        Wb, ws = ops.pack_split_f16(W.to(dev()))
     w1, b1 = (d(ln1)[0], d(ln1)[1]) if ln1 else (None, None)
     w2, b2 = (d(ln2)[0], d(ln2)[1]) if ln2 else (None, None)
     ref1, ref2 = ops.ln_chain(x, w1, b1, 1e-6, w2=w2, b2=b2, eps2=1e-6, out2_split=True)
@@ -794,7 +798,7 @@ def test_gemm_split_layernorm_epilogue(M, K, case):
                                                      ops.P(Rin), ops.P(w2), ops.P(b2), 1e-6, ops.P(out2), ops._st()), "ln")
         out1 = Rin
     else:
-        out1, out2 = ops.gemm_nt_split_ln(Ap, Wb, ws, b.to(dev()), Rd, d(ln1), d(ln2))
+        out1, out2 = ops.gemm_nt_split_ln(Ap, Wb, ws, b.to(dev()), Rd, d(ln1), d(ln2), blocked=blocked)
     torch.cuda.synchronize()
     # fp64 reference of the whole chain
     x64 = A.double() @ W.double().T + b.double() + R.double()
