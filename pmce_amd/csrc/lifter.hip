@@ -92,7 +92,10 @@ __global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__
   float v[NV];
 #pragma unroll
   for (int i4 = 0; i4 < NV / 4; ++i4) {
-    const f32x4 t = *reinterpret_cast<const f32x4*>(x + src * C + i4 * 256 + lane * 4);
+    // Streaming (non-temporal) accesses for the row itself and for the fp32 residual stream out1 (round 4): read once / next touched a
+    // product later.  NOT for out2: it is the NEXT product's A operand, and written back normally that product finds it in the Infinity
+    // Cache (profiles/r04_g_ln_chain_nontemporal_ab.txt: ln_chain -13 %, the attention after it -5 %, the lifter products -1.6 %).
+    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + src * C + i4 * 256 + lane * 4));
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i4 * 4 + i] = t[i];
   }
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__
       f32x4 t;
 #pragma unroll
       for (int i = 0; i < 4; ++i) t[i] = v[i4 * 4 + i];
-      *reinterpret_cast<f32x4*>(out1 + row * C + i4 * 256 + lane * 4) = t;
+      __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(out1 + row * C + i4 * 256 + lane * 4));
     }
   }
   if (out2) {
