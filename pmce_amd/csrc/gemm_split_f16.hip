@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
               const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);  // lane ^ 1
               const unsigned outw = odd ? ((nbr >> 16) | (w & 0xffff0000u)) : ((w & 0xffffu) | (nbr << 16));
               const unsigned vo = lane_pk + (unsigned)((r & 3) + 8 * (r >> 2)) * row_bytes + (unsigned)(j * 32) * 4u;
-              __builtin_amdgcn_raw_buffer_store_b32(outw, rsrc_x, vo, 0, 2);
+              __builtin_amdgcn_raw_buffer_store_b32(outw, rsrc_x, vo, 0, 0);  // write-back: the next product's A operand (as ln_chain's out2)
             }
         }
         report_nonfinite(p.oflow, bad);
