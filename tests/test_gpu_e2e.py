@@ -715,12 +715,14 @@ def test_adversarial_weights_both_modes_vs_oracle():
         assert err["split_f16"][i] <= 1.5 * max(err["f32"][i], err["oracle fp32"][i]) + 1e-7 * scale[i]
 
 
-def test_headline_shape_sampled_clips_vs_oracle():
-    """BASELINE configs[2] at north_star's width, directly: one B = 256, C = 512 forward in the default mode, 16 of its clips
-    against the oracle."""
+@pytest.mark.parametrize("C", [512, 256])
+def test_headline_shape_sampled_clips_vs_oracle(C):
+    """BASELINE configs[2] directly: one B = 256 forward in the default mode at north_star's width (C = 512) and at the width every
+    reference config ships (C = 256: the LayerNorm-epilogue products and, like C = 512, the two-query-tile attention at their full
+    size), 16 of its clips against the oracle."""
     from oracle import pmce_oracle as O
     from pmce_amd import synth
-    J, C, B = 17, 512, 256
+    J, B = 17, 256
     model = get_model(J, C)
     sd = cached_state_dict(J, C)
     pose2d, img_feat = synth.make_inputs(B, J, 2024)
@@ -730,7 +732,7 @@ def test_headline_shape_sampled_clips_vs_oracle():
     with torch.no_grad():
         rm, rp, rl = O.pmce_forward(sd, T(pose2d[idx]), T(img_feat[idx]), model.vj_relation)
     e = (maxabs(mesh[idx], rm), maxabs(pose[idx], rp), maxabs(pose3d[idx], rl))
-    print("B=256, C=512, 16 sampled clips vs oracle: mesh %.2e m, pose %.2e m, pose3d %.2e mm" % e)
+    print(f"B=256, C={C}, 16 sampled clips vs oracle: mesh %.2e m, pose %.2e m, pose3d %.2e mm" % e)
     assert e[0] < TIGHT_M and e[1] < TIGHT_M and e[2] < TOL_MM
 
 
