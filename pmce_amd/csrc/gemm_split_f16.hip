@@ -104,10 +104,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
   const int my_tiles = (chunk_len - bx + gx - 1) / gx;
   const int nk = p.K / (16 * KSUB);  // stages per tile
   const int total = my_tiles * nk;
-  // The two workgroups of a CU start together and their tiles take the same time: left alone they reach their epilogues
-  // (a burst of stores with the matrix pipe idle) at the same moment, tile after tile.  The second workgroup of each CU (the
-  // dispatcher fills every CU of an XCD once before it doubles up) starts about half a tile late, so that one stores while
-  // the other computes.
+  // Optional start delay of the second workgroup of each CU (the dispatcher fills every CU of an XCD once before it doubles up), so
+  // that the two do not reach their epilogues at the same moment.  Worth -8...-18 % in round 2; with today's kernel the two drift apart
+  // on their own and the launcher passes 0 (see gemm_split_any).
   if (p.skew > 0 && gridDim.x >= 512 && bx >= (gx >> 1)) {
     for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(64);
   }
@@ -670,9 +669,12 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
   p.ln1_w = p.ln1_b = p.ln2_w = p.ln2_b = nullptr; p.ln1_eps = p.ln2_eps = 0.f; p.out1 = p.out2 = nullptr;
   p.oflow = pmce_overflow_sink();
   p.clk = pmce_clock_sink();  // (thread-local: set while an entry point of a model with a clock probe runs)
-  {  // half a tile of matrix time: nk iterations x 3*TM*TN instructions x 32 cycles (TM*TN = 8 or 4), / 2, in 4096-cycle units
+  {  // Start delay of a CU's second workgroup, in 4096-cycle units.  Round 2 introduced half a tile of matrix time ((K / 16) * 12 * 32 /
+     // 4096 + 1) so that one workgroup's epilogue falls into the other's k-loop (-8...-18 % then); with today's kernel (blocked weights,
+     // pre-split operands, residual prefetch) the two drift apart on their own and the delay only costs: none measures +1.1 % at
+     // C = 512, +0.3 % at C = 256 (profiles/r04_j_gemm_start_skew_ab.txt).  PMCE_SPLIT_SKEW / pmce_gemm_split_set_skew still set one.
     const int knob = g_split_skew.load(std::memory_order_relaxed);
-    p.skew = knob >= 0 ? knob : (K / 16) * 12 * 32 / 4096 + 1;
+    p.skew = knob >= 0 ? knob : 0;
   }
   const int tile = pick_split_tile(M, N);
   if (tile == 2 && g_split_k32 && g_split_tile.load(std::memory_order_relaxed) < 0 && K % 32 == 0 && K >= 128 &&
@@ -748,7 +750,7 @@ extern "C" int pmce_gemm_nt_split_f16_ln(const float* Ap, const float* Wp, int w
   p.clk = pmce_clock_sink();
   {
     const int knob = g_split_skew.load(std::memory_order_relaxed);
-    p.skew = knob >= 0 ? knob : (K / 16) * 12 * 32 / 4096 + 1;
+    p.skew = knob >= 0 ? knob : 0;
   }
   p.ln1_w = ln1_w; p.ln1_b = ln1_b; p.ln1_eps = ln1_eps; p.out1 = out1;
   p.ln2_w = ln2_w; p.ln2_b = ln2_b; p.ln2_eps = ln2_eps; p.out2 = out2;
