@@ -203,30 +203,50 @@ def class_work(name, B, J, C, streaming=False):
     return None, None
 
 
+def library_build_id():
+    """pmce_build_id() of the loaded library (sha over its sources): the id the profiler summaries under profiles/ record."""
+    try:
+        from pmce_amd import _lib
+        return _lib.build_id()
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def _pmc_file(fn):
+    """(data, meta) of a committed profiler summary; meta carries `stale`: the file does not say it was measured on the build that is
+    loaded now (no recorded build id, or another one) - numbers derived from it are flagged, never silently mixed with this run's."""
+    path = os.path.join(REPO, "profiles", fn)
+    if not os.path.exists(path):
+        return None, None
+    try:
+        data = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None
+    rec_id = (data.get("_meta") or {}).get("build_id")
+    lib_id = library_build_id()
+    return data, {"file": f"profiles/{fn}", "build_id": rec_id, "library_build_id": lib_id, "stale": not (rec_id and lib_id and rec_id == lib_id)}
+
+
 def pmc_traffic_per_launch(kernel, C):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC pass of this same command
-    (profiles/pmc_hbm_traffic_per_launch_C<C>.json, made by scripts/gpu_pmc.sh: separate FETCH_SIZE / WRITE_SIZE passes, KiB
+    (profiles/pmc_hbm_traffic_per_launch_C<C>.json, made by scripts/gpu_session.sh pmc: separate FETCH_SIZE / WRITE_SIZE passes, KiB
     units, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction for wide coalesced reads).  bench.py cannot run
-    the profiler on itself; without the file the field is null."""
+    the profiler on itself; without the file the field is null.  Returns (bytes, source text, meta with the stale flag)."""
     for fn in (f"pmc_hbm_traffic_per_launch_C{C}.json",) + (("pmc_hbm_traffic_per_launch.json",) if C == 256 else ()):
-        path = os.path.join(REPO, "profiles", fn)
-        if not os.path.exists(path):
+        data, meta = _pmc_file(fn)
+        if not data:
             continue
-        try:
-            data = json.load(open(path))
-            tot_b, tot_n = 0.0, 0
-            for name, v in data.items():
-                if kernel in name and v.get("launches", 0) > 0:
-                    tot_b += v["launches"] * (2.0 * v["fetch_kib_raw"] + v["write_kib"]) * 1024.0
-                    tot_n += v["launches"]
-            if tot_n:
-                return round(tot_b / tot_n), f"profiles/{fn} (2*FETCH_SIZE + WRITE_SIZE, KiB, launch-weighted)"
-        except Exception:  # noqa: BLE001
-            pass
-    return None, None
+        tot_b, tot_n = 0.0, 0
+        for name, v in data.items():
+            if name != "_meta" and kernel in name and v.get("launches", 0) > 0:
+                tot_b += v["launches"] * (2.0 * v["fetch_kib_raw"] + v["write_kib"]) * 1024.0
+                tot_n += v["launches"]
+        if tot_n:
+            return round(tot_b / tot_n), f"profiles/{fn} (2*FETCH_SIZE + WRITE_SIZE, KiB, launch-weighted)", meta
+    return None, None, None
 
 
-def north_star_record(kernel_ms, launches, B, J, f16_ffn=False):
+def north_star_record(kernel_ms, launches, B, J, f16_ffn=False, C=512):
     """The CoEvoDecoder vertex<-joint cross-attention (north_star's kernel) against its two floors.  After round 2 it is
     fused with its FFN (`vertex_ca_mlp`); both floors are printed: HBM = SURVEY §8a(a8)'s 229,376 B per clip*direction*block
     at the 8 TB/s peak, MFMA = the matrix instructions the fused kernel must issue (per 32-vertex wave tile: 64 score +
@@ -249,7 +269,7 @@ def north_star_record(kernel_ms, launches, B, J, f16_ffn=False):
     # avoid in its present form.  A wave issues vector and matrix instructions one after the other, and at 1.75 waves per SIMD
     # little overlaps them: `serial_floor_ms` = matrix + vector time is the realistic floor, max(...) the optimistic one.
     t_valu = None
-    pmc = _pmc_counters()
+    pmc, pmc_meta = _pmc_counters(C)
     key = "void vertex_ca_mlp_kernel<true>" if f16_ffn else "void vertex_ca_mlp_kernel<false>"
     if name == "vertex_ca_mlp" and pmc and key in pmc and pmc[key].get("SQ_INSTS_VALU") and pmc[key].get("SQ_WAVES"):
         per_clip = pmc[key]["SQ_INSTS_VALU"] / (pmc[key]["SQ_WAVES"] / 7.0)      # 7 waves per clip (14 wave tiles, 2 per wave)
@@ -265,22 +285,30 @@ def north_star_record(kernel_ms, launches, B, J, f16_ffn=False):
     if t_valu is not None:
         rec.update({"valu_floor_ms": round(t_valu, 5), "serial_floor_ms": round(t_mfma + t_valu, 5),
                     "frac_of_serial_floor": round((t_mfma + t_valu) / ms, 4),
-                    "valu_source": "profiles/pmc_counters_per_kernel.json (SQ_INSTS_VALU per launch at B = 256, scaled per clip)"})
+                    "valu_source": f"{pmc_meta['file']} (SQ_INSTS_VALU per launch at B = 256, scaled per clip)",
+                    "valu_counters_build_id": pmc_meta["build_id"], "library_build_id": pmc_meta["library_build_id"],
+                    "stale": pmc_meta["stale"],
+                    "mfma_busy_fraction_pmc": pmc[key].get("mfma_busy_fraction"),
+                    "wave_cycles_waiting_fraction_pmc": (round(pmc[key]["SQ_WAIT_INST_ANY"] / pmc[key]["SQ_WAVE_CYCLES"], 4)
+                                                         if pmc[key].get("SQ_WAVE_CYCLES") and pmc[key].get("SQ_WAIT_INST_ANY") else None)})
     return rec
 
 
-_PMC_COUNTERS = None
+def _pmc_counters(C=512):
+    """SQ counters per kernel (scripts/pmc_kernels.sh) of width C: (data, meta) - meta["stale"] as in _pmc_file."""
+    for fn in (f"pmc_counters_per_kernel_C{C}.json",) + (("pmc_counters_per_kernel.json",) if C == 512 else ()):
+        data, meta = _pmc_file(fn)
+        if data:
+            return data, meta
+    return {}, None
 
 
-def _pmc_counters():
-    global _PMC_COUNTERS
-    if _PMC_COUNTERS is None:
-        fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_counters_per_kernel.json")
-        try:
-            _PMC_COUNTERS = json.load(open(fn))
-        except (OSError, ValueError):
-            _PMC_COUNTERS = {}
-    return _PMC_COUNTERS
+def mfma_busy_per_variant(kernel, C):
+    """Matrix-pipe busy fraction of every instantiation of `kernel` in the committed counter pass:
+    (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs)."""
+    data, meta = _pmc_counters(C)
+    out = {n: v["mfma_busy_fraction"] for n, v in data.items() if n != "_meta" and kernel in n and isinstance(v, dict) and "mfma_busy_fraction" in v}
+    return (out, meta) if out else (None, meta)
 
 
 def attention_record(kernel_ms, launches, B, J, C, split):
@@ -292,8 +320,8 @@ def attention_record(kernel_ms, launches, B, J, C, split):
     byt = B * 16 * J * 4 * C * 4.0
     ach = byt / (ms * 1e-3) / 1e9
     kern = "seq_attention_mfma_kernel" if split else ("seq_attention_pair_kernel" if C == 512 else "seq_attention_kernel")
-    tr, src = pmc_traffic_per_launch(kern, C)
-    return {"kernel": kern, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+    tr, src, tmeta = pmc_traffic_per_launch(kern, C)
+    return {"kernel": kern, "bound": "hbm", "traffic_stale": (tmeta or {}).get("stale"), "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(ach / PEAK_HBM_GBS, 4), "frac_of_achievable_6300": round(ach / 6300.0, 4), "avg_launch_ms": round(ms, 5),
             "launches_per_step": launches["seq_attention"], "algorithmic_bytes_per_launch": int(byt), "traffic": tr,
             "traffic_source": src}
@@ -315,9 +343,12 @@ def dominant_kernel_roofline(kernel_ms, launches, B, J, C, gemm_mode, clk_ghz=No
         kind = works[0][1]
         work = sum(w[0] for w in works)
         secs = dom_ms * 1e-3
-        traffic, traffic_src = pmc_traffic_per_launch(dominant, C)
+        traffic, traffic_src, tmeta = pmc_traffic_per_launch(dominant, C)
+        busy, bmeta = mfma_busy_per_variant(dominant, C)
         common = {"kernel": dominant, "classes": dom_classes, "launches_per_step": dom_launches,
                   "avg_launch_ms": round(dom_ms / dom_launches, 5), "traffic": traffic, "traffic_source": traffic_src,
+                  "traffic_stale": (tmeta or {}).get("stale"), "library_build_id": library_build_id(),
+                  "mfma_busy": busy, "mfma_busy_source": (bmeta or {}).get("file"), "mfma_busy_stale": (bmeta or {}).get("stale"),
                   "algorithmic_per_launch": work / dom_launches}
         if kind == "flop" and dominant == "gemm_split_kernel":
             # the kernel issues THREE f16 matrix products per algorithmic fp32 product: achieved = issued f16 FLOP/s against the
@@ -360,6 +391,7 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
     from pmce_amd.workload import flops_per_clip
 
     assets.allow_synthetic_base_data()                                  # no SMPL-derived files offline: synthetic template
+    t_load0 = time.perf_counter()
     # random-init weights of the named architecture; at N > 1 generated once per node and mapped by the other ranks
     if world > 1:
         sd, shm_path = shared_state_dict(J, C, int(os.environ.get("LOCAL_RANK", rank)), sharding.barrier)
@@ -369,8 +401,9 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
     model.load_state_dict(sd)
     model.set_j_regressor(assets.load_j_regressor("h36m"))
     model = model.to(dev)
+    torch.cuda.synchronize()
+    weights_load_s = time.perf_counter() - t_load0                       # this rank: weights generated / mapped, loaded, on its GPU
     if world > 1:
-        torch.cuda.synchronize()
         sharding.barrier()                                               # every rank has its copy on its GPU
         if shm_path and int(os.environ.get("LOCAL_RANK", rank)) == 0:
             try:
@@ -397,16 +430,20 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
         model.set_concurrency(False)
     k = [0]
 
-    def step():
+    def step(direct=False):
         p, f = inputs[k[0] % NB]
         k[0] += 1
-        if pipe is None:
+        if pipe is None or direct:
             return model.forward_with_joints(p, f)
         return pipe.submit(p, f)     # returns once the batch is enqueued on its lane; complete before the closing synchronize
 
     out = None
-    for _ in range(max(warmup, 1)):  # packing / workspace allocation must not be inside the timed region
+    t_first0 = time.perf_counter()
+    for i in range(max(warmup, 1)):  # packing / workspace allocation must not be inside the timed region
         out = step()
+        if i == 0:
+            torch.cuda.synchronize()
+            first_step_s = time.perf_counter() - t_first0                # this rank's first step: weight packing, workspace, kernel load
     win_ms, own_dt = [], []
     for _ in range(windows):
         torch.cuda.synchronize()
@@ -425,6 +462,7 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
     clips_per_s = B * world / (ms * 1e-3)
     # every rank's OWN rate over the last window (its own clock, before the MAX): a straggler is visible here
     per_rank = sharding.gather_rows(torch.tensor([[B / (own_dt[-1] / steps)]], dtype=torch.float64, device=dev)).flatten().tolist()
+    startup = sharding.gather_rows(torch.tensor([[weights_load_s, first_step_s]], dtype=torch.float64, device=dev)).tolist()
 
     # final metric reduction — the only collective of the path (RCCL over xGMI): per-rank partial sums
     if pipe is not None:
@@ -450,8 +488,12 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
            "ref_equiv_tflops": round(fpc * clips_per_s / 1e12, 2), "outputs_finite": finite,
            "per_rank_clips_s": [round(x, 1) for x in per_rank],
            "per_rank_ms_per_step": [round(B / x * 1e3, 4) for x in per_rank],
+           # start-up skew of the ranks (not in any timed window): weights generated or mapped + loaded + on the GPU; the first step
+           "per_rank_weights_load_s": [round(r[0], 3) for r in startup], "per_rank_first_step_s": [round(r[1], 3) for r in startup],
            "metric_reduction": {"collective": "all_reduce(SUM) of 3 fp64 partials per rank", "clips_counted": int(total[2].item()),
                                 "backend": (torch.distributed.get_backend() if world > 1 else None)}}
+    if args.sustained_seconds > 0 and not args.single_stream:
+        rec["sustained"] = sustained_record(model, pipe, step, dev, B, world, args.sustained_seconds, clips_per_s, gemm_mode)
     if not full:
         return rec, model, pipe, inputs, sd
 
@@ -479,11 +521,76 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
     # every rank's own sustained shader clock under the dominant kernel (power-limited: 8 GPUs in one chassis need not hold the same)
     rec["per_rank_sustained_clock_ghz"] = [round(x, 3) for x in
                                            sharding.gather_rows(torch.tensor([[clk_ghz or 0.0]], dtype=torch.float64, device=dev)).flatten().tolist()]
-    rec.update({"roofline": roofline, "roofline_cross_attention": north_star_record(kernel_ms, launches, B, J, f16_ffn=(gemm_mode == "split_f16")),
+    rec.update({"roofline": roofline, "roofline_cross_attention": north_star_record(kernel_ms, launches, B, J, f16_ffn=(gemm_mode == "split_f16"), C=C),
                 "roofline_attention": attention_record(kernel_ms, launches, B, J, C, gemm_mode == "split_f16" and J in (17, 19)),
                 "kernel_ms_per_step": kernel_ms, "launches_per_step": launches,
                 "kernel_ms_total_single_stream": round(sum(kernel_ms.values()), 4), "gemm_mode": gemm_mode})
     return rec, model, pipe, inputs, sd
+
+
+def sustained_record(model, pipe, step, dev, B, world, seconds, burst_value, gemm_mode):
+    """BASELINE config 5 asks for SUSTAINED clips/s and every large kernel of the path is power-limited: `value` is the median of a
+    few windows of well under a second each.  This is ONE window of at least `seconds` of back-to-back steps on the same workload (same
+    batches in flight, same rotating inputs), with the shader clock the split GEMM's workgroups measure (s_memtime against the 100 MHz
+    counter) sampled at the start, in the middle and at the end - three single forwards on the model's own handle with the clock probe
+    on, counted as steps.  Reported next to `value`, never as it."""
+    import torch
+    from pmce_amd import _lib, sharding
+    lib = _lib.load()
+    handle = model._ensure_packed().handle
+    clk = torch.zeros(2, dtype=torch.int64, device=dev)
+
+    def probe():
+        if gemm_mode != "split_f16":
+            return None
+        if pipe is not None:
+            pipe.synchronize()
+        clk.zero_()
+        torch.cuda.synchronize()
+        lib.pmce_model_set_clock_probe(handle, ctypes.c_void_p(clk.data_ptr()))
+        step(direct=True)
+        torch.cuda.synchronize()
+        lib.pmce_model_set_clock_probe(handle, None)
+        c = clk.tolist()
+        return round(c[0] / c[1] * 0.1, 3) if c[1] > 0 else None
+
+    def smi():
+        try:
+            return {"power_w": torch.cuda.power_draw() / 1000.0, "temp_c": torch.cuda.temperature()}
+        except Exception:  # noqa: BLE001
+            return None
+
+    torch.cuda.synchronize()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    clocks, smis, marks = [], [], []
+    for phase_end in (0.0, seconds / 2, seconds):
+        while time.perf_counter() - t0 < phase_end:
+            for _ in range(8):
+                step()
+            n += 8
+            if n % 64 == 0:
+                torch.cuda.synchronize()       # bound the launch queue (a few hundred ms of work at most)
+        marks.append(round(time.perf_counter() - t0, 2))
+        smis.append(smi())
+        clocks.append(probe())
+        n += 1 if clocks[-1] is not None else 0
+    torch.cuda.synchronize()
+    if pipe is not None:
+        pipe.synchronize()
+    own = time.perf_counter() - t0
+    sharding.barrier()
+    dt = sharding.reduce_max(time.perf_counter() - t0, dev)
+    val = B * world * n / dt
+    return {"value": round(val, 1), "unit": "clips/s", "seconds": round(dt, 2), "steps": n, "ms_per_step": round(dt / n * 1e3, 4),
+            "this_rank_seconds": round(own, 2),
+            "clock_ghz_start": clocks[0], "clock_ghz_middle": clocks[1], "clock_ghz_end": clocks[2], "clock_sample_at_s": marks,
+            "device_power_temp": smis if any(smis) else None,
+            "ratio_to_value": round(val / burst_value, 4) if burst_value else None,
+            "what": "one window of back-to-back steps (same batches in flight and rotating inputs as `value`); clock = shader clock measured by "
+                    "the split GEMM's workgroups during one forward at the start / middle / end"}
 
 
 def host_fed_record(model, pipe, dev, B, J, nfed):
@@ -627,6 +734,8 @@ def main():
                          "1 = strictly one batch at a time")
     ap.add_argument("--no-stagger", action="store_true", help="pipeline lanes free-run instead of starting a batch's lifter "
                                                               "when the previous batch's has finished")
+    ap.add_argument("--sustained-seconds", type=float, default=20.0,
+                    help="length of the one long window behind the `sustained` record (0 = skip); the C = 256 record runs half of it")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the extra (untimed-for-value) host-fed measurement")
     ap.add_argument("--no-latency", action="store_true", help="skip the B=1 / B=8 latency record")
     ap.add_argument("--no-variant", action="store_true", help="skip the second complete record (the other pose-encoder width)")
@@ -646,14 +755,14 @@ def main():
     # C = 256), and a child that runs while its parent holds a HIP context sees ~6 % slower kernels in its profiling pass.
     variant = variant_f32 = None
     C, B, J = args.embed_dim, args.batch, args.joints
-    keep = ("value", "unit", "ms_per_step", "windows", "config", "roofline", "roofline_cross_attention", "roofline_attention", "cpu_baseline",
+    keep = ("value", "unit", "ms_per_step", "windows", "sustained", "config", "roofline", "roofline_cross_attention", "roofline_attention", "cpu_baseline",
             "kernel_ms_per_step", "launches_per_step", "kernel_ms_total_single_stream", "ref_equiv_tflops", "outputs_finite")
 
-    def child_record(extra, cpu_ok):
+    def child_record(extra, cpu_ok, sus=0.0):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
                "--windows", str(args.windows), "--batch", str(B), "--joints", str(J),
                "--pipeline-depth", str(args.pipeline_depth), "--no-variant", "--no-host-fed", "--no-latency",
-               "--cpu-seconds", str(min(args.cpu_seconds, 8.0)), *extra]
+               "--cpu-seconds", str(min(args.cpu_seconds, 8.0)), "--sustained-seconds", str(sus), *extra]
         cmd += ["--no-stagger"] if args.no_stagger else []
         cmd += ["--no-cpu-baseline"] if (args.no_cpu_baseline or not cpu_ok) else []
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
@@ -695,7 +804,7 @@ def main():
             "stream_bench.py", ["--frames", "16384"],
             "BASELINE configs[4] stand-in: one 16,384-frame sequence, stride-1 T = 16 windows with per-frame reuse, acceleration error on the device")
         C2 = 256 if C == 512 else 512
-        variant = child_record(["--embed-dim", str(C2), "--gemm-mode", args.gemm_mode], True)
+        variant = child_record(["--embed-dim", str(C2), "--gemm-mode", args.gemm_mode], True, sus=args.sustained_seconds / 2)
         variant["why"] = ("the width every reference config ships (lib/core/config.py:59)" if C2 == 256
                           else "BASELINE.json north_star's width")
         if args.gemm_mode == "split_f16":     # the same workload with every product on the fp32 matrix pipe
@@ -735,6 +844,11 @@ def main():
                          f"(set PMCE_BENCH_SHARE_GPU=1 PMCE_DIST_BACKEND=gloo to let ranks share a device)")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if world > 1 and not os.environ.get("PMCE_BENCH_SHARE_GPU"):
+        import torch.distributed as dist
+        if dist.get_backend() != "nccl":      # one rank per GPU: the metric reduction must run over RCCL / xGMI, never silently over gloo
+            raise SystemExit(f"bench.py: {world} ranks on {ndev} GPU(s) but the process group backend is {dist.get_backend()!r}, not 'nccl' "
+                             f"(RCCL); unset PMCE_DIST_BACKEND")
 
     head, model, pipe, inputs, sd = measure_config(args, dev, rank, world, J, C, B, args.steps, args.warmup, args.windows)
 
@@ -761,13 +875,15 @@ def main():
             "data": "synthetic",
             "config": head["config"], "roofline": head["roofline"], "roofline_cross_attention": head["roofline_cross_attention"],
             "roofline_attention": head.get("roofline_attention"),
-            "cpu_baseline": cpu, "windows": head["windows"], "host_fed": host_fed, "latency": latency,
+            "cpu_baseline": cpu, "windows": head["windows"], "sustained": head.get("sustained"), "host_fed": host_fed, "latency": latency,
             f"variant_c{256 if C == 512 else 512}": variant, "variant_f32_pipe": variant_f32,
             "kernel_ms_per_step": head["kernel_ms_per_step"], "launches_per_step": head["launches_per_step"],
             "kernel_ms_total_single_stream": head["kernel_ms_total_single_stream"],
             "ref_equiv_tflops": head["ref_equiv_tflops"], "outputs_finite": head["outputs_finite"],
             "per_rank_clips_s": head["per_rank_clips_s"], "per_rank_ms_per_step": head["per_rank_ms_per_step"],
             "per_rank_sustained_clock_ghz": head.get("per_rank_sustained_clock_ghz"),
+            "per_rank_weights_load_s": head.get("per_rank_weights_load_s"), "per_rank_first_step_s": head.get("per_rank_first_step_s"),
+            "library_build_id": library_build_id(),
             "rank0_cpu_affinity": ({"cpus": len(cpu_slice), "first": cpu_slice[0], "last": cpu_slice[-1]} if cpu_slice else None),
             "metric_reduction": head["metric_reduction"],
             **other_configs,

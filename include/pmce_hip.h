@@ -44,6 +44,8 @@ typedef struct ihipStream_t* pmce_stream_t; /* == hipStream_t */
 #define PMCE_ERR_OVERFLOW (-4) /* strict overflow policy only: an earlier call produced non-finite values (pmce_model_overflowed) */
 
 int pmce_version(void);
+/* identifies the sources the library was built from (16 hex digits; pmce_amd.build.source_id()): profiler summaries record it */
+const char* pmce_build_id(void);
 const char* pmce_last_error_string(void);
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -110,6 +112,9 @@ int pmce_model_set_split_min_batch(pmce_model* m, int clips);
  * PMCE_STRICT_OVERFLOW=1 at create): while the word is set every entry point returns PMCE_ERR_OVERFLOW before launching
  * anything.  Pipeline lanes created with pmce_model_share_split_weights share the source's word. */
 int pmce_model_set_overflow_policy(pmce_model* m, int strict);
+/* the values in force (defaults come from PMCE_STRICT_OVERFLOW / PMCE_SPLIT_MIN_BATCH at create; pmce_model_share_split_weights copies both to the lane) */
+int pmce_model_get_overflow_policy(const pmce_model* m);
+int pmce_model_get_split_min_batch(const pmce_model* m);
 /* Measurement aid (bench.py), per MODEL: while set (null = off), every launch of the split GEMM made by an entry point of this model
  * adds, per workgroup, the shader clocks and the 100 MHz wall ticks its first wave was resident to device_two_words[0] / [1]: their
  * ratio x 0.1 is the shader clock in GHz the chip sustained under the kernel (MI355X is power-limited there: 1.6 - 1.8 GHz, not the
@@ -361,6 +366,15 @@ int pmce_vertex_sa_f32(const float* xin, const float* qkv, const float* Wp, cons
  * accumulate (K, V split while their tile is staged; the 64x64 projection stays fp32).  The note on packed-fp32 neighbours at pmce_gemm_nt_split_f16 applies. */
 int pmce_vertex_sa_ex_f32(const float* xin, const float* qkv, const float* Wp, const float* bp, float* yout, int B,
                           int split_f16, pmce_stream_t stream);
+/* The attention half of the vertex stream's AdaLN Block in ONE launch, three-product f16 form (what a model in split_f16 mode runs):
+ *   y = x + proj(softmax(q k^T/sqrt(32)) v),  [q|k|v] = Linear(64->192)(AdaLN(x))   (CoevoDecoder.py:103,118-131)
+ * = pmce_adaln_qkv_split_f32 followed by pmce_vertex_sa_ex_f32(split_f16 = 1), bit for bit, without the [B,431,192] fp32 QKV round
+ * trip: q, k, v come out of the qkv product's accumulators in the attention's own operand layouts; k and v pass through `scratch`
+ * (pmce_vertex_sab_scratch_floats(B) floats, 16-byte aligned, caller-owned, contents meaningless outside the call) as f16 (hi | lo)
+ * fragment planes.  qkv_img = pmce_qkv_pack_f16(Wqkv).  B > 128: one workgroup per clip; otherwise two. */
+long long pmce_vertex_sab_scratch_floats(int B);
+int pmce_vertex_sab_split_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* qkv_img, const float* bqkv,
+                              const float* Wp, const float* bp, float* scratch, float* yout, int B, pmce_stream_t stream);
 /* k|v of the joint<-vertex CrossAttention for the 431 vertex tokens: kv[B,431,128] (CoevoDecoder.py:52-53,83,183). */
 int pmce_tokens_kv_f32(const float* xk, const float* xv, const float* vt, const float* Wv3, const float* Ev,
                        const float* Wv2j, const float* Ek, const float* GB, int gb_stride, int ik, int iv, const float* Wk,

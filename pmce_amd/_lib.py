@@ -20,6 +20,7 @@ _fl = C.c_float
 # name -> argtypes  (restype is int unless listed in _RESTYPES); mirrors include/pmce_hip.h one-to-one
 PROTOTYPES = {
     "pmce_version": [],
+    "pmce_build_id": [],
     "pmce_last_error_string": [],
     "pmce_model_create": [_i, _i, _i, C.POINTER(C.c_void_p)],
     "pmce_model_destroy": [C.c_void_p],
@@ -51,6 +52,8 @@ PROTOTYPES = {
     "pmce_model_share_split_weights": [C.c_void_p, C.c_void_p],
     "pmce_model_set_split_min_batch": [C.c_void_p, _i],
     "pmce_model_set_overflow_policy": [C.c_void_p, _i],
+    "pmce_model_get_overflow_policy": [C.c_void_p],
+    "pmce_model_get_split_min_batch": [C.c_void_p],
     "pmce_model_set_clock_probe": [C.c_void_p, C.c_void_p],
     "pmce_model_overflowed": [C.c_void_p],
     "pmce_model_clear_overflow": [C.c_void_p],
@@ -98,6 +101,8 @@ PROTOTYPES = {
     "pmce_adaln_qkv_split_f32": [_f, _f, _i, _i, _f, _f, _f, _i, _s],
     "pmce_vertex_sa_f32": [_f, _f, _f, _f, _f, _i, _s],
     "pmce_vertex_sa_ex_f32": [_f, _f, _f, _f, _f, _i, _i, _s],
+    "pmce_vertex_sab_scratch_floats": [_i],
+    "pmce_vertex_sab_split_f32": [_f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _i, _s],
     "pmce_tokens_kv_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _f, _f, _f, _i, _s],
     "pmce_joint_stream_f32": [_f, _f, _f, _f, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_int), _f, _f, _f, _i, _i, _i, _s],
     "pmce_build_final_operand_f32": [_f, _f, _f, _i, _i, _s],
@@ -109,11 +114,13 @@ PROTOTYPES = {
 }
 _RESTYPES = {
     "pmce_last_error_string": C.c_char_p,
+    "pmce_build_id": C.c_char_p,
     "pmce_model_destroy": None,
     "pmce_model_tensor_name": C.c_char_p,
     "pmce_model_workspace_bytes": C.c_size_t,
     "pmce_model_split_bytes": C.c_size_t,
     "pmce_model_workspace_offset": C.c_longlong,
+    "pmce_vertex_sab_scratch_floats": C.c_longlong,
 }
 
 _lib = None
@@ -142,6 +149,11 @@ def load():
         fn.restype = _RESTYPES.get(name, C.c_int)
     _lib = lib
     return lib
+
+
+def build_id() -> str:
+    """Identity of the sources the loaded library was built from (pmce_amd.build.source_id() at build time)."""
+    return (load().pmce_build_id() or b"").decode()
 
 
 def last_error() -> str:

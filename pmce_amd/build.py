@@ -35,6 +35,20 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def source_id() -> str:
+    """sha256 over the library's sources (csrc/*.hip|cpp|hpp + include/pmce_hip.h + the flags), first 16 hex digits: compiled into the
+    library (pmce_build_id()) and recorded by the profiler summaries under profiles/, so that counters can be matched to a build."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".hpp")))
+    for f in files + [osp.join("..", "..", "include", "pmce_hip.h")]:
+        h.update(f.encode())
+        with open(osp.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS + NO_PACKED_FP32 + os.environ.get("PMCE_EXTRA_HIPCC_FLAGS", "").split()).encode())
+    return h.hexdigest()[:16]
+
+
 def needs_build() -> bool:
     if not osp.exists(LIB):
         return True
@@ -49,10 +63,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     objdir = osp.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
+    sid = source_id()
 
     def compile_one(src):
         obj = osp.join(objdir, osp.splitext(src)[0] + ".o")
         extra = os.environ.get("PMCE_EXTRA_HIPCC_FLAGS", "").split()
+        if src == "common.cpp":
+            extra = extra + [f'-DPMCE_BUILD_ID="{sid}"']
         cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(src, []), *extra, "-x", "hip", "-c", osp.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -1466,6 +1466,318 @@ __global__ __launch_bounds__(448) void vertex_sa2_kernel(const float* __restrict
 }
 
 // ======================================================================================================
+// vertex_sab - the attention half of the vertex stream's AdaLN Block in ONE launch (split mode; round 5):
+//   y = x + proj(softmax(q k^T / sqrt(32)) v),   [q | k | v] = Linear(64 -> 192)(AdaLN(x))      (CoevoDecoder.py:103, :118-131)
+// i.e. adaln_qkv_kernel<true> and vertex_sa(2)_kernel<true> without the [B,431,192] fp32 QKV round trip and without the second launch.
+// Phase 1: every wave runs AdaLN + the 64 -> 192 product (three-product f16 form, the weight's image of pmce_qkv_pack_f16) for two
+//   32-token tiles.  The accumulator layouts ARE the operand layouts of phase 2, so nothing is transposed or re-laid-out:
+//     q (swapped product, lane = token, slot order of the head's channels)  = the B fragments of S^T = K Q^T: split in registers;
+//     k (swapped product)                                                   = the A fragments of S^T (lane = key);
+//     v (operands exchanged: D[token][channel], lane = channel, r = key)     = the A fragments of O^T += V^T P^T (lane = channel, 8 keys).
+//   k and v leave as f16 (hi | lo) fragment planes - the bytes the staging waves of vertex_sa wrote into LDS - for a per-clip scratch
+//   (14 key tiles x 16 KB, written and read by this workgroup only: it never leaves the L2): the whole clip's keys do not fit in LDS
+//   beside the weight image (224 KB).  Every value is the one adaln_qkv + the staging of vertex_sa produce (same formulas, pinned to
+//   ONE fp32 value before it is split), so the result is bit-identical to the two-launch form (test_vertex_sab_*).
+// Phase 2: vertex_sa2's key loop; staging a key tile is now a plain 16 KB copy (no split arithmetic, all 7 waves share it).
+// QT = 2: one workgroup per clip, two query tiles per wave (B > 128).  QT = 1: two workgroups per clip, one query tile per wave; both
+//   compute all 14 key tiles (into their own scratch halves): at B <= 128 the second workgroup runs on a CU that would idle.
+// ======================================================================================================
+#define SAB_TILE_FLOATS 4096  // one key tile in scratch: K [32 keys][64 floats] then V^T [64 channels][32 floats]
+template <int QT>
+__global__ __launch_bounds__(448) void vertex_sab_kernel(const float* __restrict__ xin, const float* __restrict__ GB, int gb_stride, int inst,
+                                                         const float* __restrict__ qkv_img, const float* __restrict__ bqkv,
+                                                         const float* __restrict__ Wp, const float* __restrict__ bp, float* kvs,
+                                                         float* __restrict__ yout) {
+  constexpr int G = 2 / QT;  // workgroups per clip
+  __shared__ __attribute__((aligned(16))) float sW[192 * LDW64];  // phase 1: the qkv weight's f16 image; afterwards rows 0 .. 63: Wproj (fp32)
+  __shared__ __attribute__((aligned(16))) float sK[2][32 * SA_KLD];
+  __shared__ __attribute__((aligned(16))) float sVv[2][64 * SA_VTLD];
+  __shared__ __attribute__((aligned(16))) float sQ[QT == 2 ? 7 * 8 * 64 * 4 : 4];  // the second query tile's 8 q fragments per wave
+  __shared__ float sB[192];
+  __shared__ float sSc[2];
+  const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n0 = lane & 31, hb = lane >> 5;
+  for (int i = tid; i < 192 * LDW64 / 4; i += 448) reinterpret_cast<f32x4*>(sW)[i] = reinterpret_cast<const f32x4*>(qkv_img)[i];
+  if (tid < 2) sSc[tid] = qkv_img[192 * LDW64 + tid];
+  if (tid < 192) sB[tid] = bqkv[tid];
+  float* kvw = kvs + (size_t)(b * G + g) * (NTILE * SAB_TILE_FLOATS);  // this workgroup's scratch (plain pointer: written, then read)
+  const float* gb = GB + (long long)b * gb_stride + inst * 128;
+
+  // ---- phase 1 -----------------------------------------------------------------------------------------------------------
+  // one 32 x 32 tile of the 64 -> 192 product: nt = output channels 32 nt .. +31; exchanged = operands swapped (D[token][channel])
+  auto product = [&](const tl_f16x8(&ahi)[4], const tl_f16x8(&alo)[4], int nt, bool exchanged, f32x16& m, f32x16& c) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m[r] = c[r] = 0.f;
+    const float* w = sW + (nt * 32 + n0) * LDW64 + hb * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const tl_f16x8 whi = *reinterpret_cast<const tl_f16x8*>(w + s * 16), wlo = *reinterpret_cast<const tl_f16x8*>(w + s * 16 + 4);
+      if (!exchanged) {
+        m = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, ahi[s], m, 0, 0, 0);
+        m = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, ahi[s], m, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, alo[s], c, 0, 0, 0);
+      } else {
+        m = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s], whi, m, 0, 0, 0);
+        m = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s], wlo, m, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[s], whi, c, 0, 0, 0);
+      }
+    }
+  };
+  // AdaLN of key/query tile T (its 32 tokens, clamped at the clip's end) -> the product's activation fragments
+  auto activation = [&](const float* x, tl_f16x8(&ahi)[4], tl_f16x8(&alo)[4]) {
+    float a[32];
+    adaln_slots(x, a, gb, hb);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) split_slots8(a + 8 * s, ahi[s], alo[s]);
+  };
+  auto tok_of = [&](int T) {
+    const int v = T * 32 + n0;
+    return (long long)b * NV + (v < NV ? v : NV - 1);
+  };
+  // 32^-0.5 * log2(e) * 2^10 (vertex_sa_kernel<true>)
+  const float scale = 0.17677669529663688110f * 1.44269504088896340736f * 1024.0f;
+  tl_f16x8 qhi[2][2], qlo[2][2];  // query tile 0: [head][k-step]
+  tl_f16x8* sQw = reinterpret_cast<tl_f16x8*>(sQ) + wave * 8 * 64 + lane;  // (QT = 2) fragment f of this lane: sQw[f * 64]
+  // q of one tile from its activation fragments: t = 0 -> registers, t = 1 -> LDS
+  auto make_q = [&](const tl_f16x8(&ahi)[4], const tl_f16x8(&alo)[4], int t, float down) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x16 m, c;
+      product(ahi, alo, h, false, m, c);
+      float q[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = pinned(fmaf(fmaf(c[r], 0.00048828125f, m[r]), down, sB[h * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb]));  // = adaln_qkv's q
+        q[r] = pinned(v * scale);  // ONE fp32 value for both planes (common.hpp)
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (t == 0) {
+          split_slots8_plain(q + 8 * ks, qhi[h][ks], qlo[h][ks]);
+        } else {
+          tl_f16x8 fh, fl;
+          split_slots8_plain(q + 8 * ks, fh, fl);
+          sQw[((h * 2 + ks) * 2 + 0) * 64] = fh;
+          sQw[((h * 2 + ks) * 2 + 1) * 64] = fl;
+        }
+      }
+    }
+  };
+  {
+    float x0[32], x1[32];
+    load_slots(xin + tok_of(2 * wave) * 64, x0, hb);  // both tiles requested before the weight image's barrier
+    load_slots(xin + tok_of(2 * wave + 1) * 64, x1, hb);
+    __syncthreads();  // the weight image, sB, sSc
+    const float down = sSc[1];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int T = 2 * wave + t;
+      const bool tok_valid = T * 32 + n0 < NV;
+      tl_f16x8 ahi[4], alo[4];
+      activation(t == 0 ? x0 : x1, ahi, alo);
+      float* kt = kvw + (size_t)T * SAB_TILE_FLOATS;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x16 m, c;
+        product(ahi, alo, 2 + h, false, m, c);  // k: lane = key, registers = the head's channels in slot order
+        float kv_[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = pinned(fmaf(fmaf(c[r], 0.00048828125f, m[r]), down, sB[64 + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb]));
+          kv_[r] = tok_valid ? v : 0.f;  // keys beyond the clip: zero rows, as vertex_sa stages them (their scores are masked)
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          tl_f16x8 fh, fl;
+          split_slots8_plain(kv_ + 8 * ks, fh, fl);
+          float* d = kt + n0 * 64 + ((h * 2 + ks) * 2 + hb) * 8;
+          *reinterpret_cast<tl_f16x8*>(d) = fh;
+          *reinterpret_cast<tl_f16x8*>(d + 4) = fl;
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x16 m, c;
+        product(ahi, alo, 4 + h, true, m, c);  // v, operands exchanged: lane = channel 32 h + n0, register r = key (r & 3) + 8 (r >> 2) + 4 hb
+        const float bias = sB[128 + h * 32 + n0];
+        float vt_[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = pinned(fmaf(fmaf(c[r], 0.00048828125f, m[r]), down, bias));
+          vt_[r] = (T * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb < NV) ? v : 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          tl_f16x8 fh, fl;
+          split_slots8_plain(vt_ + 8 * ks, fh, fl);
+          float* d = kt + 2048 + (32 * h + n0) * 32 + (ks * 2 + hb) * 8;
+          *reinterpret_cast<tl_f16x8*>(d) = fh;
+          *reinterpret_cast<tl_f16x8*>(d + 4) = fl;
+        }
+      }
+      if (QT == 2) make_q(ahi, alo, t, down);
+    }
+    if (QT == 1) {  // this wave's query tile is in general not one of its two key tiles
+      float xq_[32];
+      load_slots(xin + tok_of(g * 7 + wave) * 64, xq_, hb);
+      tl_f16x8 ahi[4], alo[4];
+      activation(xq_, ahi, alo);
+      make_q(ahi, alo, 0, down);
+    }
+  }
+  __syncthreads();  // every key tile of the clip is in the scratch (and visible to the workgroup); the weight image is dead
+
+  // ---- phase 2: vertex_sa2_kernel's key loop ---------------------------------------------------------------------------------
+  float* sWp = sW;
+  stage_weight<64>(sWp, Wp, 64, tid, 448);
+  f32x4 pre[3];  // a key tile = 1024 float4 over 448 threads
+  auto gload = [&](int jt) {
+    const float* src = kvw + (size_t)jt * SAB_TILE_FLOATS;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int idx = tid + it * 448;
+      if (idx < 1024) pre[it] = *reinterpret_cast<const f32x4*>(src + 4 * idx);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int idx = tid + it * 448;
+      if (idx < 512) {
+        *reinterpret_cast<f32x4*>(&sK[buf][(idx >> 4) * SA_KLD + 4 * (idx & 15)]) = pre[it];
+      } else if (idx < 1024) {
+        const int i2 = idx - 512;
+        *reinterpret_cast<f32x4*>(&sVv[buf][(i2 >> 3) * SA_VTLD + 4 * (i2 & 7)]) = pre[it];
+      }
+    }
+  };
+  bool valid[QT];
+  long long tok[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int v = ((QT == 2 ? 2 * wave : g * 7 + wave) + t) * 32 + n0;
+    valid[t] = v < NV;
+    tok[t] = (long long)b * NV + (valid[t] ? v : NV - 1);
+  }
+  f32x16 O[QT][2];
+  float mrun[QT][2], lrun[QT][2], off[QT][2];
+#pragma unroll
+  for (int t = 0; t < QT; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      mrun[t][h] = -INFINITY;
+      lrun[t][h] = 0.f;
+      off[t][h] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[t][h][r] = 0.f;
+    }
+  constexpr float kQs = 0.0009765625f;
+  constexpr float kLazy = 8.0f * 1024.0f;
+  gload(0);
+  lstore(0);
+  if (NTILE > 1) gload(1);
+  __syncthreads();
+  for (int jt = 0; jt < NTILE; ++jt) {
+    const int buf = jt & 1;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      tl_f16x8 kf[2][2], vf[2][2];  // [k-step][hi | lo]
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const float* kp = &sK[buf][n0 * SA_KLD + ((h * 2 + ks) * 2 + hb) * 8];
+        kf[ks][0] = *reinterpret_cast<const tl_f16x8*>(kp);
+        kf[ks][1] = *reinterpret_cast<const tl_f16x8*>(kp + 4);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const float* vp = &sVv[buf][(32 * h + n0) * SA_VTLD + (ks * 2 + hb) * 8];
+        vf[ks][0] = *reinterpret_cast<const tl_f16x8*>(vp);
+        vf[ks][1] = *reinterpret_cast<const tl_f16x8*>(vp + 4);
+      }
+      if (h == 0) {
+        asm volatile("" ::: "memory");
+        if (jt + 1 < NTILE) lstore(buf ^ 1);
+        if (jt + 2 < NTILE) gload(jt + 2);
+      }
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const tl_f16x8 qh = t == 0 ? qhi[h][ks] : sQw[((h * 2 + ks) * 2 + 0) * 64];
+          const tl_f16x8 ql = t == 0 ? qlo[h][ks] : sQw[((h * 2 + ks) * 2 + 1) * 64];
+          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][0], qh, S, 0, 0, 0);
+          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][1], qh, S, 0, 0, 0);
+          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][0], ql, S, 0, 0, 0);
+        }
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
+          const float sv = (j < NV) ? S[r] : -INFINITY;
+          S[r] = sv;
+          mt = fmaxf(mt, sv);
+        }
+        if (__builtin_amdgcn_ballot_w64(mt > mrun[t][h] + kLazy) != 0) {
+          const float mn = fmaxf(mrun[t][h], pair_max(mt));
+          const float corr = __builtin_amdgcn_exp2f((mrun[t][h] - mn) * kQs);
+          mrun[t][h] = mn;
+          off[t][h] = fmaf(mn, -kQs, 6.0f);
+          lrun[t][h] *= corr;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) O[t][h][r] *= corr;
+        }
+        float pr[16], sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pr[r] = __builtin_amdgcn_exp2f(fmaf(S[r], kQs, off[t][h]));
+          sum += pr[r];
+        }
+        lrun[t][h] += sum;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          tl_f16x8 phi, plo;
+          split_slots8_plain(pr + 8 * ks, phi, plo);
+          O[t][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[ks][0], phi, O[t][h], 0, 0, 0);
+          O[t][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[ks][1], phi, O[t][h], 0, 0, 0);
+          O[t][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[ks][0], plo, O[t][h], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    float att[32];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float inv = 1.0f / pair_sum(lrun[t][h]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) att[16 * h + r] = O[t][h][r] * inv;
+    }
+    float x[32];
+    load_slots(xin + tok[t] * 64, x, hb);
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = bp[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb] + x[16 * nt + r];
+    tl_gemm<8, 2, LDW64>(sWp, att, acc, n0, hb);
+    if (valid[t]) {
+      float y[32];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[16 * nt + r] = acc[nt][r];
+      store_slots(yout + tok[t] * 64, y, hb);
+    }
+  }
+}
+
+// ======================================================================================================
 // tokens_kv (joint<-vertex direction, live in coevoblock3 only):
 //   kv[tok][0:64]   = Wk * AdaLN_k(xk) + bk     xk = proj_v2j_dim(vf) + v2j_K_embed   (CoevoDecoder.py:183)
 //   kv[tok][64:128] = Wv * AdaLN_v(xv) + bv     xv = vf
@@ -2006,6 +2318,22 @@ extern "C" int pmce_vertex_sa_ex_f32(const float* xin, const float* qkv, const f
 extern "C" int pmce_vertex_sa_f32(const float* xin, const float* qkv, const float* Wp, const float* bp, float* yout, int B,
                                   hipStream_t stream) {
   return pmce_vertex_sa_ex_f32(xin, qkv, Wp, bp, yout, B, 0, stream);
+}
+
+// The attention half of the vertex stream's AdaLN Block in one launch (split mode): AdaLN + qkv product + 431 x 431 attention + proj +
+// residual.  scratch: pmce_vertex_sab_scratch_floats(B) floats, 16-byte aligned (the clip's key tiles as f16 planes; contents are
+// meaningless outside the call).  qkv_img: pmce_qkv_pack_f16(Wqkv).
+extern "C" long long pmce_vertex_sab_scratch_floats(int B) { return (long long)B * (B > 128 ? 1 : 2) * NTILE * SAB_TILE_FLOATS; }
+extern "C" int pmce_vertex_sab_split_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* qkv_img,
+                                         const float* bqkv, const float* Wp, const float* bp, float* scratch, float* yout, int B,
+                                         hipStream_t stream) {
+  PMCE_REQUIRE(xin && GB && qkv_img && bqkv && Wp && bp && scratch && yout && B > 0, "vertex_sab: null pointer");
+  PMCE_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 15) == 0 && (reinterpret_cast<uintptr_t>(qkv_img) & 15) == 0, "vertex_sab: unaligned pointer");
+  if (B > 128)
+    hipLaunchKernelGGL(vertex_sab_kernel<2>, dim3(1, B), dim3(448), 0, stream, xin, GB, gb_stride, inst, qkv_img, bqkv, Wp, bp, scratch, yout);
+  else
+    hipLaunchKernelGGL(vertex_sab_kernel<1>, dim3(2, B), dim3(448), 0, stream, xin, GB, gb_stride, inst, qkv_img, bqkv, Wp, bp, scratch, yout);
+  return pmce_check_launch("vertex_sab");
 }
 
 extern "C" int pmce_tokens_kv_f32(const float* xk, const float* xv, const float* vt, const float* Wv3, const float* Ev,

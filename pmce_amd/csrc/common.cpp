@@ -38,3 +38,9 @@ int pmce_env_int(const char* name, int dflt) {
 
 extern "C" const char* pmce_last_error_string(void) { return g_err; }
 extern "C" int pmce_version(void) { return 100; }  // 0.1.0
+// sha256 (first 16 hex digits) over the sources this library was built from (pmce_amd/build.py source_id(), passed as a macro): what the
+// committed profiler summaries under profiles/ record, so that bench.py can tell counters of THIS build from stale ones
+#ifndef PMCE_BUILD_ID
+#define PMCE_BUILD_ID "unknown"
+#endif
+extern "C" const char* pmce_build_id(void) { return PMCE_BUILD_ID; }

@@ -74,37 +74,49 @@ int pmce_env_int(const char* name, int dflt);
 // so the output of one token-local GEMM is directly the B operand of the next: no LDS round trip.
 __device__ __forceinline__ int slot_channel(int s, int hb) { return 8 * (s >> 2) + 4 * hb + (s & 3); }
 
-// erf for the erf-GELU.  fp32 MFMA and fp32 VALU share the same FMA units on gfx950 (measured: both together deliver
-// LESS than MFMA alone, scripts/microbench/mfma_valu.hip), so every VALU instruction in an MFMA kernel's epilogue costs
-// matrix throughput.  ocml erff is 36 VALU instructions; this is Abramowitz-Stegun 7.1.26 on the hardware rcp/exp2: 14
-// instructions, max abs error 4.7e-7 over [-6,6] (fp32 ulp at 1 is 1.2e-7; torch's own fp32 GELU sits 4.5e-7 from fp64).
-__device__ __forceinline__ float erf_fast(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
-  return copysignf(fmaf(-p * t, e, 1.0f), x);
-}
-// The GELU of the path, one formula for every kernel and every template instantiation: each fused multiply-add is spelled out and
-// contraction is off, because hipcc's default (-ffp-contract=fast) fuses the SAME source differently from one instantiation to
-// the next - the split GEMM's packed-output form came out a 1-ulp different GELU than its fp32-output form, which shows as
-// different (hi, lo) planes and breaks "the result does not depend on which kernel a batch size selects".
+// The erf-GELU of the path (reference: nn.GELU() = x * Phi(x), exact-erf form), ONE formula for every kernel and every template
+// instantiation.  fp32 VALU work costs matrix throughput on gfx950 (fp32 MFMA and fp32 VALU share the FMA lanes:
+// scripts/microbench/mfma_valu.hip), and the decoder's FFN kernels are bound by their vector instructions, so the formula is counted
+// in issue cycles:
+//     gelu(x) = max(x, 0) - |x| * (erfc(|x| / sqrt 2) / 2),      erfc(|x| / sqrt 2) / 2 = 2^-(|x| * R(|x|) + 1)
+// with R a degree-7 polynomial fitted to -log2(erfc(a / sqrt 2)) / a on [0, 6] (weighted so that the error of the GELU, not of R, is
+// minimised; its leading coefficient is positive and a * R(a) keeps growing beyond the fit, so the tail term underflows to 0 for
+// every larger |x| and no clamp is needed).  9 FMAs + v_max + one transcendental (v_exp_f32) = 56 issue cycles per wave instruction
+// against the 84 of the form used until round 4 (Abramowitz-Stegun 7.1.26 on v_rcp + v_exp: 13 regular + 2 quarter-rate
+// instructions), and closer to the exact function: max abs error 2.5e-7 over [-12, 12] = half an ulp of the result at |x| = 4.5
+// (A-S: 3.8e-7; torch's own fp32 GELU sits 4.5e-7 from fp64), relative error of the negative tail 1.1e-5 instead of 2.2e-4 (no
+// 1 - erf cancellation: the tail is computed directly).  +-inf gives NaN (inf * 0), where torch gives inf / NaN: non-finite in,
+// non-finite out.  Fit and fp32 emulation: scripts/microbench/gelu_fit.py.
+// Each fused multiply-add is spelled out and contraction is off, because hipcc's default (-ffp-contract=fast) fuses the SAME source
+// differently from one instantiation to the next - the split GEMM's packed-output form once came out a 1-ulp different GELU than its
+// fp32-output form, which shows as different (hi, lo) planes and breaks "the result does not depend on which kernel a batch size
+// selects".
 __device__ __forceinline__ float gelu_erf(float x) {
 #pragma clang fp contract(off)
+#ifdef PMCE_AB_OLD_GELU  // A/B builds only (scripts/build_ab.sh): the round-4 formula
   const float z = x * 0.70710678118654752440f;
   const float az = fabsf(z);
-  const float t = __builtin_amdgcn_rcpf(fmaf(az, 0.3275911f, 1.0f));
-  float p = fmaf(t, 1.061405429f, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f((az * az) * -1.44269504088896340736f);
-  const float r = fmaf(-(p * t), e, 1.0f);
-  const float h = x * 0.5f;
-  return fmaf(h, copysignf(r, z), h);
+  const float tt = __builtin_amdgcn_rcpf(fmaf(az, 0.3275911f, 1.0f));
+  float pp = fmaf(tt, 1.061405429f, -1.453152027f);
+  pp = fmaf(pp, tt, 1.421413741f);
+  pp = fmaf(pp, tt, -0.284496736f);
+  pp = fmaf(pp, tt, 0.254829592f);
+  const float ee = __builtin_amdgcn_exp2f((az * az) * -1.44269504088896340736f);
+  const float rr = fmaf(-(pp * tt), ee, 1.0f);
+  const float hh = x * 0.5f;
+  return fmaf(hh, copysignf(rr, z), hh);
+#endif
+  const float a = fabsf(x);
+  float p = fmaf(2.05025208e-06f, a, -3.00662196e-05f);
+  p = fmaf(p, a, 0.000142456265f);
+  p = fmaf(p, a, 0.000240916706f);
+  p = fmaf(p, a, -0.00719628949f);
+  p = fmaf(p, a, 0.0525850132f);
+  p = fmaf(p, a, 0.459180683f);
+  p = fmaf(p, a, 1.15110803f);
+  const float t = fmaf(p, a, 1.0f);
+  const float e = __builtin_amdgcn_exp2f(-t);  // Phi(-|x|)
+  return fmaf(-a, e, fmaxf(x, 0.0f));
 }
 // two elements (the packed-fp32 form this once was is gone with -packed-fp32-ops)
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) { return f32x2{gelu_erf(x.x), gelu_erf(x.y)}; }

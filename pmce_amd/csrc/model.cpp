@@ -347,7 +347,8 @@ void carve_decoder(Carver& c, const pmce_model* m, int B, DecoderWs& w) {
   }
   w.F1 = c.take((size_t)B * NVC * D);
   w.F2 = c.take((size_t)B * NVC * D);
-  w.QKV = c.take((size_t)B * NVC * 3 * D);
+  // fp32 QKV [B,431,192] of the two-launch self-attention (fp32 pipe) or the fused kernel's key-tile scratch (pmce_vertex_sab_scratch_floats)
+  w.QKV = c.take(std::max((size_t)B * NVC * 3 * D, (size_t)pmce_vertex_sab_scratch_floats(B)));
   w.KVJ = c.take((size_t)B * NVC * 2 * D);
   w.FA = c.take((size_t)B * FINAL_K);
   w.JM = c.take((size_t)B * 32 * 3);
@@ -648,11 +649,19 @@ int vertex_block(pmce_model* m, int k, const float* vt_cur, float* vt_next, int 
     RUN(P_ADALN_MLP, pmce_adaln_mlp_pk_f32(w.F1, w.GB, gbs, ib + 3, v.vca_fc1_w, v.vca_fc1_b, v.vca_fc2_w, v.vca_fc2_b, w.F2, nullptr,
                                            nullptr, nullptr, nullptr, B, pkf(m), m->ffn_img[k - 1][0], stream));
   }
-  if (pkf(m) && m->qkv_img[k - 1])
+#ifdef PMCE_AB_NO_SAB  // A/B builds only: the two-launch form
+  if (pkf(m) && m->qkv_img[k - 1]) {
     RUN(P_ADALN_QKV, pmce_adaln_qkv_split_f32(w.F2, w.GB, gbs, ib + 4, m->qkv_img[k - 1], v.vsa_qkv_b, w.QKV, B, stream));
-  else
+    RUN(P_VERTEX_SA, pmce_vertex_sa_ex_f32(w.F2, w.QKV, v.vsa_proj_w, v.vsa_proj_b, w.F1, B, pkf(m), stream));
+  } else
+#endif
+  if (pkf(m) && m->qkv_img[k - 1]) {  // AdaLN + qkv + attention + proj + residual in one launch (coevo.hip vertex_sab)
+    RUN(P_VERTEX_SA, pmce_vertex_sab_split_f32(w.F2, w.GB, gbs, ib + 4, m->qkv_img[k - 1], v.vsa_qkv_b, v.vsa_proj_w, v.vsa_proj_b, w.QKV,
+                                               w.F1, B, stream));
+  } else {
     RUN(P_ADALN_QKV, pmce_adaln_qkv_f32(w.F2, w.GB, gbs, ib + 4, v.vsa_qkv_w, v.vsa_qkv_b, w.QKV, B, stream));
-  RUN(P_VERTEX_SA, pmce_vertex_sa_ex_f32(w.F2, w.QKV, v.vsa_proj_w, v.vsa_proj_b, w.F1, B, pkf(m), stream));
+    RUN(P_VERTEX_SA, pmce_vertex_sa_ex_f32(w.F2, w.QKV, v.vsa_proj_w, v.vsa_proj_b, w.F1, B, pkf(m), stream));
+  }
   RUN(P_ADALN_MLP, pmce_adaln_mlp_pk_f32(w.F1, w.GB, gbs, ib + 5, v.vsa_fc1_w, v.vsa_fc1_b,
                                          v.vsa_fc2_w, v.vsa_fc2_b, nullptr,
                                          v.vcoor_w, v.vcoor_b, vt_cur, vt_next, B, pkf(m), m->ffn_img[k - 1][1], stream));
@@ -1024,6 +1033,8 @@ int pmce_model_share_split_weights(pmce_model* dst, const pmce_model* src) {
   dst->split_gemm = true;
   dst->split_adopted = true;
   dst->oflow = src->oflow;  // lanes of one model report to one word
+  dst->strict_overflow = src->strict_overflow;  // ... and follow its policy and its small-batch threshold
+  dst->split_min_batch = src->split_min_batch;
   return PMCE_OK;
 }
 int pmce_model_overflowed(const pmce_model* m) {
@@ -1049,6 +1060,9 @@ int pmce_model_set_split_min_batch(pmce_model* m, int clips) {
   m->split_min_batch = clips;
   return PMCE_OK;
 }
+// the values in force (their defaults come from the environment at create time: a caller that changes one temporarily restores THIS)
+int pmce_model_get_split_min_batch(const pmce_model* m) { return m ? m->split_min_batch : -1; }
+int pmce_model_get_overflow_policy(const pmce_model* m) { return m ? (m->strict_overflow ? 1 : 0) : -1; }
 
 size_t pmce_model_workspace_bytes(const pmce_model* m, int batch) {
   if (!m || batch <= 0) return 0;

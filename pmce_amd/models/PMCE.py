@@ -66,21 +66,20 @@ class PMCE(HipModuleBase):
 
     @torch.no_grad()
     def forward(self, pose2d, img_feat):
-        mesh, pose, pose3d, _ = self._run(pose2d, img_feat, False)
+        """The reference's call (PMCE.py:15-20; ``model(pose2d, img_feat)`` at lib/core/base.py:222), under the module's overflow policy
+        (default "rerun": see HipModuleBase.set_overflow_policy)."""
+        mesh, pose, pose3d, _ = self._guarded(lambda eng: self._run(pose2d, img_feat, False, eng))
         return mesh, pose, pose3d
 
     @torch.no_grad()
     def forward_with_joints(self, pose2d, img_feat):
-        """(cam_mesh, cam_pose, pose3d, pred_pose_mm) — the forward plus the caller's tail of Tester.test."""
-        return self._run(pose2d, img_feat, True)
+        """(cam_mesh, cam_pose, pose3d, pred_pose_mm) - the forward plus the caller's tail of Tester.test; same overflow policy."""
+        return self._guarded(lambda eng: self._run(pose2d, img_feat, True, eng))
 
     @torch.no_grad()
     def forward_checked(self, pose2d, img_feat, want_joints: bool = False):
-        """``forward`` / ``forward_with_joints`` that WAITS for its result and never returns values spoilt by the f16 range: if a
-        product of the split-f16 form reported a non-finite value (possible only with non-finite inputs or with weights that drive an
-        intermediate activation beyond 65504), the batch is run again on the fp32 matrix pipe - the reference's own range - and the
-        word is cleared.  Returns (outputs, reran).  Non-finite INPUTS still give non-finite outputs for their clips, as in the
-        reference."""
+        """``forward`` / ``forward_with_joints`` with the "rerun" behaviour whatever the module's policy, saying whether it happened:
+        returns (outputs, reran)."""
         eng = self._ensure_packed()
         want = want_joints and eng.regressor_rows > 0
         out = self._run(pose2d, img_feat, want)
@@ -88,19 +87,9 @@ class PMCE(HipModuleBase):
         if not eng.overflowed():
             return (out if want_joints else out[:3]), False
         eng.clear_overflow()
-        out = self._run_on_f32_pipe(pose2d, img_feat, want, eng)
+        out = eng.run_on_f32_pipe(lambda e: self._run(pose2d, img_feat, want, e))
         torch.cuda.synchronize(eng.device)
         return (out if want_joints else out[:3]), True
-
-    def _run_on_f32_pipe(self, pose2d, img_feat, want, eng):
-        """One call of `eng` with every product on the fp32 matrix pipe (the planes stay packed: the threshold below which calls
-        stay on the fp32 pipe is raised above this batch for the duration of the call)."""
-        prev = eng.split_min_batch if eng.split_min_batch is not None else 1
-        eng.set_split_min_batch(int(pose2d.shape[0]) + 1)
-        try:
-            return self._run(pose2d, img_feat, want, eng)
-        finally:
-            eng.set_split_min_batch(prev)
 
     # benchmarking hooks
     def set_concurrency(self, enable=True):
@@ -117,9 +106,9 @@ class PMCE(HipModuleBase):
     def profile_read(self):
         return self._ensure_packed().profile_read()
 
-    def pipeline(self, depth: int = 2, stagger: bool = True) -> "Pipeline":
+    def pipeline(self, depth: int = 2, stagger: bool = True, on_overflow: str = "warn") -> "Pipeline":
         """Several batches in flight at once on shared weights; see :class:`Pipeline`."""
-        return Pipeline(self, depth, stagger)
+        return Pipeline(self, depth, stagger, on_overflow)
 
     def graphed(self, batch: int, want_joints: bool = True) -> "GraphedForward":
         """The forward for a fixed small batch captured once as a hipGraph; see :class:`GraphedForward`."""
@@ -190,15 +179,21 @@ class Pipeline:
                     t.record_stream(cur)
             return self.outputs
 
-    def __init__(self, model: "PMCE", depth: int = 2, stagger: bool = True):
+    def __init__(self, model: "PMCE", depth: int = 2, stagger: bool = True, on_overflow: str = "warn"):
+        """on_overflow: what :meth:`synchronize` does when a product reported a non-finite value - "warn" (default: name the batches),
+        "raise", or "rerun" (compute them again on the fp32 pipe into the same output tensors).  Only "rerun" keeps references to a
+        batch's INPUT tensors (the last 4 x depth submits) - the caller must then leave them unmodified until the next synchronize();
+        otherwise the pipeline holds the recent tickets weakly and retains nothing the caller has dropped."""
         self.stagger, self.prev = stagger, None
         if depth < 1:
             raise ValueError("depth must be >= 1")
-        self.model, self.depth = model, depth
+        if on_overflow not in ("warn", "raise", "rerun"):
+            raise ValueError("on_overflow must be 'warn', 'raise' or 'rerun'")
+        self.model, self.depth, self.on_overflow = model, depth, on_overflow
         self.engines, self.streams, self._main = [], [], None
         self.k = 0
         import collections
-        self._recent = collections.deque(maxlen=4 * depth)   # tickets a drain can still check / re-run (bounded: no leak in long loops)
+        self._recent = collections.deque(maxlen=4 * depth)   # tickets a drain can still check (weak references unless on_overflow == "rerun")
         self.reran = []                                       # indices of batches a drain re-ran on the fp32 pipe
         self._bind()
 
@@ -238,8 +233,10 @@ class Pipeline:
             img_feat.record_stream(st)
             done = torch.cuda.Event()
             done.record(st)
-        t = Pipeline.Ticket(out, done, self.k - 1, (pose2d, img_feat, want_joints), lane)
-        self._recent.append(t)
+        keep = self.on_overflow == "rerun"
+        t = Pipeline.Ticket(out, done, self.k - 1, (pose2d, img_feat, want_joints) if keep else None, lane)
+        import weakref
+        self._recent.append(t if keep else weakref.ref(t))
         return t
 
     def prepare(self, batch: int):
@@ -260,22 +257,27 @@ class Pipeline:
         self.prev = None
         return self
 
-    def synchronize(self, on_overflow: str = "rerun"):
-        """Wait for every lane, then poll the model's overflow word (nothing used to).  If a product reported a
-        non-finite value, the recent batches (the last 4 x depth submits) whose outputs are not finite are named in a warning
-        and - ``on_overflow="rerun"`` - computed again on the fp32 matrix pipe INTO THE SAME OUTPUT TENSORS; "warn" only
-        reports, "raise" raises PmceError.  The word is cleared either way (it is a report, not a lock)."""
+    def synchronize(self, on_overflow: str = None):
+        """Wait for every lane, then poll the model's overflow word.  If a product reported a non-finite value, the recent batches
+        (of the last 4 x depth submits, those whose tickets are still alive) whose outputs are not finite are named in a warning
+        ("warn"), or PmceError is raised ("raise"), or - "rerun", which the pipeline must have been CREATED with, because only then
+        does it hold the inputs - they are computed again on the fp32 matrix pipe INTO THE SAME OUTPUT TENSORS.  The word is cleared
+        either way (it is a report, not a lock).  Returns the indices of the named batches."""
+        on_overflow = on_overflow or self.on_overflow
+        if on_overflow == "rerun" and self.on_overflow != "rerun":
+            raise ValueError("Pipeline.synchronize(on_overflow='rerun') needs a pipeline created with on_overflow='rerun' (it holds no inputs otherwise)")
         for st in self.streams:
             st.synchronize()
         main = self._main
         if main is None or not main.overflowed():
             self._recent.clear()
             return []
-        bad = [t for t in self._recent if not all(bool(torch.isfinite(o).all()) for o in t.outputs if o is not None)]
+        recent = [t for t in ((r if isinstance(r, Pipeline.Ticket) else r()) for r in self._recent) if t is not None]
+        bad = [t for t in recent if not all(bool(torch.isfinite(o).all()) for o in t.outputs if o is not None)]
         main.clear_overflow()
         names = [t.index for t in bad]
         msg = (f"pmce_amd.Pipeline: a product of the split-f16 form produced non-finite values; batches {names} of the last "
-               f"{len(self._recent)} submits hold non-finite outputs" + ("" if bad else " (none of the recent ones: an earlier batch)"))
+               f"{len(recent)} live tickets hold non-finite outputs" + ("" if bad else " (none of those: an earlier or already dropped batch)"))
         if on_overflow == "raise":
             self._recent.clear()
             raise _lib.PmceError(msg)
@@ -284,7 +286,7 @@ class Pipeline:
             for t in bad:
                 p2, f, want = t.inputs
                 eng = self.engines[t.lane]
-                new = self.model._run_on_f32_pipe(p2, f, want and eng.regressor_rows > 0, eng)
+                new = eng.run_on_f32_pipe(lambda e: self.model._run(p2, f, want and e.regressor_rows > 0, e))
                 for dst, src in zip(t.outputs, new):
                     if dst is not None:
                         dst.copy_(src)

@@ -292,6 +292,23 @@ def vertex_self_attn(x, g, sd, p, split_f16=False):
     return y, qkv
 
 
+def vertex_self_attn_fused(x, g, sd, p):
+    """The same (split_f16 form) in ONE launch - AdaLN + qkv product + attention + proj + residual (pmce_vertex_sab_split_f32, what a
+    model in split_f16 mode runs); bit-identical to vertex_self_attn(..., split_f16=True)."""
+    lib = _lib.load()
+    x = _c(x)
+    B = x.shape[0]
+    GB = adaln_params(g, sd, [p + ".norm1"])
+    img = torch.empty(lib.pmce_qkv_image_floats(), device=x.device)
+    _lib.check(lib.pmce_qkv_pack_f16(P(_c(sd[p + ".attn.qkv.weight"])), P(img), _st()), "qkv_pack_f16")
+    scratch = torch.empty(lib.pmce_vertex_sab_scratch_floats(B), device=x.device)
+    y = torch.empty_like(x)
+    _lib.check(lib.pmce_vertex_sab_split_f32(P(x), P(GB), GB.shape[1], 0, P(img), P(_c(sd[p + ".attn.qkv.bias"])),
+                                             P(_c(sd[p + ".attn.proj.weight"])), P(_c(sd[p + ".attn.proj.bias"])), P(scratch), P(y), B,
+                                             _st()), "vertex_sab")
+    return y
+
+
 def joint_stream(xq, xk, xv, g, sd, blk, stage, jt=None):
     """Joint stream of a CoevoBlock given explicit q/k/v token sets (xq[B,J,64], xk/xv[B,431,64]):
     stage 1 = xq + CA (CoevoDecoder.py:83), 2 = + FFN (:85-86), 3 = + joint_SA_FFN (:187) (+ coords if jt)."""

@@ -52,7 +52,6 @@ class HipEngine:
         self.ws_batch = 0
         self.device = None
         self.regressor_rows = 0
-        self.split_min_batch = None
         self.split_arena = None      # torch memory holding the f16 planes (kept alive here; lanes keep the owner's)
         self._finalized = False
 
@@ -99,16 +98,15 @@ class HipEngine:
 
     def clone_shared(self) -> "HipEngine":
         """A second handle on the SAME packed weights (no copy): its own workspace, side stream and events, so that two
-        forwards can be in flight at once (models.PMCE.Pipeline)."""
+        forwards can be in flight at once (models.PMCE.Pipeline).  The lane inherits the owner's overflow policy and small-batch
+        threshold (pmce_model_share_split_weights copies both, whatever set them - API or environment)."""
         other = HipEngine(self.J, self.C, self.depth)
         other.set_gemm_mode(self.gemm_mode())
-        if self.split_min_batch is not None:
-            other.set_split_min_batch(self.split_min_batch)
-        other.split_min_batch = self.split_min_batch
-        other.set_overflow_policy(getattr(self, "strict_overflow", False))
-        other.strict_overflow = getattr(self, "strict_overflow", False)
         other.register(self.packed)
         _lib.check(other.lib.pmce_model_share_split_weights(other.handle, self.handle), "model_share_split_weights")
+        if self.gemm_mode() != "split_f16":     # (nothing to share on the fp32 pipe: copy the two settings by hand)
+            other.set_split_min_batch(self.get_split_min_batch())
+            other.set_overflow_policy(self.strict_overflow)
         if self.regressor_rows:
             _lib.check(other.lib.pmce_model_set_regressor_rows(other.handle, self.regressor_rows), "set_regressor_rows")
             other.regressor_rows = self.regressor_rows
@@ -153,6 +151,10 @@ class HipEngine:
     def set_split_min_batch(self, clips: int):
         _lib.check(self.lib.pmce_model_set_split_min_batch(self.handle, int(clips)), "model_set_split_min_batch")
 
+    def get_split_min_batch(self) -> int:
+        """The threshold in force (its default comes from PMCE_SPLIT_MIN_BATCH at create time)."""
+        return int(self.lib.pmce_model_get_split_min_batch(self.handle))
+
     def overflowed(self) -> bool:
         """A product of the split-f16 form produced a non-finite value in a completed call (non-finite inputs, an intermediate
         activation beyond f16's 65504 under exotic weights, or fp32 overflow): the affected clips' outputs are inf / nan.  The word
@@ -163,8 +165,24 @@ class HipEngine:
     def set_overflow_policy(self, strict: bool):
         _lib.check(self.lib.pmce_model_set_overflow_policy(self.handle, 1 if strict else 0), "model_set_overflow_policy")
 
+    @property
+    def strict_overflow(self) -> bool:
+        """The C-side policy in force (its default comes from PMCE_STRICT_OVERFLOW at create time)."""
+        return self.lib.pmce_model_get_overflow_policy(self.handle) == 1
+
     def clear_overflow(self):
         _lib.check(self.lib.pmce_model_clear_overflow(self.handle), "model_clear_overflow")
+
+    def run_on_f32_pipe(self, launch):
+        """launch(self) with every product on the fp32 matrix pipe - the reference's own range - while the f16 planes stay packed: the
+        threshold below which calls stay on the fp32 pipe is raised above any batch for the duration of the call and RESTORED to the
+        value that was in force (also when that came from the environment)."""
+        prev = self.get_split_min_batch()
+        self.set_split_min_batch(1 << 30)
+        try:
+            return launch(self)
+        finally:
+            self.set_split_min_batch(prev)
 
     def set_concurrency(self, enable: bool):
         _lib.check(self.lib.pmce_model_set_concurrency(self.handle, 1 if enable else 0), "model_set_concurrency")
@@ -200,6 +218,8 @@ class HipModuleBase(nn.Module):
         self._dirty = True
         self._gemm_mode = None   # None = the library's default (split_f16 unless PMCE_SPLIT_F16=0)
         self._split_min_batch = None
+        self._overflow_policy = None   # None = "rerun" (or "strict" under PMCE_STRICT_OVERFLOW=1): see set_overflow_policy
+        self.overflow_reruns = 0       # calls that were computed again on the fp32 pipe under the "rerun" policy
 
     def set_gemm_mode(self, mode, min_batch=None):
         """Arithmetic of the large products (min_batch: calls with fewer clips stay on the fp32 pipe, default 1 = none): 'split_f16' (three f16 products per fp32 product on the f16 matrix
@@ -227,24 +247,63 @@ class HipModuleBase(nn.Module):
     def overflowed(self, synchronize: bool = True) -> bool:
         """True if a product of a call on this module produced a non-finite value: non-finite INPUTS (they propagate into the
         outputs of their own clip, as in the reference), an intermediate activation beyond f16's range under exotic weights, or
-        fp32 overflow.  Finite inputs of any magnitude are in range (img_feat is row-scaled before its products).  The word only
-        reports; the affected clips' outputs are inf / nan, other clips and later calls are unaffected.
-        ``set_overflow_policy(strict=True)`` makes further forwards raise PmceError until :meth:`clear_overflow`;
-        ``PMCE.forward_checked`` re-runs an offending batch on the fp32 pipe; ``set_gemm_mode('f32')`` has fp32's range throughout."""
+        fp32 overflow.  Finite inputs of any magnitude are in range (img_feat is row-scaled before its products).  Under the default
+        policy ("rerun") ``forward`` has already dealt with it and cleared the word; under "report" the affected clips' outputs are
+        inf / nan, other clips and later calls are unaffected; see :meth:`set_overflow_policy`."""
         eng = self._ensure_packed()
         if synchronize:
             torch.cuda.synchronize(eng.device)
         return eng.overflowed()
 
-    def set_overflow_policy(self, strict: bool = False):
-        """strict=True: while the overflow word is set every further call raises (round-3 behaviour); default: report only."""
-        self._strict_overflow = bool(strict)
-        eng = self._ensure_packed()
-        eng.set_overflow_policy(self._strict_overflow)
-        eng.strict_overflow = self._strict_overflow
+    OVERFLOW_POLICIES = ("rerun", "report", "strict")
+
+    def set_overflow_policy(self, policy="rerun"):
+        """What ``forward`` (and ``forward_with_joints``) do about the one error mode the split-f16 arithmetic has and the reference
+        lacks - an intermediate activation beyond f16's 65504, possible only with weights that drive a LayerNorm / attention / GELU /
+        GRU output there:
+
+        * ``"rerun"`` (default): the call waits for its result on the current stream, polls the model's overflow word and, if a product
+          reported a non-finite value, computes the batch again on the fp32 matrix pipe (the reference's own range) and clears the
+          word: the caller of ``model(pose2d, img_feat)`` (lib/core/base.py:222) never sees a value the reference would not have
+          produced.  (Non-finite INPUTS still give non-finite outputs for their own clips, as in the reference.)  The wait costs the
+          launch-ahead of back-to-back calls; throughput loops use ``Pipeline`` or ``"report"``.
+        * ``"report"``: fully asynchronous calls; the word only reports (``overflowed()``, ``Pipeline.synchronize``, the evaluator).
+        * ``"strict"``: as "report", and while the word is set every further call raises PmceError until :meth:`clear_overflow`.
+
+        Booleans are accepted for the round-4 meaning (True = "strict", False = "report")."""
+        if policy is True:
+            policy = "strict"
+        elif policy is False:
+            policy = "report"
+        if policy not in self.OVERFLOW_POLICIES:
+            raise ValueError(f"overflow policy must be one of {self.OVERFLOW_POLICIES}")
+        self._overflow_policy = policy
+        self._ensure_packed().set_overflow_policy(policy == "strict")
+
+    def overflow_policy(self) -> str:
+        if self._overflow_policy is None:        # default: the environment's strict switch, else "rerun"
+            import os
+            self._overflow_policy = "strict" if os.environ.get("PMCE_STRICT_OVERFLOW", "0") not in ("", "0") else "rerun"
+        return self._overflow_policy
 
     def clear_overflow(self):
         self._ensure_packed().clear_overflow()
+
+    def _guarded(self, launch, eng=None):
+        """launch(engine) -> outputs, under the module's overflow policy (see set_overflow_policy)."""
+        eng = eng or self._ensure_packed()
+        out = launch(eng)
+        if self.overflow_policy() != "rerun" or eng.gemm_mode() != "split_f16" or torch.cuda.is_current_stream_capturing():
+            return out
+        st = torch.cuda.current_stream(eng.device)
+        st.synchronize()
+        if not eng.overflowed():
+            return out
+        eng.clear_overflow()
+        out = eng.run_on_f32_pipe(launch)
+        st.synchronize()
+        self.overflow_reruns += 1
+        return out
 
     # any change of the parameters' storage invalidates the packed copy
     def _apply(self, fn, *a, **k):
@@ -275,10 +334,8 @@ class HipModuleBase(nn.Module):
                 self._engine.set_gemm_mode(self._gemm_mode)
             if self._split_min_batch is not None:
                 self._engine.set_split_min_batch(self._split_min_batch)
-                self._engine.split_min_batch = self._split_min_batch
-            if getattr(self, "_strict_overflow", False):
-                self._engine.set_overflow_policy(True)
-                self._engine.strict_overflow = True
+            if self._overflow_policy is not None:
+                self._engine.set_overflow_policy(self._overflow_policy == "strict")
             self._dirty = False
         return self._engine
 

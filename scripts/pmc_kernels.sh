@@ -1,5 +1,6 @@
 #!/bin/bash
-# PMC counters for selected kernels of the forward (one pass per counter group); usage: pmc_kernels.sh "regex"
+# PMC counters for selected kernels of the forward (one pass per counter group); usage: [PMCE_PMC_C=256] pmc_kernels.sh "regex"
+# summary (with the build id of the library the counters belong to): gpurun_out/kpmc/summary.json
 set -u
 pat=${1:-vertex_ca}
 export TMPDIR=/tmp
@@ -33,6 +34,11 @@ for k in sorted(agg):
         d["mfma_busy_fraction"] = round((d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024) / (d["GRBM_GUI_ACTIVE"] / 8), 4)
         print(f"    -> matrix pipe busy {100 * d['mfma_busy_fraction']:.1f} % of the kernel's cycles")
     out[k] = d
+import sys
+sys.path.insert(0, os.getcwd())
+from pmce_amd import build as _b
+out["_meta"] = {"build_id": _b.source_id(), "embed_dim": int(os.environ.get("PMCE_PMC_C", "512")),
+                "command": "bench.py --embed-dim C --steps 1 --warmup 1 --windows 1 --single-stream under rocprofv3 --pmc <group> --kernel-trace (one pass per group)"}
 json.dump(out, open("gpurun_out/kpmc/summary.json", "w"), indent=1)
 PY
 find gpurun_out/kpmc -name "*.csv" -size +4M -delete

@@ -27,4 +27,8 @@ for n in sorted(set(out["FETCH_SIZE"]) | set(out["WRITE_SIZE"])):
         continue
     print(f"{n:60s} {f[1]:5d} {f[0]:14.1f} {w[0]:14.1f}")
     res[n] = {"launches": f[1], "fetch_kib_raw": f[0], "write_kib": w[0]}
+# which build these counters belong to (bench.py flags the file as stale when the loaded library's id differs)
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from pmce_amd import build as _b
+res["_meta"] = {"build_id": _b.source_id(), "passes": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs, kernel-trace only), KiB per launch"}
 json.dump(res, open(out_path, "w"), indent=1)

@@ -446,6 +446,36 @@ def test_vertex_self_attn_two_query_tiles_per_wave_is_bit_identical():
         assert torch.equal(y_big[lo:lo + 4], y_small), lo
 
 
+def test_vertex_self_attn_fused_is_bit_identical_to_the_two_launch_form(golden):
+    """Round 5: a model in split_f16 mode runs AdaLN + qkv + attention + proj + residual as ONE launch (vertex_sab): q, k, v leave the
+    qkv product's accumulators in the attention's operand layouts and k / v pass through a scratch as f16 planes.  Every value is the
+    one the two-launch form computes, so the result is the same bit for bit - in both grid forms (two workgroups per clip up to
+    B = 128, one beyond), which also makes a clip independent of the batch it came in - and it matches the oracle."""
+    from oracle import pmce_oracle as O
+    from pmce_amd import ops
+    sd = cached_state_dict(17, 256)
+    p = BLK + ".vertx_SA_FFN"
+    sdd = sd_dev(sd, p)
+    g1, xv, _ = _mod_inputs()
+    y = ops.vertex_self_attn_fused(xv.to(dev()), g1.to(dev()), sdd, p)
+    with torch.no_grad():
+        a = O.ada_layer_norm(xv, g1, sd, p + ".norm1", torch.float32)
+        ref = xv + O.self_attention(a, sd, p + ".attn", 2, torch.float32)
+    e = maxabs(y, ref)
+    print(f"vertex_sab vs oracle {e:.2e}")
+    assert e < 2e-5
+    y2, _ = ops.vertex_self_attn(xv.to(dev()), g1.to(dev()), sdd, p, split_f16=True)
+    assert torch.equal(y, y2)
+    B = 131
+    g, x = rnd("sa2.g", (B, 2048), 0.8).to(dev()), rnd("sa2.x", (B, 431, 64), 1.5).to(dev())
+    y_big = ops.vertex_self_attn_fused(x, g, sdd, p)                 # one workgroup per clip, two query tiles per wave
+    y_two, _ = ops.vertex_self_attn(x, g, sdd, p, split_f16=True)
+    assert torch.equal(y_big, y_two)
+    for lo in (0, 64, 127):
+        y_small = ops.vertex_self_attn_fused(x[lo:lo + 4].contiguous(), g[lo:lo + 4].contiguous(), sdd, p)   # two workgroups per clip
+        assert torch.equal(y_big[lo:lo + 4], y_small), lo
+
+
 @pytest.mark.parametrize("stage", [1, 2, 3])
 def test_joint_stream(golden, stage):
     from oracle import pmce_oracle as O
