@@ -300,14 +300,25 @@ int pmce_div_scalar_f32(const float* x, float* y, long long n, float denom, pmce
 
 /* CoevoDecoder.py:232 — vertxs[b][v][:] = joints[b][vj[v]][:]; vj int32[431].  Bit-exact copy. */
 int pmce_vertex_init_gather_f32(const float* joints, const int* vj, float* vt, int B, int J, pmce_stream_t stream);
-/* CoevoDecoder.py:177-180,184 — jf = joint_proj(jt)+joint_pos_embed; xk = proj_j2v_dim(jf)+j2v_K_embed. */
-int pmce_joint_embed_f32(const float* jt, const float* Wj, const float* bj, const float* jpos, const float* Wj2v,
-                         const float* bj2v, const float* j2vK, float* jf, float* xk, int B, int J, pmce_stream_t stream);
 /* Key/value side of the vertex<-joint CrossAttention (CoevoDecoder.py:47-62,83) with Wq / proj folded in:
  * GB[b][inst*128 + (gamma 0..63 | beta 64..127)] are the AdaLN parameters; Kf,Vf [B,64,64], s0 [B,64]. */
 int pmce_ca_fold_f32(const float* xk, const float* xv, const float* GB, int gb_stride, int iq, int ik, int iv,
                      const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv, const float* bv,
                      const float* Wp, float* Kf, float* s0, float* Vf, int B, int J, pmce_stream_t stream);
+/* The same, also (img != NULL, J <= 23) writing the operands as the LDS image pmce_vertex_ca_mlp_pk_f32's split_f16 form copies: per clip
+ * pmce_ca_image_floats() floats - s0, two scales, Kf and Vf as (hi | lo) f16 fragment planes scaled by one power of two each.  Kf / s0 / Vf may
+ * each be NULL when only the image is wanted. */
+int pmce_ca_image_floats(void);
+int pmce_ca_fold_img_f32(const float* xk, const float* xv, const float* GB, int gb_stride, int iq, int ik, int iv,
+                         const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv, const float* bv,
+                         const float* Wp, float* Kf, float* s0, float* Vf, float* img, int B, int J, pmce_stream_t stream);
+/* The joint side of a CoevoBlock in ONE launch (what the model runs): the joint embedding of CoevoDecoder.py:177-180,184 -
+ * jf = joint_proj(jt) + joint_pos_embed, xk = proj_j2v_dim(jf) + j2v_K_embed, xv = jf - followed by the fold above.  jf_out [B,J,64] may be
+ * NULL (only the block-3 joint stream reads it). */
+int pmce_joint_prep_f32(const float* jt, const float* Wj, const float* bj, const float* jpos, const float* Wj2v, const float* bj2v,
+                        const float* j2vK, float* jf_out, const float* GB, int gb_stride, int iq, int ik, int iv, const float* Wq,
+                        const float* bq, const float* Wk, const float* bk, const float* Wv, const float* bv, const float* Wp,
+                        float* Kf, float* s0, float* Vf, float* img, int B, int J, pmce_stream_t stream);
 /* THE north-star kernel: fused AdaLN + vertex<-joint cross-attention + residual for 431 query tokens
  * (first line of CrossAttentionBlock.forward, CoevoDecoder.py:83).  xq[B,431,64], or xq == NULL and
  * xq := Wv3*vt + Eq formed on the fly from vt[B,431,3]. */
@@ -327,19 +338,12 @@ int pmce_vertex_ca_mlp_f32(const float* xq, const float* vt, const float* Wv3, c
                            const float* s0, const float* Vf, const float* bp, const float* GB, int gb_stride, int inst,
                            const float* W1, const float* b1, const float* W2, const float* b2, float* yout, float* scratch,
                            int B, int J, pmce_stream_t stream);
-/* _ex forms of the two FFN-carrying kernels: split_f16 != 0 runs the 64->256->64 FFN in the three-product f16 form (weights split
- * into f16 planes while they are staged into LDS, activations split in registers; fp32 accumulate, fp32 results) - only for calls
- * that do not overlap other kernels. */
-int pmce_adaln_mlp_ex_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* W1, const float* b1,
-                          const float* W2, const float* b2, float* yout, const float* Wc, const float* bc, const float* vt_in,
-                          float* vt_out, int B, int split_f16, pmce_stream_t stream);
-int pmce_vertex_ca_mlp_ex_f32(const float* xq, const float* vt, const float* Wv3, const float* Eq, const float* Kf,
-                              const float* s0, const float* Vf, const float* bp, const float* GB, int gb_stride, int inst,
-                              const float* W1, const float* b1, const float* W2, const float* b2, float* yout, float* scratch,
-                              int B, int J, int split_f16, pmce_stream_t stream);
-/* _pk forms: with split_f16 != 0 and ffn_img != NULL every workgroup COPIES the FFN's f16 form into LDS from an image made once
- * (pmce_ffn_pack_f16 from the same W1 [256,64] / W2 [64,256]: pmce_ffn_image_floats() floats, 16-byte aligned) instead of converting
- * W1 / W2 itself; the same bits as the _ex forms (ffn_img == NULL is exactly those).  pmce_model_finalize makes the six images. */
+/* _pk forms of the two FFN-carrying kernels.  split_f16 != 0 runs the 64->256->64 FFN in the three-product f16 form (activations split in
+ * registers; fp32 accumulate, fp32 results); ffn_img != NULL: every workgroup COPIES the FFN's f16 planes into LDS (LDS-DMA) from an image
+ * made once (pmce_ffn_pack_f16 from the same W1 [256,64] / W2 [64,256]: pmce_ffn_image_floats() floats, 16-byte aligned) instead of converting
+ * W1 / W2 itself - the same bits; pmce_model_finalize makes the six images.  pmce_vertex_ca_mlp_pk_f32 with split_f16 != 0 also runs the
+ * cross-attention's two contractions in that form and REQUIRES ca_img = the folded operands' image of pmce_ca_fold_img_f32 /
+ * pmce_joint_prep_f32 (Kf / s0 / Vf are then not read); J > 23 takes the two-launch form through `scratch` (fp32 attention from Kf / s0 / Vf). */
 int pmce_ffn_image_floats(void);
 int pmce_ffn_pack_f16(const float* W1, const float* W2, float* ffn_img, pmce_stream_t stream);
 int pmce_adaln_mlp_pk_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* W1, const float* b1,
@@ -348,7 +352,7 @@ int pmce_adaln_mlp_pk_f32(const float* xin, const float* GB, int gb_stride, int 
 int pmce_vertex_ca_mlp_pk_f32(const float* xq, const float* vt, const float* Wv3, const float* Eq, const float* Kf,
                               const float* s0, const float* Vf, const float* bp, const float* GB, int gb_stride, int inst,
                               const float* W1, const float* b1, const float* W2, const float* b2, float* yout, float* scratch,
-                              int B, int J, int split_f16, const float* ffn_img, pmce_stream_t stream);
+                              int B, int J, int split_f16, const float* ffn_img, const float* ca_img, pmce_stream_t stream);
 
 /* qkv = Linear(64->192)(AdaLN(x)) on [B,431,64] (CoevoDecoder.py:103,120). */
 int pmce_adaln_qkv_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* Wqkv, const float* bqkv,

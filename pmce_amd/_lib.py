@@ -84,16 +84,16 @@ PROTOTYPES = {
     "pmce_gru_step_split_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _l, _l, _i, _i, _i, _s],
     "pmce_div_scalar_f32": [_f, _f, _l, _fl, _s],
     "pmce_vertex_init_gather_f32": [_f, _f, _f, _i, _i, _s],
-    "pmce_joint_embed_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],
+    "pmce_ca_image_floats": [],
+    "pmce_ca_fold_img_f32": [_f, _f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],
+    "pmce_joint_prep_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],
     "pmce_ca_fold_f32": [_f, _f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],
     "pmce_vertex_ca_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],
     "pmce_adaln_mlp_f32": [_f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _s],
-    "pmce_adaln_mlp_ex_f32": [_f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],
-    "pmce_vertex_ca_mlp_ex_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _s],
     "pmce_ffn_image_floats": [],
     "pmce_ffn_pack_f16": [_f, _f, _f, _s],
     "pmce_adaln_mlp_pk_f32": [_f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f, _s],
-    "pmce_vertex_ca_mlp_pk_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _s],
+    "pmce_vertex_ca_mlp_pk_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _s],
     "pmce_vertex_ca_mlp_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _s],
     "pmce_adaln_qkv_f32": [_f, _f, _i, _i, _f, _f, _f, _i, _s],
     "pmce_qkv_image_floats": [],

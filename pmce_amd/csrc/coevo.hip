@@ -129,38 +129,11 @@ __device__ __forceinline__ void adaln_small8(const float* in, float* out, const 
 }
 
 // ======================================================================================================
-// joint_embed: jf[b][i][:] = Wj*jt + bj + jpos[i] ; xk[b][i][:] = Wj2v*jf + bj2v + j2vK[i]
-// ======================================================================================================
-__global__ __launch_bounds__(JS_THREADS) void joint_embed_kernel(const float* __restrict__ jt, const float* __restrict__ Wj,
-                                                                 const float* __restrict__ bj, const float* __restrict__ jpos,
-                                                                 const float* __restrict__ Wj2v, const float* __restrict__ bj2v,
-                                                                 const float* __restrict__ j2vK, float* __restrict__ jf,
-                                                                 float* __restrict__ xk, int J) {
-  __shared__ float s_jf[32 * JLD];
-  __shared__ float s_xk[32 * JLD];
-  __shared__ __attribute__((aligned(16))) float s_w[64 * JWL];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  JTile pre;
-  jtile_fetch(pre, Wj2v, 64, 0, 0, tid);
-  for (int idx = tid; idx < J * 64; idx += JS_THREADS) {
-    const int i = idx >> 6, c = idx & 63;
-    const float* p = jt + ((long long)b * J + i) * 3;
-    const float v = ((Wj[c * 3] * p[0] + Wj[c * 3 + 1] * p[1] + Wj[c * 3 + 2] * p[2]) + bj[c]) + jpos[i * 64 + c];
-    s_jf[i * JLD + c] = v;
-    jf[((long long)b * J + i) * 64 + c] = v;
-  }
-  lin_tiled<64, 64>(s_jf, JLD, Wj2v, bj2v, s_xk, JLD, J, tid, false, s_w, pre, nullptr, 0);
-  __syncthreads();
-  for (int idx = tid; idx < J * 64; idx += JS_THREADS) {
-    const int i = idx >> 6, c = idx & 63;
-    xk[((long long)b * J + i) * 64 + c] = s_xk[i * JLD + c] + j2vK[i * 64 + c];
-  }
-}
-
-// ======================================================================================================
-// ca_fold: per clip, fold the query/output projections of the vertex<-joint cross-attention into its (tiny)
-// key/value side.  With a = gamma_q*n + beta_q (n = normalised query token), k = Wk*AdaLN_k(xk)+bk,
-// v = Wv*AdaLN_v(xv)+bv, head h = channels [32h,32h+32):
+// ca_fold (joint_prep): per clip, the joint side of a CoevoBlock's vertex<-joint cross-attention.
+//  (a) embed form (jt != null; CoevoDecoder.py:177-180,184): jf = joint_proj(jt) + joint_pos_embed ; xk = proj_j2v_dim(jf) + j2v_K_embed ;
+//      xv = jf.  (Until round 5 a launch of its own, joint_embed; jf is written out only where the joint stream needs it.)
+//  (b) fold: the query/output projections folded into the (tiny) key/value side.  With a = gamma_q*n + beta_q (n = normalised query
+//      token), k = Wk*AdaLN_k(xk)+bk, v = Wv*AdaLN_v(xv)+bv, head h = channels [32h,32h+32):
 //   score[h][i] = scale * (Wq a + bq)_h . k_i,h  =  n . Kf[h*32+i][:] + s0[h*32+i]
 //   out         = sum_h P_h (v_h Wp_h^T) + bp     =  Vf[:, h*32+i] P[h*32+i] + bp
 //   Kf[h*32+i][c] = scale*gamma_q[c]*M ; s0 = scale*(sum_c beta_q[c]*M + bq_h.k_i,h) ; M = sum_d Wq[32h+d][c]*k_i[32h+d]
@@ -168,49 +141,89 @@ __global__ __launch_bounds__(JS_THREADS) void joint_embed_kernel(const float* __
 // Rows/columns i >= J are zero (masked to -inf in vertex_ca).  Algebraically identical to
 // CrossAttention.forward (CoevoDecoder.py:47-62) after AdaLN (:83); only the summation order differs.
 // gbq/gbk/gbv: this clip's [gamma|beta] (128 floats) of normq/normk/normv.
+//  (c) image (img != null, J <= 23; round 5): the same operands as the LDS image vertex_ca_mlp's f16 form copies - per clip
+//      [s0 (64) | 2^-sK 2^-10, 2^-sV 2^-10, 0, 0 | Kf rows (h, i < J) as (hi | lo) f16 A fragments of Kf * 2^sK, stage_weight_split's row
+//      format | Vf rows c as (hi | lo) fragments of Vf * 2^sV over the keys: per head k-step 0 (keys 0 .. 15: 2 lane halves x (8 hi | 8 lo))
+//      then k-step 1 (keys 16 .. 23: 2 lane halves x (4 hi | 4 lo))], one power of two per operand and clip (max |.| -> [2^14, 2^15)).
 // ======================================================================================================
-__global__ __launch_bounds__(JS_THREADS) void ca_fold_kernel(const float* __restrict__ xk, const float* __restrict__ xv,
-                                                             const float* __restrict__ GB, int gb_stride, int iq, int ik, int iv,
-                                                             const float* __restrict__ Wq, const float* __restrict__ bq,
-                                                             const float* __restrict__ Wk, const float* __restrict__ bk,
-                                                             const float* __restrict__ Wv, const float* __restrict__ bv,
-                                                             const float* __restrict__ Wp, float* __restrict__ Kf,
-                                                             float* __restrict__ s0, float* __restrict__ Vf, int J) {
+#define CAM_VLD 52  // Vf compact row stride: 2 heads x 24 keys + 4 (conflict-free ds_read_b128 across 32 rows)
+#define CA_IMG_HDR 68
+#define CA_IMG_FLOATS(J) (CA_IMG_HDR + 2 * (J) * LDW64 + 64 * CAM_VLD)
+#define CA_IMG_STRIDE 6528  // floats per clip: CA_IMG_FLOATS(23) = 6524 rounded up to 256 bytes
+struct CaFoldArgs {
+  const float *xk, *xv;                                       // given token features [B,J,64] (xv = the joint features) ...
+  const float *jt, *Wj, *bj, *jpos, *Wj2v, *bj2v, *j2vK;      // ... or (xk == null) the embed form: joints [B,J,3] + the embedding weights
+  float* jf_out;                                              // embed form: jf [B,J,64] written here when non-null
+  const float* GB;
+  int gb_stride, iq, ik, iv;
+  const float *Wq, *bq, *Wk, *bk, *Wv, *bv, *Wp;
+  float *Kf, *s0, *Vf;                                        // fp32 folded operands (any may be null)
+  float* img;                                                 // f16 image [B][CA_IMG_STRIDE] or null
+  int J;
+};
+__global__ __launch_bounds__(JS_THREADS) void ca_fold_kernel(CaFoldArgs a) {
   __shared__ float s_a[32 * JLD];
   __shared__ float s_b[32 * JLD];
   __shared__ float s_k[32 * JLD];
   __shared__ float s_v[32 * JLD];
-  __shared__ __attribute__((aligned(16))) float s_w[64 * JWL];    // Wk, Wv, then Wq (64 x 64 tiles through lin_tiled's ring of one)
+  __shared__ __attribute__((aligned(16))) float s_w[64 * JWL];    // Wj2v, Wk, Wv, then Wq (64 x 64 tiles through lin_tiled's ring of one)
   __shared__ __attribute__((aligned(16))) float s_wp[64 * JWL];   // Wproj
+  __shared__ __attribute__((aligned(16))) float s_img[CA_IMG_STRIDE];
+  __shared__ float s_red[16];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* gb = GB + (long long)b * gb_stride;
-  // all four 64 x 64 weights travel as coalesced tiles (until round 4 each lane walked its own weight row in global memory)
+  const int J = a.J;
+  const float* gb = a.GB + (long long)b * a.gb_stride;
+  // all 64 x 64 weights travel as coalesced tiles (until round 4 each lane walked its own weight row in global memory)
   JTile pre, prep;
-  jtile_fetch(pre, Wk, 64, 0, 0, tid);
-  jtile_fetch(prep, Wp, 64, 0, 0, tid);
-  const float gq = gb[iq * 128 + lane], bqv = gb[iq * 128 + 64 + lane];
-  for (int idx = tid; idx < J * 64; idx += JS_THREADS) {
-    const int i = idx >> 6, c = idx & 63;
-    s_a[i * JLD + c] = xk[((long long)b * J + i) * 64 + c];
-    s_b[i * JLD + c] = xv[((long long)b * J + i) * 64 + c];
+  jtile_fetch(pre, a.xk ? a.Wk : a.Wj2v, 64, 0, 0, tid);
+  jtile_fetch(prep, a.Wp, 64, 0, 0, tid);
+  const float gq = gb[a.iq * 128 + lane], bqv = gb[a.iq * 128 + 64 + lane];
+  if (a.img)
+    for (int i = tid; i < CA_IMG_STRIDE; i += JS_THREADS) s_img[i] = 0.f;  // pads and dead keys: true zeros
+  if (a.xk) {
+    for (int idx = tid; idx < J * 64; idx += JS_THREADS) {
+      const int i = idx >> 6, c = idx & 63;
+      s_a[i * JLD + c] = a.xk[((long long)b * J + i) * 64 + c];
+      s_b[i * JLD + c] = a.xv[((long long)b * J + i) * 64 + c];
+    }
+    jtile_store(s_wp, prep, tid);
+    __syncthreads();
+  } else {  // joint_embed: jf -> s_b ; proj_j2v_dim(jf) + j2v_K_embed -> s_a
+    for (int idx = tid; idx < J * 64; idx += JS_THREADS) {
+      const int i = idx >> 6, c = idx & 63;
+      const float* p = a.jt + ((long long)b * J + i) * 3;
+      const float v = ((a.Wj[c * 3] * p[0] + a.Wj[c * 3 + 1] * p[1] + a.Wj[c * 3 + 2] * p[2]) + a.bj[c]) + a.jpos[i * 64 + c];
+      s_b[i * JLD + c] = v;
+      if (a.jf_out) a.jf_out[((long long)b * J + i) * 64 + c] = v;
+    }
+    jtile_store(s_wp, prep, tid);
+    lin_tiled<64, 64>(s_b, JLD, a.Wj2v, a.bj2v, s_k, JLD, J, tid, false, s_w, pre, a.Wk, 64);  // (its first barrier publishes s_b and s_wp)
+    __syncthreads();
+    for (int idx = tid; idx < J * 64; idx += JS_THREADS) {
+      const int i = idx >> 6, c = idx & 63;
+      s_a[i * JLD + c] = s_k[i * JLD + c] + a.j2vK[i * 64 + c];
+    }
+    __syncthreads();
   }
-  jtile_store(s_wp, prep, tid);
-  __syncthreads();
-  adaln_small8(s_a, s_k, gb + ik * 128, J, tid);  // s_k = AdaLN_k(xk)
-  adaln_small8(s_b, s_v, gb + iv * 128, J, tid);  // s_v = AdaLN_v(xv)
-  lin_tiled<64, 64>(s_k, JLD, Wk, bk, s_a, JLD, J, tid, false, s_w, pre, Wv, 64);  // s_a = k
-  lin_tiled<64, 64>(s_v, JLD, Wv, bv, s_b, JLD, J, tid, false, s_w, pre, Wq, 64);  // s_b = v
+  adaln_small8(s_a, s_k, gb + a.ik * 128, J, tid);  // s_k = AdaLN_k(xk)
+  adaln_small8(s_b, s_v, gb + a.iv * 128, J, tid);  // s_v = AdaLN_v(xv)
+  lin_tiled<64, 64>(s_k, JLD, a.Wk, a.bk, s_a, JLD, J, tid, false, s_w, pre, a.Wv, 64);  // s_a = k
+  lin_tiled<64, 64>(s_v, JLD, a.Wv, a.bv, s_b, JLD, J, tid, false, s_w, pre, a.Wq, 64);  // s_b = v
   __syncthreads();
   jtile_store(s_w, pre, tid);  // Wq
   __syncthreads();
   // 32^-0.5 (vertx heads = 2, head_dim 32; CoevoDecoder.py:140,37-38) times log2(e): vertex_ca's softmax runs on the
   // hardware 2^x, so the folded scores are produced directly in log2 units
   const float scale = 0.17677669529663688110f * 1.44269504088896340736f;
-  float* Kfb = Kf + (long long)b * 64 * 64;
-  float* Vfb = Vf + (long long)b * 64 * 64;
-  float* s0b = s0 + (long long)b * 64;
-  // one wavefront per (h,i) row, lane = channel c
-  for (int row = wave; row < 64; row += 8) {
+  float* Kfb = a.Kf ? a.Kf + (long long)b * 64 * 64 : nullptr;
+  float* Vfb = a.Vf ? a.Vf + (long long)b * 64 * 64 : nullptr;
+  float* s0b = a.s0 ? a.s0 + (long long)b * 64 : nullptr;
+  // one wavefront per (h,i) row, lane = channel c: rows wave, wave + 8, ... (8 per wave)
+  float kfr[8], vfr[8];
+  float mk = 0.f, mv = 0.f;
+#pragma unroll
+  for (int q8 = 0; q8 < 8; ++q8) {
+    const int row = wave + 8 * q8;
     const int h = row >> 5, i = row & 31;
     float kf = 0.f, vf = 0.f, sc = 0.f;
     if (i < J) {
@@ -232,13 +245,72 @@ __global__ __launch_bounds__(JS_THREADS) void ca_fold_kernel(const float* __rest
       }
       kf = scale * gq * M;
       float t = bqv * M;
-      if (lane < 32) t += bq[32 * h + lane] * s_a[i * JLD + 32 * h + lane];
+      if (lane < 32) t += a.bq[32 * h + lane] * s_a[i * JLD + 32 * h + lane];
       sc = scale * wave_sum(t);
     }
-    Kfb[row * 64 + lane] = kf;
-    Vfb[lane * 64 + row] = vf;
-    if (lane == 0) s0b[row] = sc;
+    if (Kfb) Kfb[row * 64 + lane] = kf;
+    if (Vfb) Vfb[lane * 64 + row] = vf;
+    if (s0b && lane == 0) s0b[row] = sc;
+    if (a.img && lane == 0) s_img[row] = sc;
+    kfr[q8] = kf;
+    vfr[q8] = vf;
+    mk = fmaxf(mk, fabsf(kf));
+    mv = fmaxf(mv, fabsf(vf));
   }
+  if (!a.img) return;  // (uniform over the grid)
+  mk = wave_max(mk);
+  mv = wave_max(mv);
+  if (lane == 0) {
+    s_red[wave] = mk;
+    s_red[8 + wave] = mv;
+  }
+  __syncthreads();
+  float MK = 0.f, MV = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    MK = fmaxf(MK, s_red[w]);
+    MV = fmaxf(MV, s_red[8 + w]);
+  }
+  int ek = 0, ev = 0;
+  if (MK > 0.f) frexpf(MK, &ek);
+  if (MV > 0.f) frexpf(MV, &ev);
+  const float upK = MK > 0.f ? ldexpf(1.f, 15 - ek) : 1.f, upV = MV > 0.f ? ldexpf(1.f, 15 - ev) : 1.f;
+  if (tid == 0) {  // what the kernel multiplies its accumulators by: the operand's 2^-s and the 2^-10 of its register-side operand
+    s_img[64] = (MK > 0.f ? ldexpf(1.f, ek - 15) : 1.f) * 0.0009765625f;
+    s_img[65] = (MV > 0.f ? ldexpf(1.f, ev - 15) : 1.f) * 0.0009765625f;
+  }
+  _Float16* im = reinterpret_cast<_Float16*>(s_img);
+#pragma unroll
+  for (int q8 = 0; q8 < 8; ++q8) {
+    const int row = wave + 8 * q8;
+    const int h = row >> 5, i = row & 31;
+    if (i < J) {  // Kf row (h, i), channel c = lane -> k-step c / 16, lane half (c / 4) & 1, element (c & 3) + 4 ((c / 8) & 1)
+      const float v = pinned(kfr[q8] * upK);  // ONE fp32 value for both planes (common.hpp)
+      const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+      const int c = lane, ks = c >> 4, hbb = (c >> 2) & 1, e = (c & 3) + 4 * ((c >> 3) & 1);
+      const int idx = (CA_IMG_HDR + (h * J + i) * LDW64) * 2 + ((ks * 2 + hbb) * 2) * 8 + e;
+      im[idx] = hi;
+      im[idx + 8] = lo;
+    }
+    if (i < 24) {  // Vf[c = lane][key (h, i)] (zero for J <= i < 24)
+      const float v = pinned(vfr[q8] * upV);
+      const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+      const int base = (CA_IMG_HDR + 2 * J * LDW64 + lane * CAM_VLD) * 2 + h * 48;
+      if (i < 16) {
+        const int idx = base + ((i >> 2) & 1) * 16 + (i & 3) + 4 * (i >> 3);
+        im[idx] = hi;
+        im[idx + 8] = lo;
+      } else {
+        const int jj = i - 16;
+        const int idx = base + 32 + (jj >> 2) * 8 + (jj & 3);
+        im[idx] = hi;
+        im[idx + 4] = lo;
+      }
+    }
+  }
+  __syncthreads();
+  float* dst = a.img + (long long)b * CA_IMG_STRIDE;
+  for (int i4 = tid; i4 < CA_IMG_FLOATS(J) / 4; i4 += JS_THREADS) reinterpret_cast<f32x4*>(dst)[i4] = reinterpret_cast<const f32x4*>(s_img)[i4];
 }
 
 // ======================================================================================================
@@ -560,9 +632,9 @@ template <bool F16>
 __device__ __forceinline__ void stage_ffn_any(float* sW1, float* sW2, float* sSc, const float* W1, const float* W2,
                                               const float* __restrict__ img, int tid, int nthreads) {
   if constexpr (F16) {
-    if (img) {
-      for (int i = tid; i < (256 * LDW64 + 64 * LDW256) / 4; i += nthreads)
-        reinterpret_cast<f32x4*>(sW1)[i] = reinterpret_cast<const f32x4*>(img)[i];
+    if (img) {  // 133 KiB, a plain copy: by LDS-DMA, every piece in flight at once (the caller's barrier is preceded by lds_dma_wait)
+      static_assert((256 * LDW64 + 64 * LDW256) * 4 % 1024 == 0, "the FFN image is a whole number of KiB");
+      lds_dma_copy(sW1, img, (256 * LDW64 + 64 * LDW256) * 4 / 1024, tid >> 6, nthreads >> 6, tid & 63);
       if (tid < 4) sSc[tid] = img[256 * LDW64 + 64 * LDW256 + tid];
       return;
     }
@@ -585,8 +657,8 @@ extern "C" int pmce_ffn_image_floats(void) { return FFN_IMG_FLOATS; }
 // Persistent workgroups (4 waves); fc1/fc2 weights live in LDS (137 KB) for the whole kernel; each wave walks
 // over 32-token tiles; the 256-wide hidden activation exists only as 16 registers at a time.
 // ======================================================================================================
-template <bool F16>
-__global__ __launch_bounds__(512) void adaln_mlp_kernel(const float* __restrict__ xin, const float* __restrict__ GB,
+template <bool F16, int NW = 8>
+__global__ __launch_bounds__(64 * NW) void adaln_mlp_kernel(const float* __restrict__ xin, const float* __restrict__ GB,
                                                         int gb_stride, int inst, const float* __restrict__ W1,
                                                         const float* __restrict__ b1, const float* __restrict__ W2,
                                                         const float* __restrict__ b2, float* __restrict__ yout,
@@ -600,14 +672,15 @@ __global__ __launch_bounds__(512) void adaln_mlp_kernel(const float* __restrict_
   float* sB2 = sB1 + 256;               // [64]
   float* sSc = sB2 + 64;                // [4 + 16] scales of the f16 form + reduction scratch
   const int tid = threadIdx.x;
-  stage_ffn_any<F16>(sW1, sW2, sSc, W1, W2, ffn_img, tid, 512);
+  stage_ffn_any<F16>(sW1, sW2, sSc, W1, W2, ffn_img, tid, 64 * NW);
   if (tid < 256) sB1[tid] = b1[tid];
   if (tid < 64) sB2[tid] = b2[tid];
+  lds_dma_wait();
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   const int n0 = lane & 31, hb = lane >> 5;
   const int ntiles = B * NTILE;
-  for (int wt = blockIdx.x * 8 + wave; wt < ntiles; wt += gridDim.x * 8) {
+  for (int wt = blockIdx.x * NW + wave; wt < ntiles; wt += gridDim.x * NW) {
     const int b = wt / NTILE, tile = wt % NTILE;
     const int v = tile * 32 + n0;
     const bool valid = v < NV;
@@ -665,41 +738,39 @@ __global__ __launch_bounds__(512) void adaln_mlp_kernel(const float* __restrict_
 // (7 wave tiles, one per wave, like vertex_ca's grid) and the operands are re-staged between items.  J <= 23; the
 // launcher falls back to the two kernels above beyond that.  Same arithmetic in the same order as vertex_ca + adaln_mlp.
 // ======================================================================================================
-#define CAM_VLD 52  // Vf compact row stride: 2 heads x 24 keys + 4 (conflict-free ds_read_b128 across 32 rows)
-template <bool F16>
-__global__ __launch_bounds__(448) void vertex_ca_mlp_kernel(const float* __restrict__ xq, const float* __restrict__ vt,
+template <bool F16, int NW = 7>
+__global__ __launch_bounds__(64 * NW) void vertex_ca_mlp_kernel(const float* __restrict__ xq, const float* __restrict__ vt,
                                                             const float* __restrict__ Wv3, const float* __restrict__ Eq,
                                                             const float* __restrict__ Kf, const float* __restrict__ s0,
                                                             const float* __restrict__ Vf, const float* __restrict__ bp,
                                                             const float* __restrict__ GB, int gb_stride, int inst,
                                                             const float* __restrict__ W1, const float* __restrict__ b1,
                                                             const float* __restrict__ W2, const float* __restrict__ b2,
-                                                            float* __restrict__ yout, int B, int J, const float* __restrict__ ffn_img) {
+                                                            float* __restrict__ yout, int B, int J, const float* __restrict__ ffn_img,
+                                                            const float* __restrict__ ca_img) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sW1 = smem;                    // [256][68]
   float* sW2 = sW1 + 256 * LDW64;       // [64][260]
   float* sB1 = sW2 + 64 * LDW256;       // [256]
   float* sB2 = sB1 + 256;               // [64]
   float* sSc = sB2 + 64;                // [4 + 16] scales of the f16 FFN form + reduction scratch (+ 12 pad)
+  // one clip's folded cross-attention operands, in the order of ca_fold's image (F16: a plain copy of it, f16 planes; fp32 form: the
+  // compact fp32 rows): [s0 (64) | 4 scales | Kf rows (h, i < J) | Vf rows c over the keys (h, i < 24)]
   float* sS0 = sSc + 32;                // [2][32]
-  float* sV = sS0 + 64;                 // [64][CAM_VLD]   Vf[c][h*24 + i], i < 24
-  float* sK = sV + 64 * CAM_VLD;        // [2*J][68]       Kf[h*J + i][c], i < J
+  float* sK = sS0 + CA_IMG_HDR;         // [2*J][68]       Kf[h*J + i][c], i < J
+  float* sV = sK + 2 * J * LDW64;       // [64][CAM_VLD]   Vf[c][h*24 + i], i < 24
   const int tid = threadIdx.x;
-  stage_ffn_any<F16>(sW1, sW2, sSc, W1, W2, ffn_img, tid, 448);
+  stage_ffn_any<F16>(sW1, sW2, sSc, W1, W2, ffn_img, tid, 64 * NW);
   if (tid < 256) sB1[tid] = b1[tid];
   if (tid < 64) sB2[tid] = b2[tid];
   const int lane = tid & 63, wave = tid >> 6;
   const int n0 = lane & 31, hb = lane >> 5;
   const int krow = min(n0, J - 1);  // rows >= J of a head's score tile are masked below: any finite operand will do
-  for (int item = blockIdx.x; item < 2 * B; item += gridDim.x) {
-    const int b = item >> 1;
-    const int tile = (item & 1) * 7 + wave;
+  // a work item = half a clip = 7 wave tiles: with NW = 7 one per wave; with fewer waves a wave walks tiles wave, wave + NW, ...
+  auto load_x = [&](int b, int tile, float* x) {
     const int v = tile * 32 + n0;
-    const bool valid = v < NV;
-    const int vc = valid ? v : NV - 1;
+    const int vc = v < NV ? v : NV - 1;
     const long long tok = (long long)b * NV + vc;
-    // this wave's 32 query tokens first: their latency hides under the staging of the clip's folded operands
-    float x[32];
     if (xq) {
       load_slots(xq + tok * 64, x, hb);
     } else {
@@ -712,24 +783,13 @@ __global__ __launch_bounds__(448) void vertex_ca_mlp_kernel(const float* __restr
         x[s] = (Wv3[c * 3] * p0 + Wv3[c * 3 + 1] * p1 + Wv3[c * 3 + 2] * p2) + x[s];
       }
     }
-    __syncthreads();  // the previous item's operands are no longer read (and, first time, the weights are staged)
-    {
-      const float* Kb = Kf + (long long)b * 4096;
-      const float* Vb = Vf + (long long)b * 4096;
-      for (int i = tid; i < 2 * J * 16; i += 448) {  // Kf rows (h, i < J), 16 float4 each
-        const int r = i >> 4, c4 = i & 15;
-        const int h = r / J, ii = r - h * J;
-        *reinterpret_cast<f32x4*>(sK + r * LDW64 + 4 * c4) = *reinterpret_cast<const f32x4*>(Kb + (h * 32 + ii) * 64 + 4 * c4);
-      }
-      for (int i = tid; i < 64 * 12; i += 448) {  // Vf row c: keys 0..23 of both heads, 12 float4
-        const int c = i / 12, k4 = i - c * 12;
-        const int h = k4 / 6, j4 = k4 - h * 6;
-        *reinterpret_cast<f32x4*>(sV + c * CAM_VLD + h * 24 + 4 * j4) = *reinterpret_cast<const f32x4*>(Vb + c * 64 + h * 32 + 4 * j4);
-      }
-      if (tid < 64) sS0[tid] = s0[(long long)b * 64 + tid];
-    }
+  };
+  auto compute = [&](int b, int tile, float* x) {
+    const int v = tile * 32 + n0;
+    const bool valid = v < NV;
+    const long long tok = (long long)b * NV + (valid ? v : NV - 1);
     // ---- cross-attention (vertex_ca_kernel) ----
-    {
+    if constexpr (!F16) {
       float n[32];
       {
         float s = 0.f;
@@ -746,7 +806,6 @@ __global__ __launch_bounds__(448) void vertex_ca_mlp_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < 32; ++i) n[i] = (x[i] - mean) * inv;
       }
-      __syncthreads();
       f32x16 sc[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h)
@@ -809,6 +868,100 @@ __global__ __launch_bounds__(448) void vertex_ca_mlp_kernel(const float* __restr
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[16 * nt + r] = x[16 * nt + r] + o[nt][r];  // F1 (stays in registers)
+    } else {
+      // The same two contractions in the three-product f16 form (round 5): 24 + 12..24 matrix instructions of 32 cycles instead of 64 + 48 of
+      // 64.  Both register-side operands carry 2^10 (n: |n| < 8; P: <= 1) so that their lo planes are normal f16 numbers, the LDS-side
+      // operands are ca_fold's image (hi | lo planes of Kf 2^sK and Vf 2^sV); one accumulator per product, as in vertex_sa.
+      const float kscale = sS0[64], vscale = sS0[65];
+      tl_f16x8 nhi[4], nlo[4];
+      {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) s += x[i];
+        const float mean = pair_sum(s) * (1.0f / 64.0f);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          const float d = x[i] - mean;
+          ss += d * d;
+        }
+        const float inv = (1.0f / (sqrtf(pair_sum(ss) * (1.0f / 63.0f)) + 1e-6f)) * 1024.0f;
+        float n[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) n[i] = pinned((x[i] - mean) * inv);  // ONE fp32 value for both planes (common.hpp)
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) split_slots8_plain(n + 8 * sI, nhi[sI], nlo[sI]);
+      }
+      float p[32];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+        const float* w = sK + (h * J + krow) * LDW64 + hb * 8;
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) {
+          const tl_f16x8 whi = *reinterpret_cast<const tl_f16x8*>(w + sI * 16), wlo = *reinterpret_cast<const tl_f16x8*>(w + sI * 16 + 4);
+          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, nhi[sI], S, 0, 0, 0);
+          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, nhi[sI], S, 0, 0, 0);
+          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, nlo[sI], S, 0, 0, 0);
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * hb;
+          const float sv = (i < J) ? fmaf(S[r], kscale, sS0[h * 32 + i]) : -INFINITY;
+          S[r] = sv;
+          m = fmaxf(m, sv);
+        }
+        m = pair_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(S[r] - m);  // scores are in log2 units (ca_fold)
+          p[16 * h + r] = e;
+          sum += e;
+        }
+        const float inv = (1.0f / pair_sum(sum)) * 1024.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[16 * h + r] = pinned(p[16 * h + r] * inv);
+      }
+      f32x16 o[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[nt][r] = 0.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        tl_f16x8 phi, plo;
+        split_slots8_plain(p + 16 * h, phi, plo);  // keys 0 .. 15 of the head
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const float* v = sV + (nt * 32 + n0) * CAM_VLD + h * 24 + hb * 8;
+          const tl_f16x8 vhi = *reinterpret_cast<const tl_f16x8*>(v), vlo = *reinterpret_cast<const tl_f16x8*>(v + 4);
+          o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, phi, o[nt], 0, 0, 0);
+          o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo, phi, o[nt], 0, 0, 0);
+          o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, plo, o[nt], 0, 0, 0);
+        }
+        if (J > 16) {  // keys 16 .. 23 (wave-uniform): the fragment's upper four elements (keys 24 ..) are zero on both sides
+          split_slots8_plain(p + 16 * h + 8, phi, plo);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const float* v = sV + (nt * 32 + n0) * CAM_VLD + h * 24 + 16 + hb * 4;
+            const tl_f16x4 a4 = *reinterpret_cast<const tl_f16x4*>(v), b4 = *reinterpret_cast<const tl_f16x4*>(v + 2);
+            const _Float16 z = (_Float16)0.f;
+            const tl_f16x8 vhi = {a4[0], a4[1], a4[2], a4[3], z, z, z, z}, vlo = {b4[0], b4[1], b4[2], b4[3], z, z, z, z};
+            o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, phi, o[nt], 0, 0, 0);
+            o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo, phi, o[nt], 0, 0, 0);
+            o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, plo, o[nt], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          x[16 * nt + r] = x[16 * nt + r] + fmaf(o[nt][r], vscale, bp[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb]);  // F1 (stays in registers)
     }
     // ---- FFN (adaln_mlp_kernel) ----
     float a[32];
@@ -822,6 +975,80 @@ __global__ __launch_bounds__(448) void vertex_ca_mlp_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) y[16 * nt + r] = acc2[nt][r];
       store_slots(yout + tok * 64, y, hb);
+    }
+  };
+  for (int item = blockIdx.x; item < 2 * B; item += gridDim.x) {
+    const int b = item >> 1;
+    const int tile0 = (item & 1) * 7 + wave;
+    // this wave's first 32 query tokens before anything else: their latency hides under the staging of the clip's folded operands
+    float x[32];
+    load_x(b, tile0, x);
+    if (item == (int)blockIdx.x) lds_dma_wait();   // first item: the FFN image's LDS-DMA has landed (wave-uniform)
+    __syncthreads();  // the previous item's operands are no longer read (and, first time, the weights are staged)
+    if constexpr (F16) {
+      // ca_fold's image, a plain copy; every load in flight before the first LDS write
+      constexpr int NT = 64 * NW, CIT = (CA_IMG_FLOATS(23) / 4 + NT - 1) / NT;
+      const f32x4* src = reinterpret_cast<const f32x4*>(ca_img + (long long)b * CA_IMG_STRIDE);
+      const int n4 = CA_IMG_FLOATS(J) / 4;
+      f32x4 creg[CIT];
+#pragma unroll
+      for (int u = 0; u < CIT; ++u) {
+        const int i = tid + u * NT;
+        if (i < n4) creg[u] = src[i];
+      }
+#pragma unroll
+      for (int u = 0; u < CIT; ++u) {
+        const int i = tid + u * NT;
+        if (i < n4) reinterpret_cast<f32x4*>(sS0)[i] = creg[u];
+      }
+    } else {
+      const float* Kb = Kf + (long long)b * 4096;
+      const float* Vb = Vf + (long long)b * 4096;
+      // every load of the item's operands is in flight before the first LDS write (left as plain loops hipcc emits load -> wait ->
+      // store per iteration: four exposed L2 round trips per item)
+      constexpr int NT = 64 * NW, KIT = (2 * 23 * 16 + NT - 1) / NT, VIT = (64 * 12 + NT - 1) / NT;
+      f32x4 kreg[KIT], vreg[VIT];
+#pragma unroll
+      for (int u = 0; u < KIT; ++u) {  // Kf rows (h, i < J), 16 float4 each
+        const int i = tid + u * NT;
+        if (i < 2 * J * 16) {
+          const int r = i >> 4, c4 = i & 15;
+          const int h = r / J, ii = r - h * J;
+          kreg[u] = *reinterpret_cast<const f32x4*>(Kb + (h * 32 + ii) * 64 + 4 * c4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < VIT; ++u) {  // Vf row c: keys 0..23 of both heads, 12 float4
+        const int i = tid + u * NT;
+        if (i < 64 * 12) {
+          const int c = i / 12, k4 = i - c * 12;
+          const int h = k4 / 6, j4 = k4 - h * 6;
+          vreg[u] = *reinterpret_cast<const f32x4*>(Vb + c * 64 + h * 32 + 4 * j4);
+        }
+      }
+      if (tid < 64) sS0[tid] = s0[(long long)b * 64 + tid];
+#pragma unroll
+      for (int u = 0; u < KIT; ++u) {
+        const int i = tid + u * NT;
+        if (i < 2 * J * 16) *reinterpret_cast<f32x4*>(sK + (i >> 4) * LDW64 + 4 * (i & 15)) = kreg[u];
+      }
+#pragma unroll
+      for (int u = 0; u < VIT; ++u) {
+        const int i = tid + u * NT;
+        if (i < 64 * 12) {
+          const int c = i / 12, k4 = i - c * 12;
+          const int h = k4 / 6, j4 = k4 - h * 6;
+          *reinterpret_cast<f32x4*>(sV + c * CAM_VLD + h * 24 + 4 * j4) = vreg[u];
+        }
+      }
+    }
+    __syncthreads();
+    compute(b, tile0, x);
+    if (NW < 7) {
+      for (int tw = wave + NW; tw < 7; tw += NW) {
+        load_x(b, (item & 1) * 7 + tw, x);
+        compute(b, (item & 1) * 7 + tw, x);
+      }
     }
   }
 }
@@ -844,8 +1071,9 @@ __global__ __launch_bounds__(256, F16 ? 2 : 1) void adaln_qkv_kernel(const float
   __shared__ float sSc[2];
   const int tid = threadIdx.x;
   if constexpr (F16) {  // Wqkv = the image
-    for (int i = tid; i < 192 * LDW64 / 4; i += 256) reinterpret_cast<f32x4*>(sW)[i] = reinterpret_cast<const f32x4*>(Wqkv)[i];
+    lds_dma_copy(sW, Wqkv, 192 * LDW64 * 4 / 1024, tid >> 6, 4, tid & 63);
     if (tid < 2) sSc[tid] = Wqkv[192 * LDW64 + tid];
+    lds_dma_wait();
   } else {
     stage_weight<64>(sW, Wqkv, 192, tid, 256);
   }
@@ -1498,7 +1726,8 @@ __global__ __launch_bounds__(448) void vertex_sab_kernel(const float* __restrict
   const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int n0 = lane & 31, hb = lane >> 5;
-  for (int i = tid; i < 192 * LDW64 / 4; i += 448) reinterpret_cast<f32x4*>(sW)[i] = reinterpret_cast<const f32x4*>(qkv_img)[i];
+  static_assert(192 * LDW64 * 4 % 1024 == 0, "the qkv weight image is a whole number of KiB");
+  lds_dma_copy(sW, qkv_img, 192 * LDW64 * 4 / 1024, wave, 7, lane);  // 51 KiB, every piece in flight at once
   if (tid < 2) sSc[tid] = qkv_img[192 * LDW64 + tid];
   if (tid < 192) sB[tid] = bqkv[tid];
   float* kvw = kvs + (size_t)(b * G + g) * (NTILE * SAB_TILE_FLOATS);  // this workgroup's scratch (plain pointer: written, then read)
@@ -1568,6 +1797,7 @@ __global__ __launch_bounds__(448) void vertex_sab_kernel(const float* __restrict
     float x0[32], x1[32];
     load_slots(xin + tok_of(2 * wave) * 64, x0, hb);  // both tiles requested before the weight image's barrier
     load_slots(xin + tok_of(2 * wave + 1) * 64, x1, hb);
+    lds_dma_wait();
     __syncthreads();  // the weight image, sB, sSc
     const float down = sSc[1];
 #pragma unroll
@@ -1714,13 +1944,15 @@ __global__ __launch_bounds__(448) void vertex_sab_kernel(const float* __restrict
           S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][0], ql, S, 0, 0, 0);
         }
         float mt = -INFINITY;
+        if (jt == NTILE - 1) {  // only the clip's last key tile holds keys beyond it (wave-uniform)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
-          const float sv = (j < NV) ? S[r] : -INFINITY;
-          S[r] = sv;
-          mt = fmaxf(mt, sv);
+          for (int r = 0; r < 16; ++r) {
+            const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
+            S[r] = (j < NV) ? S[r] : -INFINITY;
+          }
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, S[r]);
         if (__builtin_amdgcn_ballot_w64(mt > mrun[t][h] + kLazy) != 0) {
           const float mn = fmaxf(mrun[t][h], pair_max(mt));
           const float corr = __builtin_amdgcn_exp2f((mrun[t][h] - mn) * kQs);
@@ -2147,9 +2379,15 @@ __global__ __launch_bounds__(256) void j_regress_kernel(const float* __restrict_
 // ======================================================================================================
 // C-ABI launchers
 // ======================================================================================================
+#ifndef PMCE_AB_MLP_WAVES   // A/B builds only (scripts/build_ab.sh): waves per workgroup of the FFN kernels
+#define PMCE_AB_MLP_WAVES 8
+#endif
+#ifndef PMCE_AB_CAM_WAVES
+#define PMCE_AB_CAM_WAVES 7
+#endif
 static int mlp_grid(int B) {
   const int tiles = B * NTILE;
-  int g = (tiles + 7) / 8;
+  int g = (tiles + PMCE_AB_MLP_WAVES - 1) / PMCE_AB_MLP_WAVES;
   return g < 256 ? g : 256;
 }
 static int tl_grid(int B, int per_cu) {
@@ -2166,22 +2404,46 @@ extern "C" int pmce_vertex_init_gather_f32(const float* joints, const int* vj, f
   return pmce_check_launch("vertex_init_gather");
 }
 
-extern "C" int pmce_joint_embed_f32(const float* jt, const float* Wj, const float* bj, const float* jpos, const float* Wj2v,
-                                    const float* bj2v, const float* j2vK, float* jf, float* xk, int B, int J,
-                                    hipStream_t stream) {
-  PMCE_REQUIRE(J >= 1 && J <= 32 && B > 0, "joint_embed: J must be in 1..32");
-  hipLaunchKernelGGL(joint_embed_kernel, dim3(B), dim3(JS_THREADS), 0, stream, jt, Wj, bj, jpos, Wj2v, bj2v, j2vK, jf, xk, J);
-  return pmce_check_launch("joint_embed");
+static int launch_ca_fold(const CaFoldArgs& a, int B, hipStream_t stream, const char* what) {
+  PMCE_REQUIRE(a.J >= 1 && a.J <= 32 && B > 0, "%s: J must be in 1..32", what);
+  PMCE_REQUIRE(!a.img || (a.J <= 23 && (reinterpret_cast<uintptr_t>(a.img) & 15) == 0), "%s: the f16 image needs J <= 23 and a 16-byte aligned buffer", what);
+  hipLaunchKernelGGL(ca_fold_kernel, dim3(B), dim3(JS_THREADS), 0, stream, a);
+  return pmce_check_launch(what);
 }
-
+extern "C" int pmce_ca_image_floats(void) { return CA_IMG_STRIDE; }
+// img (may be null): the operands' f16 image per clip for pmce_vertex_ca_mlp_pk_f32's split_f16 form, [B][pmce_ca_image_floats()], J <= 23.
+// Kf / s0 / Vf may each be null when only the image is wanted.
+extern "C" int pmce_ca_fold_img_f32(const float* xk, const float* xv, const float* GB, int gb_stride, int iq, int ik, int iv,
+                                    const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv,
+                                    const float* bv, const float* Wp, float* Kf, float* s0, float* Vf, float* img, int B, int J,
+                                    hipStream_t stream) {
+  PMCE_REQUIRE(xk && xv && GB && Wq && bq && Wk && bk && Wv && bv && Wp, "ca_fold: null pointer");
+  CaFoldArgs a{};
+  a.xk = xk; a.xv = xv; a.GB = GB; a.gb_stride = gb_stride; a.iq = iq; a.ik = ik; a.iv = iv;
+  a.Wq = Wq; a.bq = bq; a.Wk = Wk; a.bk = bk; a.Wv = Wv; a.bv = bv; a.Wp = Wp;
+  a.Kf = Kf; a.s0 = s0; a.Vf = Vf; a.img = img; a.J = J;
+  return launch_ca_fold(a, B, stream, "ca_fold");
+}
 extern "C" int pmce_ca_fold_f32(const float* xk, const float* xv, const float* GB, int gb_stride, int iq, int ik, int iv,
                                 const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv,
                                 const float* bv, const float* Wp, float* Kf, float* s0, float* Vf, int B, int J,
                                 hipStream_t stream) {
-  PMCE_REQUIRE(J >= 1 && J <= 32 && B > 0, "ca_fold: J must be in 1..32");
-  hipLaunchKernelGGL(ca_fold_kernel, dim3(B), dim3(JS_THREADS), 0, stream, xk, xv, GB, gb_stride, iq, ik, iv, Wq, bq, Wk, bk, Wv, bv,
-                     Wp, Kf, s0, Vf, J);
-  return pmce_check_launch("ca_fold");
+  return pmce_ca_fold_img_f32(xk, xv, GB, gb_stride, iq, ik, iv, Wq, bq, Wk, bk, Wv, bv, Wp, Kf, s0, Vf, nullptr, B, J, stream);
+}
+// The joint side of a CoevoBlock in one launch: the joint embedding (CoevoDecoder.py:177-180,184: jf = joint_proj(jt) + joint_pos_embed,
+// xk = proj_j2v_dim(jf) + j2v_K_embed, xv = jf) followed by the fold.  jf_out [B,J,64] may be null (only the joint stream reads it).
+extern "C" int pmce_joint_prep_f32(const float* jt, const float* Wj, const float* bj, const float* jpos, const float* Wj2v,
+                                   const float* bj2v, const float* j2vK, float* jf_out, const float* GB, int gb_stride, int iq, int ik,
+                                   int iv, const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv,
+                                   const float* bv, const float* Wp, float* Kf, float* s0, float* Vf, float* img, int B, int J,
+                                   hipStream_t stream) {
+  PMCE_REQUIRE(jt && Wj && bj && jpos && Wj2v && bj2v && j2vK && GB && Wq && bq && Wk && bk && Wv && bv && Wp, "joint_prep: null pointer");
+  CaFoldArgs a{};
+  a.jt = jt; a.Wj = Wj; a.bj = bj; a.jpos = jpos; a.Wj2v = Wj2v; a.bj2v = bj2v; a.j2vK = j2vK; a.jf_out = jf_out;
+  a.GB = GB; a.gb_stride = gb_stride; a.iq = iq; a.ik = ik; a.iv = iv;
+  a.Wq = Wq; a.bq = bq; a.Wk = Wk; a.bk = bk; a.Wv = Wv; a.bv = bv; a.Wp = Wp;
+  a.Kf = Kf; a.s0 = s0; a.Vf = Vf; a.img = img; a.J = J;
+  return launch_ca_fold(a, B, stream, "joint_prep");
 }
 
 extern "C" int pmce_vertex_ca_f32(const float* xq, const float* vt, const float* Wv3, const float* Eq, const float* Kf,
@@ -2193,21 +2455,6 @@ extern "C" int pmce_vertex_ca_f32(const float* xq, const float* vt, const float*
   return pmce_check_launch("vertex_ca");
 }
 
-extern "C" int pmce_adaln_mlp_pk_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* W1,
-                                     const float* b1, const float* W2, const float* b2, float* yout, const float* Wc,
-                                     const float* bc, const float* vt_in, float* vt_out, int B, int split_f16,
-                                     const float* ffn_img, hipStream_t stream);
-extern "C" int pmce_vertex_ca_mlp_pk_f32(const float* xq, const float* vt, const float* Wv3, const float* Eq, const float* Kf,
-                                         const float* s0, const float* Vf, const float* bp, const float* GB, int gb_stride,
-                                         int inst, const float* W1, const float* b1, const float* W2, const float* b2,
-                                         float* yout, float* scratch, int B, int J, int split_f16, const float* ffn_img,
-                                         hipStream_t stream);
-extern "C" int pmce_adaln_mlp_ex_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* W1,
-                                     const float* b1, const float* W2, const float* b2, float* yout, const float* Wc,
-                                     const float* bc, const float* vt_in, float* vt_out, int B, int split_f16,
-                                     hipStream_t stream) {
-  return pmce_adaln_mlp_pk_f32(xin, GB, gb_stride, inst, W1, b1, W2, b2, yout, Wc, bc, vt_in, vt_out, B, split_f16, nullptr, stream);
-}
 // ffn_img: the FFN's pre-made LDS image of the f16 form (pmce_ffn_pack_f16; null = made by every workgroup from W1 / W2)
 extern "C" int pmce_adaln_mlp_pk_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* W1,
                                      const float* b1, const float* W2, const float* b2, float* yout, const float* Wc,
@@ -2218,12 +2465,12 @@ extern "C" int pmce_adaln_mlp_pk_f32(const float* xin, const float* GB, int gb_s
   const size_t lds = (size_t)(256 * LDW64 + 64 * LDW256 + 256 + 64 + 32) * sizeof(float);
   static std::atomic<unsigned long long> attr{0}, attr_s{0};
   if (split_f16) {
-    PMCE_TRY(pmce_opt_in_lds((const void*)adaln_mlp_kernel<true>, (int)lds, attr_s, "adaln_mlp"));
-    hipLaunchKernelGGL(adaln_mlp_kernel<true>, dim3(mlp_grid(B)), dim3(512), lds, stream, xin, GB, gb_stride, inst, W1, b1, W2, b2,
+    PMCE_TRY(pmce_opt_in_lds((const void*)adaln_mlp_kernel<true, PMCE_AB_MLP_WAVES>, (int)lds, attr_s, "adaln_mlp"));
+    hipLaunchKernelGGL((adaln_mlp_kernel<true, PMCE_AB_MLP_WAVES>), dim3(mlp_grid(B)), dim3(64 * PMCE_AB_MLP_WAVES), lds, stream, xin, GB, gb_stride, inst, W1, b1, W2, b2,
                        yout, Wc, bc, vt_in, vt_out, B, ffn_img);
   } else {
-    PMCE_TRY(pmce_opt_in_lds((const void*)adaln_mlp_kernel<false>, (int)lds, attr, "adaln_mlp"));
-    hipLaunchKernelGGL(adaln_mlp_kernel<false>, dim3(mlp_grid(B)), dim3(512), lds, stream, xin, GB, gb_stride, inst, W1, b1, W2, b2,
+    PMCE_TRY(pmce_opt_in_lds((const void*)adaln_mlp_kernel<false, PMCE_AB_MLP_WAVES>, (int)lds, attr, "adaln_mlp"));
+    hipLaunchKernelGGL((adaln_mlp_kernel<false, PMCE_AB_MLP_WAVES>), dim3(mlp_grid(B)), dim3(64 * PMCE_AB_MLP_WAVES), lds, stream, xin, GB, gb_stride, inst, W1, b1, W2, b2,
                        yout, Wc, bc, vt_in, vt_out, B, nullptr);
   }
   return pmce_check_launch("adaln_mlp");
@@ -2231,41 +2478,38 @@ extern "C" int pmce_adaln_mlp_pk_f32(const float* xin, const float* GB, int gb_s
 extern "C" int pmce_adaln_mlp_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* W1,
                                   const float* b1, const float* W2, const float* b2, float* yout, const float* Wc,
                                   const float* bc, const float* vt_in, float* vt_out, int B, hipStream_t stream) {
-  return pmce_adaln_mlp_ex_f32(xin, GB, gb_stride, inst, W1, b1, W2, b2, yout, Wc, bc, vt_in, vt_out, B, 0, stream);
+  return pmce_adaln_mlp_pk_f32(xin, GB, gb_stride, inst, W1, b1, W2, b2, yout, Wc, bc, vt_in, vt_out, B, 0, nullptr, stream);
 }
 
-extern "C" int pmce_vertex_ca_mlp_ex_f32(const float* xq, const float* vt, const float* Wv3, const float* Eq, const float* Kf,
-                                         const float* s0, const float* Vf, const float* bp, const float* GB, int gb_stride,
-                                         int inst, const float* W1, const float* b1, const float* W2, const float* b2,
-                                         float* yout, float* scratch, int B, int J, int split_f16, hipStream_t stream) {
-  return pmce_vertex_ca_mlp_pk_f32(xq, vt, Wv3, Eq, Kf, s0, Vf, bp, GB, gb_stride, inst, W1, b1, W2, b2, yout, scratch, B, J, split_f16,
-                                   nullptr, stream);
-}
+// split_f16 != 0: the FFN AND the cross-attention in the three-product f16 form - ffn_img (pmce_ffn_pack_f16; null = converted per
+// workgroup from W1 / W2) and ca_img (required: pmce_ca_fold_img_f32's / pmce_joint_prep_f32's image of the folded operands; Kf / s0 /
+// Vf are then not read and may be null).  J > 23: the two-launch fp32-attention form through `scratch` (needs Kf / s0 / Vf).
 extern "C" int pmce_vertex_ca_mlp_pk_f32(const float* xq, const float* vt, const float* Wv3, const float* Eq, const float* Kf,
                                          const float* s0, const float* Vf, const float* bp, const float* GB, int gb_stride,
                                          int inst, const float* W1, const float* b1, const float* W2, const float* b2,
                                          float* yout, float* scratch, int B, int J, int split_f16, const float* ffn_img,
-                                         hipStream_t stream) {
-  PMCE_REQUIRE((xq || (vt && Wv3 && Eq)) && Kf && s0 && Vf && bp && GB && W1 && b1 && W2 && b2 && yout,
-               "vertex_ca_mlp: null pointer");
+                                         const float* ca_img, hipStream_t stream) {
+  PMCE_REQUIRE((xq || (vt && Wv3 && Eq)) && bp && GB && W1 && b1 && W2 && b2 && yout, "vertex_ca_mlp: null pointer");
   PMCE_REQUIRE(J >= 1 && J <= 32 && B > 0, "vertex_ca_mlp: J must be in 1..32");
   if (J > 23) {  // one clip's folded operands no longer fit beside the FFN weights: the two-launch form
-    PMCE_REQUIRE(scratch, "vertex_ca_mlp: J > 23 needs a [B,431,64] scratch buffer");
+    PMCE_REQUIRE(scratch && Kf && s0 && Vf, "vertex_ca_mlp: J > 23 needs Kf / s0 / Vf and a [B,431,64] scratch buffer");
     PMCE_TRY(pmce_vertex_ca_f32(xq, vt, Wv3, Eq, Kf, s0, Vf, bp, scratch, B, J, stream));
     return pmce_adaln_mlp_pk_f32(scratch, GB, gb_stride, inst, W1, b1, W2, b2, yout, nullptr, nullptr, nullptr, nullptr, B, split_f16,
                                  ffn_img, stream);
   }
-  const size_t lds = (size_t)(256 * LDW64 + 64 * LDW256 + 256 + 64 + 32 + 64 + 64 * CAM_VLD + 2 * J * LDW64) * sizeof(float);
+  const size_t lds = (size_t)(256 * LDW64 + 64 * LDW256 + 256 + 64 + 32 + CA_IMG_FLOATS(J)) * sizeof(float);
   static std::atomic<unsigned long long> attr{0}, attr_s{0};
   const int g = 2 * B < 256 ? 2 * B : 256;
   if (split_f16) {
-    PMCE_TRY(pmce_opt_in_lds((const void*)vertex_ca_mlp_kernel<true>, 163840, attr_s, "vertex_ca_mlp"));
-    hipLaunchKernelGGL(vertex_ca_mlp_kernel<true>, dim3(g), dim3(448), lds, stream, xq, vt, Wv3, Eq, Kf, s0, Vf, bp, GB, gb_stride,
-                       inst, W1, b1, W2, b2, yout, B, J, ffn_img);
+    PMCE_REQUIRE(ca_img && (reinterpret_cast<uintptr_t>(ca_img) & 15) == 0, "vertex_ca_mlp: the split_f16 form needs the operands' image (pmce_ca_fold_img_f32)");
+    PMCE_TRY(pmce_opt_in_lds((const void*)vertex_ca_mlp_kernel<true, PMCE_AB_CAM_WAVES>, 163840, attr_s, "vertex_ca_mlp"));
+    hipLaunchKernelGGL((vertex_ca_mlp_kernel<true, PMCE_AB_CAM_WAVES>), dim3(g), dim3(64 * PMCE_AB_CAM_WAVES), lds, stream, xq, vt, Wv3, Eq, Kf, s0, Vf, bp, GB, gb_stride,
+                       inst, W1, b1, W2, b2, yout, B, J, ffn_img, ca_img);
   } else {
-    PMCE_TRY(pmce_opt_in_lds((const void*)vertex_ca_mlp_kernel<false>, 163840, attr, "vertex_ca_mlp"));
-    hipLaunchKernelGGL(vertex_ca_mlp_kernel<false>, dim3(g), dim3(448), lds, stream, xq, vt, Wv3, Eq, Kf, s0, Vf, bp, GB, gb_stride,
-                       inst, W1, b1, W2, b2, yout, B, J, nullptr);
+    PMCE_REQUIRE(Kf && s0 && Vf, "vertex_ca_mlp: null pointer");
+    PMCE_TRY(pmce_opt_in_lds((const void*)vertex_ca_mlp_kernel<false, PMCE_AB_CAM_WAVES>, 163840, attr, "vertex_ca_mlp"));
+    hipLaunchKernelGGL((vertex_ca_mlp_kernel<false, PMCE_AB_CAM_WAVES>), dim3(g), dim3(64 * PMCE_AB_CAM_WAVES), lds, stream, xq, vt, Wv3, Eq, Kf, s0, Vf, bp, GB, gb_stride,
+                       inst, W1, b1, W2, b2, yout, B, J, nullptr, nullptr);
   }
   return pmce_check_launch("vertex_ca_mlp");
 }
@@ -2273,7 +2517,8 @@ extern "C" int pmce_vertex_ca_mlp_f32(const float* xq, const float* vt, const fl
                                       const float* s0, const float* Vf, const float* bp, const float* GB, int gb_stride,
                                       int inst, const float* W1, const float* b1, const float* W2, const float* b2, float* yout,
                                       float* scratch, int B, int J, hipStream_t stream) {
-  return pmce_vertex_ca_mlp_ex_f32(xq, vt, Wv3, Eq, Kf, s0, Vf, bp, GB, gb_stride, inst, W1, b1, W2, b2, yout, scratch, B, J, 0, stream);
+  return pmce_vertex_ca_mlp_pk_f32(xq, vt, Wv3, Eq, Kf, s0, Vf, bp, GB, gb_stride, inst, W1, b1, W2, b2, yout, scratch, B, J, 0, nullptr,
+                                   nullptr, stream);
 }
 
 extern "C" int pmce_adaln_qkv_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* Wqkv,

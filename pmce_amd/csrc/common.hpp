@@ -153,16 +153,48 @@ __device__ __forceinline__ void tl_gemm(const float* __restrict__ Wl, const floa
   }
 }
 
-// Cooperative copy of a row-major [rows][K] global matrix into LDS [rows][K+4].
+// Cooperative copy of a row-major [rows][K] global matrix into LDS [rows][K+4].  Four loads per thread are in flight before the first
+// LDS write: left to itself hipcc emits load -> wait -> store per iteration, one exposed L2 round trip each (round 5: the un-batched
+// copy of a 137 KB FFN image cost a workgroup 17 serial round trips, a quarter of the kernel).
 template <int K>
 __device__ __forceinline__ void stage_weight(float* __restrict__ dst, const float* __restrict__ src, int rows, int tid,
                                              int nthreads) {
   constexpr int C4 = K / 4;
-  for (int i = tid; i < rows * C4; i += nthreads) {
-    const int r = i / C4, c = i % C4;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)r * K + 4 * c);
-    *reinterpret_cast<f32x4*>(dst + r * (K + 4) + 4 * c) = v;
+  const int total = rows * C4;
+  for (int i0 = tid; i0 < total; i0 += 4 * nthreads) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * nthreads;
+      if (i < total) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(i / C4) * K + 4 * (i % C4));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * nthreads;
+      if (i < total) *reinterpret_cast<f32x4*>(dst + (i / C4) * (K + 4) + 4 * (i % C4)) = v[u];
+    }
   }
+}
+
+// LDS-DMA (buffer_load_dwordx4 ... lds): 64 lanes x 16 B from per-lane buffer offsets straight into LDS at M0 + lane * 16 - no VGPR round
+// trip, no ds_write.  hipcc does not count these loads: whoever reads the destination first issues lds_dma_wait() (s_waitcnt vmcnt(0))
+// and, across waves, a barrier.  (M0 is compiler-reserved: saved and restored inside the statement.)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff, unsigned lds_wave_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(lds_wave_base), "s"(soff)
+      : "memory");
+}
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Linear copy of `kib` KiB (16-byte aligned source, LDS destination) by LDS-DMA: every wave instruction moves 1 KiB, the waves take the
+// 1 KiB pieces round-robin and issue all of theirs back to back (<= 63 per wave: the counter's range).  lds_dma_wait + barrier before use.
+__device__ __forceinline__ void lds_dma_copy(float* lds_dst, const float* src, int kib, int wave, int nwaves, int lane) {
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 0xffffffff, 0x00020000);
+  const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)lds_dst);
+  const int w0 = __builtin_amdgcn_readfirstlane(wave);  // (wave-uniform by construction; the M0 operand must be scalar)
+  for (int c = w0; c < kib; c += nwaves) lds_dma16(rsrc, (unsigned)(c * 1024 + lane * 16), 0, base + (unsigned)c * 1024u);
 }
 
 // Four consecutive channels c..c+3 (c % 4 == 0) of a row, written in the pre-split operand layout of the three-product f16 GEMM

@@ -318,7 +318,7 @@ struct LifterWs {
   float *FS, *FR;  // split mode: the raw image features as row-scaled f16 planes [frames][2048] + 2^e per frame (prep_features)
 };
 struct DecoderWs {
-  float *GI0, *Y0, *GI1, *Y1, *GB, *VT[3], *JF[3], *XK[3], *KF[3], *S0[3], *VF[3], *F1, *F2, *QKV, *KVJ, *FA, *JM;
+  float *GI0, *Y0, *GI1, *Y1, *GB, *VT[3], *JF[3], *KF[3], *S0[3], *VF[3], *CAI[3], *F1, *F2, *QKV, *KVJ, *FA, *JM;
 };
 
 void carve_lifter(Carver& c, const pmce_model* m, int B, LifterWs& w) {
@@ -340,10 +340,10 @@ void carve_decoder(Carver& c, const pmce_model* m, int B, DecoderWs& w) {
   for (int i = 0; i < 3; ++i) w.VT[i] = c.take((size_t)B * NVC * 3);
   for (int i = 0; i < 3; ++i) {
     w.JF[i] = c.take((size_t)B * 32 * D);
-    w.XK[i] = c.take((size_t)B * 32 * D);
     w.KF[i] = c.take((size_t)B * 4096);
     w.S0[i] = c.take((size_t)B * 64);
     w.VF[i] = c.take((size_t)B * 4096);
+    w.CAI[i] = c.take((size_t)B * pmce_ca_image_floats());  // the folded operands as f16 planes (vertex_ca_mlp's split form)
   }
   w.F1 = c.take((size_t)B * NVC * D);
   w.F2 = c.take((size_t)B * NVC * D);
@@ -607,14 +607,14 @@ int joint_prep(pmce_model* m, int k, const float* joints, int B, DecoderWs& w, h
   const int J = m->J;
   const VertexBlockW& v = m->w.vb[k - 1];
   const int ib = (k - 1) * 6, gbs = N_ADA * 128;
-  RUN(P_JOINT_EMBED, pmce_joint_embed_f32(joints, v.joint_proj_w, v.joint_proj_b,
-                                          v.joint_pos, v.j2v_w,
-                                          v.j2v_b, v.j2v_K, w.JF[k - 1], w.XK[k - 1], B,
-                                          J, stream));
-  RUN(P_CA_FOLD, pmce_ca_fold_f32(w.XK[k - 1], w.JF[k - 1], w.GB, gbs, ib + 0, ib + 1, ib + 2, v.vca_wq_w,
-                                  v.vca_wq_b, v.vca_wk_w, v.vca_wk_b,
-                                  v.vca_wv_w, v.vca_wv_b, v.vca_proj_w,
-                                  w.KF[k - 1], w.S0[k - 1], w.VF[k - 1], B, J, stream));
+  // one launch: joint embedding + fold.  The f16 form of the fused vertex kernel reads the operands' image only (J <= 23); the fp32
+  // form (and the two-launch fallback beyond J = 23) the fp32 operands.  jf is read by the joint stream of block 3 only.
+  const bool image = pkf(m) && m->fused_ca && J <= 23;
+  RUN(P_CA_FOLD, pmce_joint_prep_f32(joints, v.joint_proj_w, v.joint_proj_b, v.joint_pos, v.j2v_w, v.j2v_b, v.j2v_K,
+                                     k == 3 ? w.JF[k - 1] : nullptr, w.GB, gbs, ib + 0, ib + 1, ib + 2, v.vca_wq_w, v.vca_wq_b, v.vca_wk_w,
+                                     v.vca_wk_b, v.vca_wv_w, v.vca_wv_b, v.vca_proj_w, image ? nullptr : w.KF[k - 1],
+                                     image ? nullptr : w.S0[k - 1], image ? nullptr : w.VF[k - 1], image ? w.CAI[k - 1] : nullptr, B, J,
+                                     stream));
   return PMCE_OK;
 }
 
@@ -642,7 +642,7 @@ int vertex_block(pmce_model* m, int k, const float* vt_cur, float* vt_next, int 
   if (m->fused_ca) {  // CrossAttentionBlock (CoevoDecoder.py:82-87) in one launch, bit-identical to the two below
     RUN(P_VERTEX_CA_MLP, pmce_vertex_ca_mlp_pk_f32(nullptr, vt_cur, v.vertx_proj_w, v.Eq, w.KF[k - 1], w.S0[k - 1], w.VF[k - 1],
                                                    v.vca_proj_b, w.GB, gbs, ib + 3, v.vca_fc1_w, v.vca_fc1_b, v.vca_fc2_w,
-                                                   v.vca_fc2_b, w.F2, w.F1, B, J, pkf(m), m->ffn_img[k - 1][0], stream));
+                                                   v.vca_fc2_b, w.F2, w.F1, B, J, pkf(m), m->ffn_img[k - 1][0], w.CAI[k - 1], stream));
   } else {
     RUN(P_VERTEX_CA, pmce_vertex_ca_f32(nullptr, vt_cur, v.vertx_proj_w, v.Eq, w.KF[k - 1], w.S0[k - 1], w.VF[k - 1],
                                         v.vca_proj_b, w.F1, B, J, stream));

@@ -36,19 +36,24 @@ class Pose2Mesh(HipModuleBase):
 
     @torch.no_grad()
     def forward(self, joints, img_feats):
-        eng = self._ensure_packed()
+        """Under the module's overflow policy (default "rerun": HipModuleBase.set_overflow_policy)."""
         joints = _check_input(joints, (self.num_joint, 3), "joints")
         img_feats = _check_input(img_feats, (SEQLEN, FEAT_DIM), "img_feats")
         B = joints.shape[0]
-        pose = torch.empty(B, self.num_joint, 3, device=joints.device, dtype=torch.float32)
-        mesh = torch.empty(B, NUM_VERTS_FULL, 3, device=joints.device, dtype=torch.float32)
         if B == 0:
+            return (torch.empty(0, self.num_joint, 3, device=joints.device, dtype=torch.float32),
+                    torch.empty(0, NUM_VERTS_FULL, 3, device=joints.device, dtype=torch.float32))
+
+        def launch(eng):
+            pose = torch.empty(B, self.num_joint, 3, device=joints.device, dtype=torch.float32)
+            mesh = torch.empty(B, NUM_VERTS_FULL, 3, device=joints.device, dtype=torch.float32)
+            ws = eng.workspace(B)
+            _lib.check(eng.lib.pmce_decoder_forward(eng.handle, _lib.ptr(joints), _lib.ptr(img_feats), _lib.ptr(pose),
+                                                    _lib.ptr(mesh), B, C.c_void_p(ws.data_ptr()), ws.numel(),
+                                                    _lib.current_stream()), "pmce_decoder_forward")
             return pose, mesh
-        ws = eng.workspace(B)
-        _lib.check(eng.lib.pmce_decoder_forward(eng.handle, _lib.ptr(joints), _lib.ptr(img_feats), _lib.ptr(pose),
-                                                _lib.ptr(mesh), B, C.c_void_p(ws.data_ptr()), ws.numel(),
-                                                _lib.current_stream()), "pmce_decoder_forward")
-        return pose, mesh
+
+        return self._guarded(launch)
 
 
 def get_model(num_joint, embed_dim):

@@ -36,18 +36,22 @@ class GraphormerNet(HipModuleBase):
 
     @torch.no_grad()
     def forward(self, x, img_feat):
-        eng = self._ensure_packed()
+        """Under the module's overflow policy (default "rerun": HipModuleBase.set_overflow_policy)."""
         x = _check_input(x, (SEQLEN, self.num_joints, 2), "pose2d")
         img_feat = _check_input(img_feat, (SEQLEN, FEAT_DIM), "img_feat")
         B = x.shape[0]
-        out = torch.empty(B, self.num_joints, 3, device=x.device, dtype=torch.float32)
         if B == 0:
+            return torch.empty(0, self.num_joints, 3, device=x.device, dtype=torch.float32)
+
+        def launch(eng):
+            out = torch.empty(B, self.num_joints, 3, device=x.device, dtype=torch.float32)
+            ws = eng.workspace(B)
+            _lib.check(eng.lib.pmce_lifter_forward(eng.handle, _lib.ptr(x), _lib.ptr(img_feat), _lib.ptr(out), B,
+                                                   C.c_void_p(ws.data_ptr()), ws.numel(), _lib.current_stream()),
+                       "pmce_lifter_forward")
             return out
-        ws = eng.workspace(B)
-        _lib.check(eng.lib.pmce_lifter_forward(eng.handle, _lib.ptr(x), _lib.ptr(img_feat), _lib.ptr(out), B,
-                                               C.c_void_p(ws.data_ptr()), ws.numel(), _lib.current_stream()),
-                   "pmce_lifter_forward")
-        return out
+
+        return self._guarded(launch)
 
 
 def get_model(num_joint=17, embed_dim=256, depth=3, pretrained=False, allow_pickle=None):

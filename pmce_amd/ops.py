@@ -222,8 +222,10 @@ def ffn_image(fc1_w, fc2_w):
 
 def cross_attn_block_vertex(xq, xk, xv, g, sd, p, split_f16=False, packed=False):
     """The whole vertex-stream CrossAttentionBlock in one launch (CoevoDecoder.py:82-87), p = '...vertx_CA_FFN':
-    xq + CA(...) then + Mlp(AdaLN_2(.)).  Bit-identical to cross_attn_vertex followed by adaln_mlp.
-    packed (with split_f16): the FFN's f16 form from a pre-made image (ffn_image) instead of converted per workgroup."""
+    xq + CA(...) then + Mlp(AdaLN_2(.)).  fp32 form: bit-identical to cross_attn_vertex followed by adaln_mlp.  split_f16: the FFN and
+    (round 5, J <= 23) the attention's two contractions in the three-product f16 form - the folded key / value operands reach the kernel as
+    the f16 image ca_fold writes.  packed (with split_f16): the FFN's planes from a pre-made image (ffn_image) instead of converted per
+    workgroup."""
     lib = _lib.load()
     xq, xk, xv = _c(xq), _c(xk), _c(xv)
     B, Nq, _ = xq.shape
@@ -234,18 +236,19 @@ def cross_attn_block_vertex(xq, xk, xv, g, sd, p, split_f16=False, packed=False)
     Kf = torch.empty(B, 64, 64, device=dev)
     s0 = torch.empty(B, 64, device=dev)
     Vf = torch.empty(B, 64, 64, device=dev)
+    img = torch.empty(B, lib.pmce_ca_image_floats(), device=dev) if (split_f16 and J <= 23) else None
     w = {k: _c(sd[f"{p}.attn.{k}"]) for k in ("wq.weight", "wq.bias", "wk.weight", "wk.bias", "wv.weight", "wv.bias",
                                               "proj.weight", "proj.bias")}
-    _lib.check(lib.pmce_ca_fold_f32(P(xk), P(xv), P(GB), GB.shape[1], 0, 1, 2, P(w["wq.weight"]), P(w["wq.bias"]),
-                                    P(w["wk.weight"]), P(w["wk.bias"]), P(w["wv.weight"]), P(w["wv.bias"]),
-                                    P(w["proj.weight"]), P(Kf), P(s0), P(Vf), B, J, _st()), "ca_fold")
+    _lib.check(lib.pmce_ca_fold_img_f32(P(xk), P(xv), P(GB), GB.shape[1], 0, 1, 2, P(w["wq.weight"]), P(w["wq.bias"]),
+                                        P(w["wk.weight"]), P(w["wk.bias"]), P(w["wv.weight"]), P(w["wv.bias"]),
+                                        P(w["proj.weight"]), P(Kf), P(s0), P(Vf), P(img), B, J, _st()), "ca_fold")
     m = [_c(sd[p + k]) for k in (".mlp.fc1.weight", ".mlp.fc1.bias", ".mlp.fc2.weight", ".mlp.fc2.bias")]
     out = torch.empty_like(xq)
     scratch = torch.empty_like(xq) if J > 23 else None
-    img = ffn_image(m[0], m[2]) if packed else None
+    fimg = ffn_image(m[0], m[2]) if packed else None
     _lib.check(lib.pmce_vertex_ca_mlp_pk_f32(P(xq), None, None, None, P(Kf), P(s0), P(Vf), P(w["proj.bias"]), P(GB), GB.shape[1],
                                              3, P(m[0]), P(m[1]), P(m[2]), P(m[3]), P(out), P(scratch), B, J,
-                                             1 if split_f16 else 0, P(img), _st()), "vertex_ca_mlp")
+                                             1 if split_f16 else 0, P(fimg), P(img), _st()), "vertex_ca_mlp")
     return out
 
 

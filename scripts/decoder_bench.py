@@ -20,6 +20,7 @@ def main():
     dec = models.CoevoDecoder.get_model(J, 256)
     dec.load_state_dict(sd)
     dec = dec.to(dev)
+    dec.set_overflow_policy("report")      # asynchronous calls in the timed loop; outputs_finite is checked at the end
     g = torch.Generator().manual_seed(0)
     joints = (torch.randn(B, J, 3, generator=g) * 0.3).to(dev)                      # N(0, 0.3^2) m  (SURVEY 8d cfg 2)
     feats = torch.relu(torch.randn(B, 16, 2048, generator=g)).to(dev)

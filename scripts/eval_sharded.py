@@ -76,10 +76,12 @@ def main():
         pending = (ticket, b0)
     if pending is not None:
         consume(pending)
+    named = pipe.synchronize()          # drains the lanes and polls the model's overflow word BEFORE the metrics are finished (a warning names
+                                        # the batches; every batch was already reduced as it was produced, and non-finite predictions are counted and
+                                        # named per clip in the result - nothing is re-run behind the metrics' back)
     res = run.finish(seq_ids, lo, hi)
     torch.cuda.synchronize(); sharding.barrier()
     dt = sharding.reduce_max(time.perf_counter() - t0, dev)
-    named = pipe.synchronize()          # polls the model's overflow word (non-finite predictions are named in the result anyway)
     if rank == 0:
         # where a batch of this configuration spends its time, and the roofline of its dominant kernel (one stream, HIP events)
         import bench

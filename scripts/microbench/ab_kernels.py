@@ -15,6 +15,7 @@ model = models.PMCE.get_model(J, C, 3)
 model.load_state_dict(synth.make_state_dict(synth.pmce_spec(J, C, 3), seed=123))
 model.set_j_regressor(assets.load_j_regressor("h36m"))
 model = model.to(dev)
+model.set_overflow_policy("report")          # asynchronous calls (the default "rerun" policy waits for every forward)
 only = os.environ.get("AB_CLASSES", "").split(",") if os.environ.get("AB_CLASSES") else None
 out = {"lib": os.path.basename(_lib.LIB_PATH), "C": C}
 for B in [int(a) for a in sys.argv[1:]] or [1, 256]:

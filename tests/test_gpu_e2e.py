@@ -627,6 +627,7 @@ def test_nonfinite_inputs_propagate_like_the_reference():
     pose2d, img_feat = synth.make_inputs(B, J, 31)
     p2, f = T(pose2d).to(dev()), T(img_feat).to(dev())
     try:
+        model.set_overflow_policy("report")                         # fully asynchronous calls; the word only reports
         good = [t.clone() for t in model(p2, f)]
         assert not model.overflowed()
         f_bad = f.clone()
@@ -660,8 +661,26 @@ def test_nonfinite_inputs_propagate_like_the_reference():
         assert not torch.isfinite(outs[0][1]).all()               # non-finite inputs stay non-finite (as in the reference)
         outs, reran = model.forward_checked(p2, f)
         assert not reran and all(torch.equal(o, g) for o, g in zip(outs, good))
-        # the pipeline polls when it drains and names the batch
+        # the pipeline polls when it drains and names the batch (default: it only names it and holds no inputs) ...
         pipe = model.pipeline(2)
+        ts = [pipe.submit(p2, x) for x in (f, f_bad, f)]
+        assert all(t.inputs is None for t in ts)
+        with pytest.warns(UserWarning, match="non-finite"):
+            named = pipe.synchronize()
+        assert named == [1] and pipe.reran == [] and not model.overflowed()
+        with pytest.raises(ValueError, match="created with"):
+            pipe.synchronize(on_overflow="rerun")
+        # ... a ticket the caller dropped is not kept alive by the pipeline (~0.5 GB of retained batches at B = 256)
+        import gc
+        import weakref
+        t = pipe.submit(p2, f)
+        w = weakref.ref(t)
+        del t
+        gc.collect()
+        assert w() is None
+        assert pipe.synchronize() == []
+        # ... and one created with on_overflow="rerun" keeps the inputs and computes the batch again on the fp32 pipe
+        pipe = model.pipeline(2, on_overflow="rerun")
         ts = [pipe.submit(p2, x) for x in (f, f_bad, f)]
         with pytest.warns(UserWarning, match="non-finite"):
             named = pipe.synchronize()
@@ -669,10 +688,59 @@ def test_nonfinite_inputs_propagate_like_the_reference():
         for a, b in zip(ts[2].result(), good):
             assert torch.equal(a, b)
         assert pipe.synchronize() == []
+        # the module's DEFAULT policy: forward() itself waits, re-runs, clears - non-finite inputs stay non-finite, as in the reference
+        model.set_overflow_policy("rerun")
+        n0 = model.overflow_reruns
+        out = model(p2, f_bad)
+        assert model.overflow_reruns == n0 + 1 and not model.overflowed()
+        assert not torch.isfinite(out[0][1]).all() and torch.isfinite(out[0][0]).all()
+        out = model(p2, f)
+        assert model.overflow_reruns == n0 + 1 and all(torch.equal(o, g) for o, g in zip(out, good[:3]))
     finally:
-        model.set_overflow_policy(False)
+        model.set_overflow_policy("rerun")
         model.set_gemm_mode(None)
         model.clear_overflow()
+
+
+def test_forward_never_returns_what_the_reference_would_not():
+    """VERDICT r04 #7.  Weights that push ONE hidden unit of a decoder MLP past f16's 65504 (fc1 bias 7e4 -> GELU output 7e4): the
+    three-product f16 form turns that into inf, the reference (fp32) does not.  Under the module's default overflow policy the
+    plain ``model(pose2d, img_feat)`` of lib/core/base.py:222 returns finite values - the batch is computed again on the fp32 pipe,
+    bit-identical to a model in 'f32' mode - and they match the oracle on the same weights; 'report' shows what it guards against."""
+    from oracle import pmce_oracle as O
+    from pmce_amd import assets, models, synth
+    J, C, B = 17, 256, 2
+    sd = {k: v.clone() for k, v in cached_state_dict(J, C).items()}
+    sd["pose_mesh_coevo.coevoblock3.vertx_SA_FFN.mlp.fc1.bias"][5] = 7.0e4
+    _MODELS.clear()
+    torch.cuda.empty_cache()
+    model = models.PMCE.get_model(J, C, 3)
+    model.load_state_dict(sd)
+    model.set_j_regressor(assets.load_j_regressor("h36m"))
+    model = model.to(dev())
+    model.set_gemm_mode("split_f16", min_batch=1)
+    assert model.overflow_policy() == "rerun"
+    pose2d, img_feat = synth.make_inputs(B, J, 77)
+    p2, f = T(pose2d).to(dev()), T(img_feat).to(dev())
+    mesh, pose, pose3d = model(p2, f)
+    assert model.overflow_reruns == 1 and not model.overflowed()
+    assert all(bool(torch.isfinite(t).all()) for t in (mesh, pose, pose3d))
+    with torch.no_grad():
+        rm, rp, rl = O.pmce_forward(sd, T(pose2d), T(img_feat), model.vj_relation)
+    e = (maxabs(mesh, rm), maxabs(pose, rp), maxabs(pose3d, rl))
+    scale = max(1.0, float(rm.abs().max()))      # (the 7e4 hidden unit shifts every vertex by the same large offset: tolerance relative to it)
+    print(f"re-run on the fp32 pipe vs oracle: mesh {e[0]:.2e} m (max |mesh| {scale:.1f}), pose {e[1]:.2e} m, pose3d {e[2]:.2e} mm")
+    assert e[0] < TOL_M * scale and e[1] < TOL_M and e[2] / 1000 < TOL_M
+    mesh4, pose4, pose3d4, pred4 = model.forward_with_joints(p2, f)          # the same policy applies
+    assert model.overflow_reruns == 2 and torch.equal(mesh4, mesh) and bool(torch.isfinite(pred4).all())
+    model.set_overflow_policy("report")
+    bad = model(p2, f)
+    assert model.overflowed() and not bool(torch.isfinite(bad[0]).all())     # what the default policy keeps away from the caller
+    model.clear_overflow()
+    model.set_gemm_mode("f32")
+    ref32 = model(p2, f)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(ref32, (mesh, pose, pose3d)))
 
 
 def test_adversarial_weights_both_modes_vs_oracle():

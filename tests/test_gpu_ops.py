@@ -357,8 +357,25 @@ def test_cross_attn_block_vertex_fused(golden):
         e_16 = maxabs(fused16, ref3)          # the FFN in the three-product f16 form
         packed16 = ops.cross_attn_block_vertex(xq3.to(dev()), xk3.to(dev()), xk3.to(dev()), g3.to(dev()), sdd, p, split_f16=True, packed=True)
         assert torch.equal(packed16, fused16), "the FFN from its pre-made LDS image must give the bits of the per-workgroup conversion"
-        print(f"fused CrossAttentionBlock J={J}: vs oracle {e_or:.2e} (f16-split FFN {e_16:.2e}); vs vertex_ca + adaln_mlp {e_two:.2e}")
+        print(f"fused CrossAttentionBlock J={J}: vs oracle {e_or:.2e} (attention + FFN in the three-product f16 form {e_16:.2e}); vs vertex_ca + adaln_mlp {e_two:.2e}")
         assert e_or < 2e-5 and e_two < 5e-6 and e_16 < 2e-5
+    # the f16 form's folded operands carry ONE power of two per clip and operand: weights that make them large / small / lopsided
+    J = 17
+    g3, xq3, xk3 = rnd("cab.g", (B, 2048), 0.8), rnd("cab.xq", (B, 431, 64), 1.5), rnd("cab.xk", (B, J, 64), 1.5)
+    for wq_s, wv_s, pr_s in ((40.0, 1.0, 1.0), (1e-3, 300.0, 1e-2), (5.0, 1e-4, 1e3)):
+        sd2 = {k: v.clone() for k, v in sd.items() if k.startswith(p)}
+        sd2[p + ".attn.wq.weight"] *= wq_s
+        sd2[p + ".attn.wv.weight"] *= wv_s
+        sd2[p + ".attn.proj.weight"] *= pr_s
+        sdd2 = {k: v.to(dev()) for k, v in sd2.items()}
+        f16 = ops.cross_attn_block_vertex(xq3.to(dev()), xk3.to(dev()), xk3.to(dev()), g3.to(dev()), sdd2, p, split_f16=True, packed=True)
+        f32 = ops.cross_attn_block_vertex(xq3.to(dev()), xk3.to(dev()), xk3.to(dev()), g3.to(dev()), sdd2, p)
+        with torch.no_grad():
+            ref64 = O.cross_attention_block(xq3.double(), xk3.double(), xk3.double(), g3.double(), sd2, p, 2, torch.float64)
+        scale = float(ref64.abs().max())
+        e16, e32 = maxabs(f16, ref64), maxabs(f32, ref64)
+        print(f"   scaled weights (wq x{wq_s:g}, wv x{wv_s:g}, proj x{pr_s:g}): f16 form {e16:.2e}, fp32 form {e32:.2e} vs the fp64 oracle (max |out| {scale:.1f})")
+        assert e16 <= 1.5 * e32 + 2e-6 * max(1.0, scale), (wq_s, wv_s, pr_s)
     print(f"fused CrossAttentionBlock vs reference fixture {e_ref:.2e}")
     assert e_ref < 2e-5
 
