@@ -20,7 +20,7 @@
  *     pmce_model_profile_read (waits for the recorded events);
  *   - mutable state outside the handles: the thread-local error string and, while a model entry point runs, the thread-local
  *     pointer to that model's overflow word - one process per GPU or several host threads with their own streams are both fine -
- *     and the process-wide TUNING AIDS pmce_gemm_set_tuning, pmce_gemm_split_set_tuning / _set_skew (relaxed atomics
+ *     and the process-wide TUNING AIDS pmce_gemm_set_tuning, pmce_gemm_split_set_tuning (relaxed atomics
  *     read at launch time: meant for benchmarks and tests, not to be flipped while forwards are being enqueued elsewhere).
  * Fixed structural constants of the path: T = 16 frames, F = 2048 image-feature channels, V = 431 coarse
  * vertices, 6890 mesh vertices, D = 64 decoder channels, GRU hidden 1024, 8 lifter heads.  J <= 32,
@@ -56,7 +56,15 @@ const char* pmce_last_error_string(void);
  * ------------------------------------------------------------------------------------------------------- */
 typedef struct pmce_model pmce_model;
 
-/* num_joint: J (17, or 19 for COCO-input checkpoints); embed_dim: C (256|512); depth: lifter depth (3). */
+/* num_joint: J (17, or 19 for COCO-input checkpoints); embed_dim: C (256|512); depth: lifter depth (3).
+ * ENVIRONMENT: the library reads exactly five variables, all here, once per handle; each only sets the initial value of a setting that has an
+ * API setter and a getter (tests/test_host_logic.py flips every one):
+ *   PMCE_SPLIT_F16=0        initial gemm mode fp32 pipe           (pmce_model_set_gemm_mode / pmce_model_gemm_mode)
+ *   PMCE_SPLIT_MIN_BATCH=n  calls below n clips stay on fp32 pipe (pmce_model_set_split_min_batch / _get_)
+ *   PMCE_STRICT_OVERFLOW=1  strict overflow policy                (pmce_model_set_overflow_policy / _get_)
+ *   PMCE_SINGLE_STREAM=1    no second stream inside a forward     (pmce_model_set_concurrency / _get_)
+ *   PMCE_SPLIT_OVERLAP=0    diagnostic: the split mode strictly serial, one stream (pmce_model_get_split_overlap; Python's Pipeline reads it too)
+ * (Rounds 2-4 carried 16 more A/B switches that kept superseded kernels reachable; round 5 removed them with those kernels.) */
 int pmce_model_create(int num_joint, int embed_dim, int depth, pmce_model** out);
 void pmce_model_destroy(pmce_model* m);
 /* Register one packed tensor by name (names: pmce_model_tensor_name).  The pointer must stay valid. */
@@ -169,6 +177,8 @@ int pmce_window_rows_f32(const float* src, const int* win, float* dst, int W, in
  * short joint-side kernels on a second, internally created HIP stream, forked from and joined back into the caller's
  * stream with events (hipGraph-capturable; results are identical).  0 keeps every launch on the caller's stream. */
 int pmce_model_set_concurrency(pmce_model* m, int enable);
+int pmce_model_get_concurrency(const pmce_model* m);
+int pmce_model_get_split_overlap(const pmce_model* m);
 
 /* Staggering of several forwards in flight (one handle per lane, shared weights): makes `stream` wait until the pose
  * lifter of the last pmce_forward enqueued on `m` has finished, so that the next batch's lifter (long matrix-bound GEMMs)
@@ -252,8 +262,6 @@ int pmce_gemm_nt_split_f16_ln(const float* Ap, const float* Wp, int w_blocked, c
 int pmce_split_rows_f16(const float* A, long long M, int K, long long lda, float* Ap, pmce_stream_t stream);
 /* Tuning aid only: force the tile configuration of pmce_gemm_nt_split_f16 (0: 128x256, 1: 128x128, 2: 64x128; -1 automatic). */
 int pmce_gemm_split_set_tuning(int tile);
-/* Tuning aid only: start delay of every CU's second workgroup in units of 4096 cycles (-1: half a tile of matrix time). */
-int pmce_gemm_split_set_skew(int units);
 /* PoseEstimation.py:78-81 — x[tok] = joint_embed(pose2d) + imgfeat_embed(img_feat)[b,t] + spatial_pos[j]. */
 int pmce_embed_tokens_f32(const float* pose2d, const float* E, const float* Wje, const float* bje, const float* spos,
                           float* x, long long ntok, int J, int C, pmce_stream_t stream);
@@ -354,26 +362,20 @@ int pmce_vertex_ca_mlp_pk_f32(const float* xq, const float* vt, const float* Wv3
                               const float* W1, const float* b1, const float* W2, const float* b2, float* yout, float* scratch,
                               int B, int J, int split_f16, const float* ffn_img, const float* ca_img, pmce_stream_t stream);
 
-/* qkv = Linear(64->192)(AdaLN(x)) on [B,431,64] (CoevoDecoder.py:103,120). */
+/* fp32 pipe: qkv = Linear(64->192)(AdaLN(x)) on [B,431,64] (CoevoDecoder.py:103,120), then
+ * y = x + proj(softmax(q k^T/sqrt(32)) v), 2 heads, 431x431 per clip (CoevoDecoder.py:118-131,103). */
 int pmce_adaln_qkv_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* Wqkv, const float* bqkv,
                        float* qkv, int B, pmce_stream_t stream);
-/* The same product in the three-product f16 form (fp32 in, fp32 out; what a model in split_f16 mode runs): qkv_img =
- * pmce_qkv_pack_f16(Wqkv [192,64]) - pmce_qkv_image_floats() floats, 16-byte aligned, made once per weight. */
-int pmce_qkv_image_floats(void);
-int pmce_qkv_pack_f16(const float* Wqkv, float* qkv_img, pmce_stream_t stream);
-int pmce_adaln_qkv_split_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* qkv_img, const float* bqkv,
-                             float* qkv, int B, pmce_stream_t stream);
-/* y = x + proj(softmax(q k^T/sqrt(32)) v), 2 heads, 431x431 per clip (CoevoDecoder.py:118-131,103). */
 int pmce_vertex_sa_f32(const float* xin, const float* qkv, const float* Wp, const float* bp, float* yout, int B,
                        pmce_stream_t stream);
-/* The same with split_f16 != 0: both contractions (q k^T and p v) as three f16 matrix products of (hi, lo) halves, fp32
- * accumulate (K, V split while their tile is staged; the 64x64 projection stays fp32).  The note on packed-fp32 neighbours at pmce_gemm_nt_split_f16 applies. */
-int pmce_vertex_sa_ex_f32(const float* xin, const float* qkv, const float* Wp, const float* bp, float* yout, int B,
-                          int split_f16, pmce_stream_t stream);
+/* The qkv weight [192,64] as the f16 image pmce_vertex_sab_split_f32 copies into LDS: pmce_qkv_image_floats() floats, 16-byte aligned, made
+ * once per weight. */
+int pmce_qkv_image_floats(void);
+int pmce_qkv_pack_f16(const float* Wqkv, float* qkv_img, pmce_stream_t stream);
 /* The attention half of the vertex stream's AdaLN Block in ONE launch, three-product f16 form (what a model in split_f16 mode runs):
  *   y = x + proj(softmax(q k^T/sqrt(32)) v),  [q|k|v] = Linear(64->192)(AdaLN(x))   (CoevoDecoder.py:103,118-131)
- * = pmce_adaln_qkv_split_f32 followed by pmce_vertex_sa_ex_f32(split_f16 = 1), bit for bit, without the [B,431,192] fp32 QKV round
- * trip: q, k, v come out of the qkv product's accumulators in the attention's own operand layouts; k and v pass through `scratch`
+ * without a [B,431,192] fp32 QKV round trip: q, k, v come out of the qkv product's accumulators in the attention's own operand
+ * layouts (every contraction but the output projection as three f16 matrix products of (hi, lo) halves, fp32 accumulate); k and v pass through `scratch`
  * (pmce_vertex_sab_scratch_floats(B) floats, 16-byte aligned, caller-owned, contents meaningless outside the call) as f16 (hi | lo)
  * fragment planes.  qkv_img = pmce_qkv_pack_f16(Wqkv).  B > 128: one workgroup per clip; otherwise two. */
 long long pmce_vertex_sab_scratch_floats(int B);

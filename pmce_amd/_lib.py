@@ -54,6 +54,8 @@ PROTOTYPES = {
     "pmce_model_set_overflow_policy": [C.c_void_p, _i],
     "pmce_model_get_overflow_policy": [C.c_void_p],
     "pmce_model_get_split_min_batch": [C.c_void_p],
+    "pmce_model_get_concurrency": [C.c_void_p],
+    "pmce_model_get_split_overlap": [C.c_void_p],
     "pmce_model_set_clock_probe": [C.c_void_p, C.c_void_p],
     "pmce_model_overflowed": [C.c_void_p],
     "pmce_model_clear_overflow": [C.c_void_p],
@@ -75,7 +77,6 @@ PROTOTYPES = {
     "pmce_seq_attention_split_f16": [_f, _f, _i, _i, _i, _i, _l, _l, _l, _s],
     "pmce_gemm_nt_split_f16_rowmap": [_f, _f, _f, _f, _f, _i, _i, _i, _l, _i, _l, _l, _s],
     "pmce_gemm_split_set_tuning": [_i],
-    "pmce_gemm_split_set_skew": [_i],
     "pmce_embed_tokens_f32": [_f, _f, _f, _f, _f, _f, _l, _i, _i, _s],
     "pmce_ln_chain_f32": [_f, _l, _i, _f, _f, _fl, _f, _i, _i, _f, _f, _f, _fl, _f, _s],
     "pmce_seq_attention_f32": [_f, _f, _i, _i, _i, _i, _l, _l, _l, _s],
@@ -98,9 +99,7 @@ PROTOTYPES = {
     "pmce_adaln_qkv_f32": [_f, _f, _i, _i, _f, _f, _f, _i, _s],
     "pmce_qkv_image_floats": [],
     "pmce_qkv_pack_f16": [_f, _f, _s],
-    "pmce_adaln_qkv_split_f32": [_f, _f, _i, _i, _f, _f, _f, _i, _s],
     "pmce_vertex_sa_f32": [_f, _f, _f, _f, _f, _i, _s],
-    "pmce_vertex_sa_ex_f32": [_f, _f, _f, _f, _f, _i, _i, _s],
     "pmce_vertex_sab_scratch_floats": [_i],
     "pmce_vertex_sab_split_f32": [_f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _i, _s],
     "pmce_tokens_kv_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _f, _f, _f, _i, _s],

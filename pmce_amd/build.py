@@ -20,11 +20,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 FILE_FLAGS = {src: NO_PACKED_FP32 for src in SOURCES if src.endswith(".hip")}
 
-# The diagnostics library (NOT the product; scripts/microbench/README): the two experimental split-GEMM variants kept for the record and
-# the bystander kernels of the matrix-pipe interference report, which ARE packed-fp32 code on purpose.
+# The diagnostics library (NOT the product): the bystander kernels of the matrix-pipe interference report, which ARE packed-fp32 code on
+# purpose, and the f16-subnormal probe.  (The two experimental split-GEMM variants it carried until round 4 - wave-specialised 192x256,
+# 16x16x32 - are in the history: measured, not faster, profiles/r03_a_gemm_ws_*, r02_k_*.)
 DIAG_DIR = osp.join(HERE, "..", "scripts", "microbench")
 DIAG_LIB = osp.join(DIAG_DIR, "libpmce_diag.so")
-DIAG_SOURCES = ["diag_entry.hip", "gemm_split_ws.hip", "gemm_split_m16.hip", "dbg_victims.hip"]
+DIAG_SOURCES = ["dbg_victims.hip"]
 DIAG_FILE_FLAGS = {src: NO_PACKED_FP32 for src in DIAG_SOURCES if src != "dbg_victims.hip"}
 
 

@@ -8,12 +8,13 @@
 //
 // Kernels (V = 431 vertices, D = 64 channels, J <= 32 joints):
 //   vertex_init_gather   integer gather  vertxs = joints[:, vj_relation]                (CoevoDecoder.py:232)
-//   joint_embed          jf = joint_proj(jt)+pos ; xk = proj_j2v_dim(jf)+j2v_K_embed     (:177-180,:184)
-//   ca_fold              per clip: fold Wq into K and Wproj into V of the vertex<-joint cross-attention
-//   vertex_ca            fused AdaLN + vertex<-joint cross-attention + residual          (:83, :47-62, :23-29)
-//   adaln_mlp            x + Mlp(AdaLN(x)) (+ Linear(64->3) + coordinate residual)       (:85-86,:104,:189)
-//   adaln_qkv            qkv = Linear(64->192)(AdaLN(x))                                 (:103,:120)
-//   vertex_sa            flash-style 431x431 self-attention (2 heads) + proj + residual  (:118-131,:103)
+//   ca_fold              per clip: joint embedding (jf, xk; :177-180,:184) + Wq folded into K and Wproj into V of the vertex<-joint
+//                        cross-attention (+ the operands' f16 image for the split mode)
+//   vertex_ca            fused AdaLN + vertex<-joint cross-attention + residual          (:83, :47-62, :23-29)   [fp32 pipe, stand-alone]
+//   vertex_ca_mlp        the whole vertex-stream CrossAttentionBlock in one launch       (:82-87)                [both modes]
+//   adaln_mlp            x + Mlp(AdaLN(x)) (+ Linear(64->3) + coordinate residual)       (:85-86,:104,:189)      [both modes]
+//   adaln_qkv, vertex_sa qkv = Linear(64->192)(AdaLN(x)); flash-style 431x431 self-attention + proj + residual (:103,:118-131) [fp32 pipe]
+//   vertex_sab           the same two in ONE launch, three-product f16 form                                      [split mode]
 //   tokens_kv            k = Wk*AdaLN_k(xk)+bk, v = Wv*AdaLN_v(xv)+bv for the joint<-vertex direction
 //   joint_stream         block-3 joint stream: joint<-vertex CA + FFN + SA + FFN + coords (:183,:187,:189)
 #include "common.hpp"
@@ -1056,27 +1057,17 @@ __global__ __launch_bounds__(64 * NW) void vertex_ca_mlp_kernel(const float* __r
 // ======================================================================================================
 // adaln_qkv: qkv[tok][0:192] = Wqkv * AdaLN(x) + bqkv   (vertex self-attention input, CoevoDecoder.py:103,120)
 // ======================================================================================================
-// F16 (split mode): the product in the three-product f16 form of the FFN above - the weight as (hi, lo) fragments of W * 2^s from an image
-// made once (pmce_qkv_pack_f16: stage_weight_split's layout, then {2^s, 2^-s}); 72 matrix instructions of 32 cycles per 32-token
-// tile instead of 192 of 64.
+// (fp32 pipe; the split mode's qkv product lives inside vertex_sab, from the weight image of pmce_qkv_pack_f16: stage_weight_split's
+// layout of Wqkv * 2^s as (hi | lo) f16 fragments, then {2^s, 2^-s})
 #define QKV_IMG_FLOATS (192 * LDW64 + 32)
-// (the f16 form fits 2 workgroups per CU - 234 registers; the fp32 form's 192 64-cycle instructions per tile are scheduled over 497)
-template <bool F16>
-__global__ __launch_bounds__(256, F16 ? 2 : 1) void adaln_qkv_kernel(const float* __restrict__ xin, const float* __restrict__ GB,
+__global__ __launch_bounds__(256, 1) void adaln_qkv_kernel(const float* __restrict__ xin, const float* __restrict__ GB,
                                                         int gb_stride, int inst, const float* __restrict__ Wqkv,
                                                         const float* __restrict__ bqkv, float* __restrict__ qkv, int B) {
   __shared__ __attribute__((aligned(16))) float sW[192 * LDW64];
   __shared__ __attribute__((aligned(16))) float sT[4 * 32 * 32];  // per-wave output transpose tile: [token][8 chunks of 4 channels], chunk ^ (token & 7)
   __shared__ float sB[192];
-  __shared__ float sSc[2];
   const int tid = threadIdx.x;
-  if constexpr (F16) {  // Wqkv = the image
-    lds_dma_copy(sW, Wqkv, 192 * LDW64 * 4 / 1024, tid >> 6, 4, tid & 63);
-    if (tid < 2) sSc[tid] = Wqkv[192 * LDW64 + tid];
-    lds_dma_wait();
-  } else {
-    stage_weight<64>(sW, Wqkv, 192, tid, 256);
-  }
+  stage_weight<64>(sW, Wqkv, 192, tid, 256);
   if (tid < 192) sB[tid] = bqkv[tid];
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
@@ -1109,35 +1100,11 @@ __global__ __launch_bounds__(256, F16 ? 2 : 1) void adaln_qkv_kernel(const float
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       f32x16 acc[3];
-      if constexpr (F16) {
-        const float down = sSc[1];
-        tl_f16x8 ahi[4], alo[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) split_slots8(a + 8 * s, ahi[s], alo[s]);
+      for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt) {
-          f32x16 m, c;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) m[r] = c[r] = 0.f;
-          const float* w = sW + ((3 * half + nt) * 32 + n0) * LDW64 + hb * 8;
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const tl_f16x8 whi = *reinterpret_cast<const tl_f16x8*>(w + s * 16), wlo = *reinterpret_cast<const tl_f16x8*>(w + s * 16 + 4);
-            m = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, ahi[s], m, 0, 0, 0);
-            m = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, ahi[s], m, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, alo[s], c, 0, 0, 0);
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            acc[nt][r] = fmaf(fmaf(c[r], 0.00048828125f, m[r]), down, sB[(3 * half + nt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb]);
-        }
-      } else {
-#pragma unroll
-        for (int nt = 0; nt < 3; ++nt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[nt][r] = sB[(3 * half + nt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb];
-        tl_gemm<8, 3, LDW64>(sW + 3 * half * 32 * LDW64, a, acc, n0, hb);
-      }
+        for (int r = 0; r < 16; ++r) acc[nt][r] = sB[(3 * half + nt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb];
+      tl_gemm<8, 3, LDW64>(sW + 3 * half * 32 * LDW64, a, acc, n0, hb);
 #pragma unroll
       for (int nt = 0; nt < 3; ++nt) {
 #pragma unroll
@@ -1162,29 +1129,20 @@ __global__ __launch_bounds__(256, F16 ? 2 : 1) void adaln_qkv_kernel(const float
 }
 
 // ======================================================================================================
-// vertex_sa: y = x + proj(softmax(q k^T / sqrt(32)) v), 2 heads x 32, 431 x 431 per clip (CoevoDecoder.py:118-131).
+// vertex_sa (fp32 pipe): y = x + proj(softmax(q k^T / sqrt(32)) v), 2 heads x 32, 431 x 431 per clip (CoevoDecoder.py:118-131).
 // grid (2, B) x 448 threads: wave w owns query tile blockIdx.x*7+w for BOTH heads; the 14 key tiles (32 keys x
 // {k,v} x 64 ch) stream through a double-buffered LDS ring shared by the 7 waves.  S^T = K Q^T puts one query
 // per lane pair, so the online softmax is in-lane; P^T is reused directly as the B operand of O^T += V^T P^T.
+// (The split mode runs vertex_sab below: the same attention in the three-product f16 form, fused with its qkv product.)
 // ======================================================================================================
 #define SA_KLD 68
 #define SA_VLD 64
-#define SA_VTLD 36  // F16 form: V^T rows (one channel, 32 keys as 2 k-steps x 2 lane halves x (hi | lo) x 8 f16 = 32 floats) + 4
-// F16 = the three-product f16 form for both contractions (scores and output; the 64x64 projection stays on the fp32 pipe).  The
-// key tile is split into f16 (hi, lo) planes WHILE it is staged: K rows as A fragments in the slot order of the head's 32
-// channels, V TRANSPOSED (rows = channels, 8 keys per fragment) so that it is the A operand of O^T += V^T P^T; q is split once,
-// P per key tile.  One accumulator per product: the lo planes are kept at their true magnitude, and the register-side operands
-// carry a power of two that keeps THEIR lo halves normal f16 numbers (q: 2^10, undone inside the exp2's multiply-add; P: 2^6,
-// cancelled by 1/l).  The lo halves of small K / V elements (|x| < 0.25) are subnormal f16; the matrix pipe reads subnormals as
-// they are (scripts/microbench/mfma_denorm.hip, test_mfma_reads_f16_subnormals), so each costs at most 2^-25 absolute.
-// 24 matrix instructions of 32 cycles per key tile instead of 64 of 64.  The softmax rescales lazily: the reference maximum only
-// moves (a wave-uniform branch) when some query's tile maximum exceeds it by more than 2^8 - same mathematics, P <= 2^14 in f16.
-template <bool F16>
+#define SA_VTLD 36  // vertex_sab: V^T rows (one channel, 32 keys as 2 k-steps x 2 lane halves x (hi | lo) x 8 f16 = 32 floats) + 4
 __global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict__ xin, const float* __restrict__ qkv,
                                                         const float* __restrict__ Wp, const float* __restrict__ bp,
                                                         float* __restrict__ yout) {
   __shared__ __attribute__((aligned(16))) float sK[2][32 * SA_KLD];
-  __shared__ __attribute__((aligned(16))) float sVv[2][F16 ? 64 * SA_VTLD : 32 * SA_VLD];
+  __shared__ __attribute__((aligned(16))) float sVv[2][32 * SA_VLD];
   __shared__ __attribute__((aligned(16))) float sWp[64 * LDW64];
   const int b = blockIdx.y, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -1192,80 +1150,29 @@ __global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict_
   const float* qkv_b = qkv + (long long)b * NV * 192;
   stage_weight<64>(sWp, Wp, 64, tid, 448);
 
-  // staging assignment: 32 rows x 32 float4 (16 of k, 16 of v) = 1024 float4 per key tile.  fp32 form: thread -> (row, float4) in
-  // order.  f16 form: waves 0, 1 stage V - a thread takes 4 consecutive keys x 4 channels and writes, per channel, the 4 keys of
-  // its fragment group as one 8-byte (hi) and one 8-byte (lo) store into the transposed tile; waves 2 .. 6 stage K (512 float4
-  // over 320 threads), each float4 = 4 channels of one key = half a fragment group.
-  f32x4 pre[F16 ? 4 : 3];
-  const int vg = (tid >> 3) & 7, vq = (tid & 7) + 8 * (tid >> 6);  // V role: key group (keys 4 vg .. +3), channel quad
+  // staging: 32 rows x 32 float4 (16 of k, 16 of v) = 1024 float4 per key tile, thread -> (row, float4) in order
+  f32x4 pre[3];
   auto gload = [&](int jt) {
-    if constexpr (!F16) {
 #pragma unroll
-      for (int it = 0; it < 3; ++it) {
-        const int idx = tid + it * 448;
-        if (idx < 1024) {
-          const int rr = idx >> 5, c4 = idx & 31;
-          const int j = jt * 32 + rr;
-          pre[it] = (j < NV) ? *reinterpret_cast<const f32x4*>(qkv_b + (long long)j * 192 + 64 + 4 * c4)
-                             : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-    } else if (wave < 2) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int j = jt * 32 + 4 * vg + k;
-        pre[k] = (j < NV) ? *reinterpret_cast<const f32x4*>(qkv_b + (long long)j * 192 + 128 + 4 * vq) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int idx = tid - 128 + it * 320;
-        if (idx < 512) {
-          const int j = jt * 32 + (idx >> 4);
-          pre[it] = (j < NV) ? *reinterpret_cast<const f32x4*>(qkv_b + (long long)j * 192 + 64 + 4 * (idx & 15))
-                             : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+    for (int it = 0; it < 3; ++it) {
+      const int idx = tid + it * 448;
+      if (idx < 1024) {
+        const int rr = idx >> 5, c4 = idx & 31;
+        const int j = jt * 32 + rr;
+        pre[it] = (j < NV) ? *reinterpret_cast<const f32x4*>(qkv_b + (long long)j * 192 + 64 + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   };
   auto lstore = [&](int buf) {
-    if constexpr (!F16) {
 #pragma unroll
-      for (int it = 0; it < 3; ++it) {
-        const int idx = tid + it * 448;
-        if (idx < 1024) {
-          const int rr = idx >> 5, c4 = idx & 31;
-          if (c4 < 16)
-            *reinterpret_cast<f32x4*>(&sK[buf][rr * SA_KLD + 4 * c4]) = pre[it];
-          else
-            *reinterpret_cast<f32x4*>(&sVv[buf][rr * SA_VLD + 4 * (c4 - 16)]) = pre[it];
-        }
-      }
-    } else if (wave < 2) {
-      // V^T: key group vg -> k-step vg / 4, lane half (vg % 4) & 1, elements 4 ((vg % 4) >> 1) .. +3 of the 8-key fragment
-      const int ks = vg >> 2, g = vg & 3;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        tl_f16x4 hi, lo;
-        split4_plain(pre[0][i], pre[1][i], pre[2][i], pre[3][i], hi, lo);
-        _Float16* d = reinterpret_cast<_Float16*>(&sVv[buf][(4 * vq + i) * SA_VTLD + (ks * 2 + (g & 1)) * 8]) + (g >> 1) * 4;
-        *reinterpret_cast<tl_f16x4*>(d) = hi;
-        *reinterpret_cast<tl_f16x4*>(d + 8) = lo;
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int idx = tid - 128 + it * 320;
-        if (idx < 512) {
-          const int rr = idx >> 4, c4 = idx & 15;
-          tl_f16x4 hi, lo;
-          split4_plain(pre[it][0], pre[it][1], pre[it][2], pre[it][3], hi, lo);
-          // K: channels 4 c4 .. +3 of key rr -> head c4 / 8, k-step (c4 % 8) / 4, group c4 % 4 (stage_weight_split's order)
-          const int h = c4 >> 3, ks = (c4 >> 2) & 1, g = c4 & 3;
-          _Float16* d = reinterpret_cast<_Float16*>(&sK[buf][rr * SA_KLD + ((h * 2 + ks) * 2 + (g & 1)) * 8]) + (g >> 1) * 4;
-          *reinterpret_cast<tl_f16x4*>(d) = hi;
-          *reinterpret_cast<tl_f16x4*>(d + 8) = lo;
-        }
+    for (int it = 0; it < 3; ++it) {
+      const int idx = tid + it * 448;
+      if (idx < 1024) {
+        const int rr = idx >> 5, c4 = idx & 31;
+        if (c4 < 16)
+          *reinterpret_cast<f32x4*>(&sK[buf][rr * SA_KLD + 4 * c4]) = pre[it];
+        else
+          *reinterpret_cast<f32x4*>(&sVv[buf][rr * SA_VLD + 4 * (c4 - 16)]) = pre[it];
       }
     }
   };
@@ -1276,17 +1183,10 @@ __global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict_
   const long long tok = (long long)b * NV + (valid ? v : NV - 1);
   float q[32];
   load_slots(qkv + tok * 192, q, hb);
-  // 32^-0.5 * log2(e): scores are kept in log2 units so the softmax uses the native v_exp_f32 (2^x); the f16 form carries 2^10 more
-  const float scale = 0.17677669529663688110f * 1.44269504088896340736f * (F16 ? 1024.0f : 1.0f);
+  // 32^-0.5 * log2(e): scores are kept in log2 units so the softmax uses the native v_exp_f32 (2^x)
+  const float scale = 0.17677669529663688110f * 1.44269504088896340736f;
 #pragma unroll
-  for (int s = 0; s < 32; ++s) q[s] = pinned(q[s] * scale);  // ONE fp32 value for both planes, whatever the code around it (common.hpp)
-  tl_f16x8 qhi[2][2], qlo[2][2];  // [head][k-step]
-  if constexpr (F16) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) split_slots8_plain(q + 16 * h + 8 * ks, qhi[h][ks], qlo[h][ks]);
-  }
+  for (int s = 0; s < 32; ++s) q[s] = pinned(q[s] * scale);
 
   f32x16 O[2];
   float mrun[2], lrun[2];
@@ -1297,123 +1197,48 @@ __global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) O[h][r] = 0.f;
   }
-  constexpr float kQs = 0.0009765625f;     // 2^-10: scores of the f16 form -> log2 units
-  constexpr float kLazy = 8.0f * 1024.0f;  // the reference maximum moves when a tile maximum exceeds it by 2^8 (in score units)
-  float off[2] = {0.f, 0.f};               // 6 - mrun * 2^-10: P = 2^(s * 2^-10 + off) <= 2^14
-
   // tile jt + 1 is written to LDS at the TOP of iteration jt (from the registers iteration jt - 1 loaded), tile jt + 2 is fetched
-  // right after: the staging arithmetic runs under the fragment reads' latency instead of in front of the barrier
+  // right after: the staging runs under the fragment reads' latency instead of in front of the barrier
   gload(0);
   lstore(0);
   if (NTILE > 1) gload(1);
   __syncthreads();
   for (int jt = 0; jt < NTILE; ++jt) {
     const int buf = jt & 1;
-    if constexpr (!F16) {
-      if (jt + 1 < NTILE) lstore(buf ^ 1);
-      if (jt + 2 < NTILE) gload(jt + 2);
+    if (jt + 1 < NTILE) lstore(buf ^ 1);
+    if (jt + 2 < NTILE) gload(jt + 2);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        f32x16 S;
+    for (int h = 0; h < 2; ++h) {
+      f32x16 S;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S[r] = 0.f;
-        tl_gemm<4, 1, SA_KLD>(&sK[buf][32 * h], q + 16 * h, &S, n0, hb);
-        float mt = -INFINITY;
+      for (int r = 0; r < 16; ++r) S[r] = 0.f;
+      tl_gemm<4, 1, SA_KLD>(&sK[buf][32 * h], q + 16 * h, &S, n0, hb);
+      float mt = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
-          const float sv = (j < NV) ? S[r] : -INFINITY;
-          S[r] = sv;
-          mt = fmaxf(mt, sv);
-        }
-        mt = pair_max(mt);
-        const float mn = fmaxf(mrun[h], mt);
-        const float corr = __builtin_amdgcn_exp2f(mrun[h] - mn);
-        float pr[16], sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          pr[r] = __builtin_amdgcn_exp2f(S[r] - mn);
-          sum += pr[r];
-        }
-        lrun[h] = lrun[h] * corr + pair_sum(sum);
-        mrun[h] = mn;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) O[h][r] *= corr;
-        const float* vb = &sVv[buf][4 * hb * SA_VLD + 32 * h + n0];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          const float a = vb[((s & 3) + 8 * (s >> 2)) * SA_VLD];
-          O[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pr[s], O[h], 0, 0, 0);
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
+        const float sv = (j < NV) ? S[r] : -INFINITY;
+        S[r] = sv;
+        mt = fmaxf(mt, sv);
       }
-    } else {
-      // all 16 fragments of the tile are read up front (one exposed LDS latency per tile; 1 workgroup per CU leaves the registers)
-      tl_f16x8 kf[2][2][2], vf[2][2][2];  // [head][k-step][hi | lo]
+      mt = pair_max(mt);
+      const float mn = fmaxf(mrun[h], mt);
+      const float corr = __builtin_amdgcn_exp2f(mrun[h] - mn);
+      float pr[16], sum = 0.f;
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const float* kp = &sK[buf][n0 * SA_KLD + ((h * 2 + ks) * 2 + hb) * 8];
-          kf[h][ks][0] = *reinterpret_cast<const tl_f16x8*>(kp);
-          kf[h][ks][1] = *reinterpret_cast<const tl_f16x8*>(kp + 4);
-        }
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const float* vp = &sVv[buf][(32 * h + n0) * SA_VTLD + (ks * 2 + hb) * 8];
-          vf[h][ks][0] = *reinterpret_cast<const tl_f16x8*>(vp);
-          vf[h][ks][1] = *reinterpret_cast<const tl_f16x8*>(vp + 4);
-        }
-      asm volatile("" ::: "memory");
-      if (jt + 1 < NTILE) lstore(buf ^ 1);
-      if (jt + 2 < NTILE) gload(jt + 2);
-      f32x16 S[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) S[h][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          S[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[h][ks][0], qhi[h][ks], S[h], 0, 0, 0);
-          S[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[h][ks][1], qhi[h][ks], S[h], 0, 0, 0);
-          S[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[h][ks][0], qlo[h][ks], S[h], 0, 0, 0);
-        }
+      for (int r = 0; r < 16; ++r) {
+        pr[r] = __builtin_amdgcn_exp2f(S[r] - mn);
+        sum += pr[r];
       }
+      lrun[h] = lrun[h] * corr + pair_sum(sum);
+      mrun[h] = mn;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float mt = -INFINITY;  // this lane's half of the tile; the pair is only joined when the reference maximum moves
+      for (int r = 0; r < 16; ++r) O[h][r] *= corr;
+      const float* vb = &sVv[buf][4 * hb * SA_VLD + 32 * h + n0];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
-          const float sv = (j < NV) ? S[h][r] : -INFINITY;
-          S[h][r] = sv;
-          mt = fmaxf(mt, sv);
-        }
-        if (__builtin_amdgcn_ballot_w64(mt > mrun[h] + kLazy) != 0) {  // always on the first tile (mrun = -inf), rarely afterwards
-          const float mn = fmaxf(mrun[h], pair_max(mt));
-          const float corr = __builtin_amdgcn_exp2f((mrun[h] - mn) * kQs);
-          mrun[h] = mn;
-          off[h] = fmaf(mn, -kQs, 6.0f);
-          lrun[h] *= corr;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) O[h][r] *= corr;
-        }
-        float pr[16], sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          pr[r] = __builtin_amdgcn_exp2f(fmaf(S[h][r], kQs, off[h]));
-          sum += pr[r];
-        }
-        lrun[h] += sum;  // per lane (its 16 keys of every tile); the pair is summed once after the loop
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          tl_f16x8 phi, plo;
-          split_slots8_plain(pr + 8 * ks, phi, plo);
-          O[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[h][ks][0], phi, O[h], 0, 0, 0);
-          O[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[h][ks][1], phi, O[h], 0, 0, 0);
-          O[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[h][ks][0], plo, O[h], 0, 0, 0);
-        }
+      for (int s = 0; s < 16; ++s) {
+        const float a = vb[((s & 3) + 8 * (s >> 2)) * SA_VLD];
+        O[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pr[s], O[h], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -1421,7 +1246,7 @@ __global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict_
   float att[32];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const float inv = 1.0f / (F16 ? pair_sum(lrun[h]) : lrun[h]);  // (the f16 form's l carries the same 2^6 as its O)
+    const float inv = 1.0f / lrun[h];
 #pragma unroll
     for (int r = 0; r < 16; ++r) att[16 * h + r] = O[h][r] * inv;
   }
@@ -1443,272 +1268,32 @@ __global__ __launch_bounds__(448) void vertex_sa_kernel(const float* __restrict_
   }
 }
 
-// The same attention with TWO query tiles per wave (one workgroup per clip instead of two): staging a key tile (global loads, split, LDS
-// writes), its barrier and its fragment reads are paid per (workgroup, key tile) whatever the number of queries a wave owns - 0.8 of
-// the 2.2 us a key tile costs (profiles/r04_g_vertex_sa_ablation.txt) - and 2 B workgroups on 256 CUs are two rounds from B = 129 on.
-// Every query tile's arithmetic is the one-tile kernel's in the same order (bit-identical results: a clip does not depend on the batch
-// it came in); the launcher takes this form where the one-tile form would need more than one round.
-__global__ __launch_bounds__(448) void vertex_sa2_kernel(const float* __restrict__ xin, const float* __restrict__ qkv,
-                                                        const float* __restrict__ Wp, const float* __restrict__ bp,
-                                                        float* __restrict__ yout) {
-  __shared__ __attribute__((aligned(16))) float sK[2][32 * SA_KLD];
-  constexpr bool F16 = true;
-  constexpr int QT = 2;
-  __shared__ __attribute__((aligned(16))) float sVv[2][64 * SA_VTLD];
-  __shared__ __attribute__((aligned(16))) float sWp[64 * LDW64];
-  __shared__ __attribute__((aligned(16))) float sQ[7 * 8 * 64 * 4];  // the second query tile's 8 q fragments per wave (56 KB)
-  const int b = blockIdx.y, tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int n0 = lane & 31, hb = lane >> 5;
-  const float* qkv_b = qkv + (long long)b * NV * 192;
-  stage_weight<64>(sWp, Wp, 64, tid, 448);
-
-  // staging assignment: 32 rows x 32 float4 (16 of k, 16 of v) = 1024 float4 per key tile.  fp32 form: thread -> (row, float4) in
-  // order.  f16 form: waves 0, 1 stage V - a thread takes 4 consecutive keys x 4 channels and writes, per channel, the 4 keys of
-  // its fragment group as one 8-byte (hi) and one 8-byte (lo) store into the transposed tile; waves 2 .. 6 stage K (512 float4
-  // over 320 threads), each float4 = 4 channels of one key = half a fragment group.
-  f32x4 pre[F16 ? 4 : 3];
-  const int vg = (tid >> 3) & 7, vq = (tid & 7) + 8 * (tid >> 6);  // V role: key group (keys 4 vg .. +3), channel quad
-  auto gload = [&](int jt) {
-    if constexpr (!F16) {
-#pragma unroll
-      for (int it = 0; it < 3; ++it) {
-        const int idx = tid + it * 448;
-        if (idx < 1024) {
-          const int rr = idx >> 5, c4 = idx & 31;
-          const int j = jt * 32 + rr;
-          pre[it] = (j < NV) ? *reinterpret_cast<const f32x4*>(qkv_b + (long long)j * 192 + 64 + 4 * c4)
-                             : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-    } else if (wave < 2) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int j = jt * 32 + 4 * vg + k;
-        pre[k] = (j < NV) ? *reinterpret_cast<const f32x4*>(qkv_b + (long long)j * 192 + 128 + 4 * vq) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int idx = tid - 128 + it * 320;
-        if (idx < 512) {
-          const int j = jt * 32 + (idx >> 4);
-          pre[it] = (j < NV) ? *reinterpret_cast<const f32x4*>(qkv_b + (long long)j * 192 + 64 + 4 * (idx & 15))
-                             : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-    }
-  };
-  auto lstore = [&](int buf) {
-    if constexpr (!F16) {
-#pragma unroll
-      for (int it = 0; it < 3; ++it) {
-        const int idx = tid + it * 448;
-        if (idx < 1024) {
-          const int rr = idx >> 5, c4 = idx & 31;
-          if (c4 < 16)
-            *reinterpret_cast<f32x4*>(&sK[buf][rr * SA_KLD + 4 * c4]) = pre[it];
-          else
-            *reinterpret_cast<f32x4*>(&sVv[buf][rr * SA_VLD + 4 * (c4 - 16)]) = pre[it];
-        }
-      }
-    } else if (wave < 2) {
-      // V^T: key group vg -> k-step vg / 4, lane half (vg % 4) & 1, elements 4 ((vg % 4) >> 1) .. +3 of the 8-key fragment
-      const int ks = vg >> 2, g = vg & 3;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        tl_f16x4 hi, lo;
-        split4_plain(pre[0][i], pre[1][i], pre[2][i], pre[3][i], hi, lo);
-        _Float16* d = reinterpret_cast<_Float16*>(&sVv[buf][(4 * vq + i) * SA_VTLD + (ks * 2 + (g & 1)) * 8]) + (g >> 1) * 4;
-        *reinterpret_cast<tl_f16x4*>(d) = hi;
-        *reinterpret_cast<tl_f16x4*>(d + 8) = lo;
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int idx = tid - 128 + it * 320;
-        if (idx < 512) {
-          const int rr = idx >> 4, c4 = idx & 15;
-          tl_f16x4 hi, lo;
-          split4_plain(pre[it][0], pre[it][1], pre[it][2], pre[it][3], hi, lo);
-          // K: channels 4 c4 .. +3 of key rr -> head c4 / 8, k-step (c4 % 8) / 4, group c4 % 4 (stage_weight_split's order)
-          const int h = c4 >> 3, ks = (c4 >> 2) & 1, g = c4 & 3;
-          _Float16* d = reinterpret_cast<_Float16*>(&sK[buf][rr * SA_KLD + ((h * 2 + ks) * 2 + (g & 1)) * 8]) + (g >> 1) * 4;
-          *reinterpret_cast<tl_f16x4*>(d) = hi;
-          *reinterpret_cast<tl_f16x4*>(d + 8) = lo;
-        }
-      }
-    }
-  };
-
-  // wave w owns query tiles 2 w and 2 w + 1 (14 tiles = the clip): every per-tile quantity below is the one-tile kernel's, twice
-  // The first tile's q fragments stay in registers; the second tile's (32 registers) live in LDS, 16 bytes per lane and fragment, and are
-  // read just before their products - with both in registers the kernel spilled 22 (the one-workgroup-per-CU LDS budget has the room).
-  bool valid[QT];
-  long long tok[QT];
-  tl_f16x8 qhi[2][2], qlo[2][2];  // tile 0: [head][k-step]
-  tl_f16x8* sQw = reinterpret_cast<tl_f16x8*>(sQ) + wave * 8 * 64 + lane;  // fragment f of this lane: sQw[f * 64]
-  const float scale = 0.17677669529663688110f * 1.44269504088896340736f * 1024.0f;
-#pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    const int v = (wave * QT + t) * 32 + n0;
-    valid[t] = v < NV;
-    tok[t] = (long long)b * NV + (valid[t] ? v : NV - 1);
-    float q[32];
-    load_slots(qkv + tok[t] * 192, q, hb);
-#pragma unroll
-    for (int s = 0; s < 32; ++s) q[s] = pinned(q[s] * scale);  // ONE fp32 value for both planes, whatever the code around it (common.hpp)
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        if (t == 0) {
-          split_slots8_plain(q + 16 * h + 8 * ks, qhi[h][ks], qlo[h][ks]);
-        } else {
-          tl_f16x8 fh, fl;
-          split_slots8_plain(q + 16 * h + 8 * ks, fh, fl);
-          sQw[((h * 2 + ks) * 2 + 0) * 64] = fh;
-          sQw[((h * 2 + ks) * 2 + 1) * 64] = fl;
-        }
-      }
-  }
-  f32x16 O[QT][2];
-  float mrun[QT][2], lrun[QT][2], off[QT][2];
-#pragma unroll
-  for (int t = 0; t < QT; ++t)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      mrun[t][h] = -INFINITY;
-      lrun[t][h] = 0.f;
-      off[t][h] = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) O[t][h][r] = 0.f;
-    }
-  constexpr float kQs = 0.0009765625f;
-  constexpr float kLazy = 8.0f * 1024.0f;
-
-  // tile jt + 1 is written to LDS at the TOP of iteration jt (from the registers iteration jt - 1 loaded), tile jt + 2 is fetched
-  // right after: the staging arithmetic runs under the fragment reads' latency instead of in front of the barrier
-  gload(0);
-  lstore(0);
-  if (NTILE > 1) gload(1);
-  __syncthreads();
-  for (int jt = 0; jt < NTILE; ++jt) {
-    const int buf = jt & 1;
-    // a head's 8 fragments serve BOTH query tiles; the next key tile is staged once the first head's reads are under way
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      tl_f16x8 kf[2][2], vf[2][2];  // [k-step][hi | lo]
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const float* kp = &sK[buf][n0 * SA_KLD + ((h * 2 + ks) * 2 + hb) * 8];
-        kf[ks][0] = *reinterpret_cast<const tl_f16x8*>(kp);
-        kf[ks][1] = *reinterpret_cast<const tl_f16x8*>(kp + 4);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const float* vp = &sVv[buf][(32 * h + n0) * SA_VTLD + (ks * 2 + hb) * 8];
-        vf[ks][0] = *reinterpret_cast<const tl_f16x8*>(vp);
-        vf[ks][1] = *reinterpret_cast<const tl_f16x8*>(vp + 4);
-      }
-      if (h == 0) {
-        asm volatile("" ::: "memory");
-        if (jt + 1 < NTILE) lstore(buf ^ 1);
-        if (jt + 2 < NTILE) gload(jt + 2);
-      }
-#pragma unroll
-      for (int t = 0; t < QT; ++t) {
-        f32x16 S;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) S[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const tl_f16x8 qh = t == 0 ? qhi[h][ks] : sQw[((h * 2 + ks) * 2 + 0) * 64];
-          const tl_f16x8 ql = t == 0 ? qlo[h][ks] : sQw[((h * 2 + ks) * 2 + 1) * 64];
-          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][0], qh, S, 0, 0, 0);
-          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][1], qh, S, 0, 0, 0);
-          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][0], ql, S, 0, 0, 0);
-        }
-        float mt = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
-          const float sv = (j < NV) ? S[r] : -INFINITY;
-          S[r] = sv;
-          mt = fmaxf(mt, sv);
-        }
-        if (__builtin_amdgcn_ballot_w64(mt > mrun[t][h] + kLazy) != 0) {
-          const float mn = fmaxf(mrun[t][h], pair_max(mt));
-          const float corr = __builtin_amdgcn_exp2f((mrun[t][h] - mn) * kQs);
-          mrun[t][h] = mn;
-          off[t][h] = fmaf(mn, -kQs, 6.0f);
-          lrun[t][h] *= corr;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) O[t][h][r] *= corr;
-        }
-        float pr[16], sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          pr[r] = __builtin_amdgcn_exp2f(fmaf(S[r], kQs, off[t][h]));
-          sum += pr[r];
-        }
-        lrun[t][h] += sum;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          tl_f16x8 phi, plo;
-          split_slots8_plain(pr + 8 * ks, phi, plo);
-          O[t][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[ks][0], phi, O[t][h], 0, 0, 0);
-          O[t][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[ks][1], phi, O[t][h], 0, 0, 0);
-          O[t][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[ks][0], plo, O[t][h], 0, 0, 0);
-        }
-      }
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    float att[32];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const float inv = 1.0f / pair_sum(lrun[t][h]);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) att[16 * h + r] = O[t][h][r] * inv;
-    }
-    float x[32];
-    load_slots(xin + tok[t] * 64, x, hb);
-    f32x16 acc[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nt][r] = bp[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb] + x[16 * nt + r];
-    tl_gemm<8, 2, LDW64>(sWp, att, acc, n0, hb);
-    if (valid[t]) {
-      float y[32];
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) y[16 * nt + r] = acc[nt][r];
-      store_slots(yout + tok[t] * 64, y, hb);
-    }
-  }
-}
-
 // ======================================================================================================
-// vertex_sab - the attention half of the vertex stream's AdaLN Block in ONE launch (split mode; round 5):
+// vertex_sab - the attention half of the vertex stream's AdaLN Block in ONE launch (split mode):
 //   y = x + proj(softmax(q k^T / sqrt(32)) v),   [q | k | v] = Linear(64 -> 192)(AdaLN(x))      (CoevoDecoder.py:103, :118-131)
-// i.e. adaln_qkv_kernel<true> and vertex_sa(2)_kernel<true> without the [B,431,192] fp32 QKV round trip and without the second launch.
-// Phase 1: every wave runs AdaLN + the 64 -> 192 product (three-product f16 form, the weight's image of pmce_qkv_pack_f16) for two
-//   32-token tiles.  The accumulator layouts ARE the operand layouts of phase 2, so nothing is transposed or re-laid-out:
+// 431 x 431 per clip, 2 heads x 32, flash-style; every contraction but the 64 x 64 output projection in the three-product f16 form.
+// Phase 1: every wave runs AdaLN + the 64 -> 192 product (the weight's image of pmce_qkv_pack_f16, staged by LDS-DMA) for two 32-token
+//   tiles.  The accumulator layouts ARE the operand layouts of phase 2, so nothing is transposed or re-laid-out:
 //     q (swapped product, lane = token, slot order of the head's channels)  = the B fragments of S^T = K Q^T: split in registers;
 //     k (swapped product)                                                   = the A fragments of S^T (lane = key);
 //     v (operands exchanged: D[token][channel], lane = channel, r = key)     = the A fragments of O^T += V^T P^T (lane = channel, 8 keys).
-//   k and v leave as f16 (hi | lo) fragment planes - the bytes the staging waves of vertex_sa wrote into LDS - for a per-clip scratch
-//   (14 key tiles x 16 KB, written and read by this workgroup only: it never leaves the L2): the whole clip's keys do not fit in LDS
-//   beside the weight image (224 KB).  Every value is the one adaln_qkv + the staging of vertex_sa produce (same formulas, pinned to
-//   ONE fp32 value before it is split), so the result is bit-identical to the two-launch form (test_vertex_sab_*).
-// Phase 2: vertex_sa2's key loop; staging a key tile is now a plain 16 KB copy (no split arithmetic, all 7 waves share it).
-// QT = 2: one workgroup per clip, two query tiles per wave (B > 128).  QT = 1: two workgroups per clip, one query tile per wave; both
-//   compute all 14 key tiles (into their own scratch halves): at B <= 128 the second workgroup runs on a CU that would idle.
+//   k and v leave as f16 (hi | lo) fragment planes for a per-clip scratch (14 key tiles x 16 KB, written and read by this workgroup only:
+//   it never leaves the L2) - the whole clip's keys do not fit in LDS beside the weight image (224 KB).  Every value is pinned to ONE
+//   fp32 number before it is split (common.hpp).  (Until round 5 two launches - adaln_qkv with a [B,431,192] fp32 QKV round trip, then
+//   the attention, whose staging waves split and transposed K / V on their way into LDS: the fused kernel reproduced that form bit for
+//   bit, profiles/r05_a_*, before it was removed.)
+// Phase 2: the 14 key tiles stream through a double-buffered LDS ring shared by the 7 waves (a plain 16 KB copy per tile).  S^T = K Q^T
+//   puts one query per lane pair, so the online softmax is in-lane, and P^T in the accumulator layout is directly the B operand of
+//   O^T += V^T P^T.  One accumulator per product: the lo planes are kept at their true magnitude and the register-side operands carry a
+//   power of two that keeps THEIR lo halves normal f16 numbers (q: 2^10, undone inside the exp2's multiply-add; P: 2^6, cancelled by 1/l).
+//   The lo halves of small K / V elements (|x| < 0.25) are subnormal f16; the matrix pipe reads subnormals as they are
+//   (scripts/microbench/mfma_denorm.hip, test_mfma_reads_f16_subnormals), so each costs at most 2^-25 absolute.  24 matrix instructions
+//   of 32 cycles per key tile and query tile.  The softmax rescales lazily: the reference maximum only moves (a wave-uniform branch)
+//   when some query's tile maximum exceeds it by more than 2^8 - same mathematics, P <= 2^14 in f16.
+// QT = 2: one workgroup per clip, two query tiles per wave (B > 128: staging, barrier and fragment reads are paid per (workgroup, key
+//   tile) whatever the number of queries a wave owns, and 2 B workgroups would be two rounds).  QT = 1: two workgroups per clip, one
+//   query tile per wave; both compute all 14 key tiles (into their own scratch halves): at B <= 128 the second workgroup runs on a CU
+//   that would idle.  Same arithmetic per query tile in the same order: a clip's result does not depend on the batch it came in.
 // ======================================================================================================
 #define SAB_TILE_FLOATS 4096  // one key tile in scratch: K [32 keys][64 floats] then V^T [64 channels][32 floats]
 template <int QT>
@@ -1764,7 +1349,7 @@ __global__ __launch_bounds__(448) void vertex_sab_kernel(const float* __restrict
     const int v = T * 32 + n0;
     return (long long)b * NV + (v < NV ? v : NV - 1);
   };
-  // 32^-0.5 * log2(e) * 2^10 (vertex_sa_kernel<true>)
+  // 32^-0.5 * log2(e): scores in log2 units so that the softmax uses the native v_exp_f32 (2^x); times the 2^10 of q's f16 split
   const float scale = 0.17677669529663688110f * 1.44269504088896340736f * 1024.0f;
   tl_f16x8 qhi[2][2], qlo[2][2];  // query tile 0: [head][k-step]
   tl_f16x8* sQw = reinterpret_cast<tl_f16x8*>(sQ) + wave * 8 * 64 + lane;  // (QT = 2) fragment f of this lane: sQw[f * 64]
@@ -1777,7 +1362,7 @@ __global__ __launch_bounds__(448) void vertex_sab_kernel(const float* __restrict
       float q[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = pinned(fmaf(fmaf(c[r], 0.00048828125f, m[r]), down, sB[h * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb]));  // = adaln_qkv's q
+        const float v = pinned(fmaf(fmaf(c[r], 0.00048828125f, m[r]), down, sB[h * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb]));
         q[r] = pinned(v * scale);  // ONE fp32 value for both planes (common.hpp)
       }
 #pragma unroll
@@ -1815,7 +1400,7 @@ __global__ __launch_bounds__(448) void vertex_sab_kernel(const float* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float v = pinned(fmaf(fmaf(c[r], 0.00048828125f, m[r]), down, sB[64 + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb]));
-          kv_[r] = tok_valid ? v : 0.f;  // keys beyond the clip: zero rows, as vertex_sa stages them (their scores are masked)
+          kv_[r] = tok_valid ? v : 0.f;  // keys beyond the clip: zero rows (their scores are masked)
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -1858,7 +1443,7 @@ __global__ __launch_bounds__(448) void vertex_sab_kernel(const float* __restrict
   }
   __syncthreads();  // every key tile of the clip is in the scratch (and visible to the workgroup); the weight image is dead
 
-  // ---- phase 2: vertex_sa2_kernel's key loop ---------------------------------------------------------------------------------
+  // ---- phase 2: the key loop ---------------------------------------------------------------------------------------------------
   float* sWp = sW;
   stage_weight<64>(sWp, Wp, 64, tid, 448);
   f32x4 pre[3];  // a key tile = 1024 float4 over 448 threads
@@ -2379,15 +1964,12 @@ __global__ __launch_bounds__(256) void j_regress_kernel(const float* __restrict_
 // ======================================================================================================
 // C-ABI launchers
 // ======================================================================================================
-#ifndef PMCE_AB_MLP_WAVES   // A/B builds only (scripts/build_ab.sh): waves per workgroup of the FFN kernels
-#define PMCE_AB_MLP_WAVES 8
-#endif
-#ifndef PMCE_AB_CAM_WAVES
-#define PMCE_AB_CAM_WAVES 7
-#endif
+// waves per workgroup of the two FFN-carrying kernels (two per SIMD: one wave per SIMD measured 33 % slower, profiles/r05_b_*)
+#define MLP_WAVES 8
+#define CAM_WAVES 7
 static int mlp_grid(int B) {
   const int tiles = B * NTILE;
-  int g = (tiles + PMCE_AB_MLP_WAVES - 1) / PMCE_AB_MLP_WAVES;
+  int g = (tiles + MLP_WAVES - 1) / MLP_WAVES;
   return g < 256 ? g : 256;
 }
 static int tl_grid(int B, int per_cu) {
@@ -2465,12 +2047,12 @@ extern "C" int pmce_adaln_mlp_pk_f32(const float* xin, const float* GB, int gb_s
   const size_t lds = (size_t)(256 * LDW64 + 64 * LDW256 + 256 + 64 + 32) * sizeof(float);
   static std::atomic<unsigned long long> attr{0}, attr_s{0};
   if (split_f16) {
-    PMCE_TRY(pmce_opt_in_lds((const void*)adaln_mlp_kernel<true, PMCE_AB_MLP_WAVES>, (int)lds, attr_s, "adaln_mlp"));
-    hipLaunchKernelGGL((adaln_mlp_kernel<true, PMCE_AB_MLP_WAVES>), dim3(mlp_grid(B)), dim3(64 * PMCE_AB_MLP_WAVES), lds, stream, xin, GB, gb_stride, inst, W1, b1, W2, b2,
+    PMCE_TRY(pmce_opt_in_lds((const void*)adaln_mlp_kernel<true, MLP_WAVES>, (int)lds, attr_s, "adaln_mlp"));
+    hipLaunchKernelGGL((adaln_mlp_kernel<true, MLP_WAVES>), dim3(mlp_grid(B)), dim3(64 * MLP_WAVES), lds, stream, xin, GB, gb_stride, inst, W1, b1, W2, b2,
                        yout, Wc, bc, vt_in, vt_out, B, ffn_img);
   } else {
-    PMCE_TRY(pmce_opt_in_lds((const void*)adaln_mlp_kernel<false, PMCE_AB_MLP_WAVES>, (int)lds, attr, "adaln_mlp"));
-    hipLaunchKernelGGL((adaln_mlp_kernel<false, PMCE_AB_MLP_WAVES>), dim3(mlp_grid(B)), dim3(64 * PMCE_AB_MLP_WAVES), lds, stream, xin, GB, gb_stride, inst, W1, b1, W2, b2,
+    PMCE_TRY(pmce_opt_in_lds((const void*)adaln_mlp_kernel<false, MLP_WAVES>, (int)lds, attr, "adaln_mlp"));
+    hipLaunchKernelGGL((adaln_mlp_kernel<false, MLP_WAVES>), dim3(mlp_grid(B)), dim3(64 * MLP_WAVES), lds, stream, xin, GB, gb_stride, inst, W1, b1, W2, b2,
                        yout, Wc, bc, vt_in, vt_out, B, nullptr);
   }
   return pmce_check_launch("adaln_mlp");
@@ -2502,13 +2084,13 @@ extern "C" int pmce_vertex_ca_mlp_pk_f32(const float* xq, const float* vt, const
   const int g = 2 * B < 256 ? 2 * B : 256;
   if (split_f16) {
     PMCE_REQUIRE(ca_img && (reinterpret_cast<uintptr_t>(ca_img) & 15) == 0, "vertex_ca_mlp: the split_f16 form needs the operands' image (pmce_ca_fold_img_f32)");
-    PMCE_TRY(pmce_opt_in_lds((const void*)vertex_ca_mlp_kernel<true, PMCE_AB_CAM_WAVES>, 163840, attr_s, "vertex_ca_mlp"));
-    hipLaunchKernelGGL((vertex_ca_mlp_kernel<true, PMCE_AB_CAM_WAVES>), dim3(g), dim3(64 * PMCE_AB_CAM_WAVES), lds, stream, xq, vt, Wv3, Eq, Kf, s0, Vf, bp, GB, gb_stride,
+    PMCE_TRY(pmce_opt_in_lds((const void*)vertex_ca_mlp_kernel<true, CAM_WAVES>, 163840, attr_s, "vertex_ca_mlp"));
+    hipLaunchKernelGGL((vertex_ca_mlp_kernel<true, CAM_WAVES>), dim3(g), dim3(64 * CAM_WAVES), lds, stream, xq, vt, Wv3, Eq, Kf, s0, Vf, bp, GB, gb_stride,
                        inst, W1, b1, W2, b2, yout, B, J, ffn_img, ca_img);
   } else {
     PMCE_REQUIRE(Kf && s0 && Vf, "vertex_ca_mlp: null pointer");
-    PMCE_TRY(pmce_opt_in_lds((const void*)vertex_ca_mlp_kernel<false, PMCE_AB_CAM_WAVES>, 163840, attr, "vertex_ca_mlp"));
-    hipLaunchKernelGGL((vertex_ca_mlp_kernel<false, PMCE_AB_CAM_WAVES>), dim3(g), dim3(64 * PMCE_AB_CAM_WAVES), lds, stream, xq, vt, Wv3, Eq, Kf, s0, Vf, bp, GB, gb_stride,
+    PMCE_TRY(pmce_opt_in_lds((const void*)vertex_ca_mlp_kernel<false, CAM_WAVES>, 163840, attr, "vertex_ca_mlp"));
+    hipLaunchKernelGGL((vertex_ca_mlp_kernel<false, CAM_WAVES>), dim3(g), dim3(64 * CAM_WAVES), lds, stream, xq, vt, Wv3, Eq, Kf, s0, Vf, bp, GB, gb_stride,
                        inst, W1, b1, W2, b2, yout, B, J, nullptr, nullptr);
   }
   return pmce_check_launch("vertex_ca_mlp");
@@ -2524,10 +2106,10 @@ extern "C" int pmce_vertex_ca_mlp_f32(const float* xq, const float* vt, const fl
 extern "C" int pmce_adaln_qkv_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* Wqkv,
                                   const float* bqkv, float* qkv, int B, hipStream_t stream) {
   PMCE_REQUIRE(xin && GB && Wqkv && bqkv && qkv && B > 0, "adaln_qkv: null pointer");
-  hipLaunchKernelGGL(adaln_qkv_kernel<false>, dim3(tl_grid(B, 2)), dim3(256), 0, stream, xin, GB, gb_stride, inst, Wqkv, bqkv, qkv, B);
+  hipLaunchKernelGGL(adaln_qkv_kernel, dim3(tl_grid(B, 2)), dim3(256), 0, stream, xin, GB, gb_stride, inst, Wqkv, bqkv, qkv, B);
   return pmce_check_launch("adaln_qkv");
 }
-// The same product in the three-product f16 form (fp32 in, fp32 out): qkv_img = pmce_qkv_pack_f16(Wqkv), made once per weight.
+// The qkv weight's f16 image for pmce_vertex_sab_split_f32: made once per weight.
 __global__ __launch_bounds__(256) void qkv_pack_kernel(const float* __restrict__ W, float* __restrict__ img) {
   __shared__ float red[16];
   float up, down;
@@ -2544,25 +2126,12 @@ extern "C" int pmce_qkv_pack_f16(const float* Wqkv, float* img, hipStream_t stre
   hipLaunchKernelGGL(qkv_pack_kernel, dim3(1), dim3(256), 0, stream, Wqkv, img);
   return pmce_check_launch("qkv_pack_f16");
 }
-extern "C" int pmce_adaln_qkv_split_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* qkv_img,
-                                        const float* bqkv, float* qkv, int B, hipStream_t stream) {
-  PMCE_REQUIRE(xin && GB && qkv_img && bqkv && qkv && B > 0, "adaln_qkv_split: null pointer");
-  hipLaunchKernelGGL(adaln_qkv_kernel<true>, dim3(tl_grid(B, 2)), dim3(256), 0, stream, xin, GB, gb_stride, inst, qkv_img, bqkv, qkv, B);
-  return pmce_check_launch("adaln_qkv_split");
-}
 
-extern "C" int pmce_vertex_sa_ex_f32(const float* xin, const float* qkv, const float* Wp, const float* bp, float* yout, int B,
-                                     int split_f16, hipStream_t stream) {
-  PMCE_REQUIRE(xin && qkv && Wp && bp && yout && B > 0, "vertex_sa: null pointer");
-  static const int two_tiles = pmce_env_int("PMCE_SA_TWO_TILES", 1);  // A/B knob, read once
-  if (split_f16 && two_tiles && B > 128) hipLaunchKernelGGL(vertex_sa2_kernel, dim3(1, B), dim3(448), 0, stream, xin, qkv, Wp, bp, yout);
-  else if (split_f16) hipLaunchKernelGGL(vertex_sa_kernel<true>, dim3(2, B), dim3(448), 0, stream, xin, qkv, Wp, bp, yout);
-  else hipLaunchKernelGGL(vertex_sa_kernel<false>, dim3(2, B), dim3(448), 0, stream, xin, qkv, Wp, bp, yout);
-  return pmce_check_launch("vertex_sa");
-}
 extern "C" int pmce_vertex_sa_f32(const float* xin, const float* qkv, const float* Wp, const float* bp, float* yout, int B,
                                   hipStream_t stream) {
-  return pmce_vertex_sa_ex_f32(xin, qkv, Wp, bp, yout, B, 0, stream);
+  PMCE_REQUIRE(xin && qkv && Wp && bp && yout && B > 0, "vertex_sa: null pointer");
+  hipLaunchKernelGGL(vertex_sa_kernel, dim3(2, B), dim3(448), 0, stream, xin, qkv, Wp, bp, yout);
+  return pmce_check_launch("vertex_sa");
 }
 
 // The attention half of the vertex stream's AdaLN Block in one launch (split mode): AdaLN + qkv product + 431 x 431 attention + proj +

@@ -93,19 +93,6 @@ __device__ __forceinline__ int slot_channel(int s, int hb) { return 8 * (s >> 2)
 // selects".
 __device__ __forceinline__ float gelu_erf(float x) {
 #pragma clang fp contract(off)
-#ifdef PMCE_AB_OLD_GELU  // A/B builds only (scripts/build_ab.sh): the round-4 formula
-  const float z = x * 0.70710678118654752440f;
-  const float az = fabsf(z);
-  const float tt = __builtin_amdgcn_rcpf(fmaf(az, 0.3275911f, 1.0f));
-  float pp = fmaf(tt, 1.061405429f, -1.453152027f);
-  pp = fmaf(pp, tt, 1.421413741f);
-  pp = fmaf(pp, tt, -0.284496736f);
-  pp = fmaf(pp, tt, 0.254829592f);
-  const float ee = __builtin_amdgcn_exp2f((az * az) * -1.44269504088896340736f);
-  const float rr = fmaf(-(pp * tt), ee, 1.0f);
-  const float hh = x * 0.5f;
-  return fmaf(hh, copysignf(rr, z), hh);
-#endif
   const float a = fabsf(x);
   float p = fmaf(2.05025208e-06f, a, -3.00662196e-05f);
   p = fmaf(p, a, 0.000142456265f);

@@ -414,10 +414,9 @@ static void launch_gemm(const GemmParams& p, int batch, bool cmap, hipStream_t s
 // ceil(ceil(tiles / 8) / 32) tiles of BM x BN.  M = B*16*J is rarely a multiple of 128*256 (B=256, J=17: 544 row tiles
 // of 128), so the shape that quantises best wins; `ovh` is the measured per-area handicap of the smaller tiles at large
 // K (twice the operand traffic per FLOP for 64x64).  Blocks per CU (LDS: 2 x (BM+BN) x 128 B; VGPRs) only size the grid.
-// Tuning overrides (never set in production): initialised ONCE from PMCE_GEMM_TILE / PMCE_GEMM_GRID, changed only through
-// pmce_gemm_set_tuning (scripts/gemm_sweep.py) - no environment reads on the launch path.
-static std::atomic<int> g_force_tile{pmce_env_int("PMCE_GEMM_TILE", -1)};
-static std::atomic<int> g_force_grid{pmce_env_int("PMCE_GEMM_GRID", 0)};
+// Tuning overrides (never set in production): changed only through pmce_gemm_set_tuning (scripts/gemm_sweep.py).
+static std::atomic<int> g_force_tile{-1};
+static std::atomic<int> g_force_grid{0};
 extern "C" int pmce_gemm_set_tuning(int tile, int grid_per_cu) {
   g_force_tile.store(tile, std::memory_order_relaxed);
   g_force_grid.store(grid_per_cu, std::memory_order_relaxed);

@@ -21,7 +21,6 @@ struct SplitParams {
   int ntm, ntn;
   int c_div;             // > 0: C row r lives at (r % c_div) * c_lo + (r / c_div) * c_hi (elements); never with R
   long long c_lo, c_hi;
-  int skew;  // start delay of the second workgroup per CU, in units of 4096 cycles
   unsigned long long* clk;  // optional probe {shader clocks, 100 MHz ticks}: each workgroup's first wave adds its kernel residence (null = off)
   unsigned* oflow;  // device-visible word set to 1 when a result is not finite (an activation beyond f16's 65504, or fp32 overflow); may be null
   // LayerNorm epilogue (LNEP instantiation; N == 256 == the tile's width, so a workgroup owns whole rows): with x = the product + bias + R,

@@ -104,12 +104,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
   const int my_tiles = (chunk_len - bx + gx - 1) / gx;
   const int nk = p.K / (16 * KSUB);  // stages per tile
   const int total = my_tiles * nk;
-  // Optional start delay of the second workgroup of each CU (the dispatcher fills every CU of an XCD once before it doubles up), so
-  // that the two do not reach their epilogues at the same moment.  Worth -8...-18 % in round 2; with today's kernel the two drift apart
-  // on their own and the launcher passes 0 (see gemm_split_any).
-  if (p.skew > 0 && gridDim.x >= 512 && bx >= (gx >> 1)) {
-    for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(64);
-  }
+  // (Round 2 started every CU's second workgroup half a tile late so that the two would not reach their epilogues together, -8...-18 % then;
+  // with today's kernel they drift apart on their own and the delay only cost: +1.1 % at C = 512 without it,
+  // profiles/r04_j_gemm_start_skew_ab.txt.  Removed in round 5.)
 
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, 0xffffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, 0xffffffff, 0x00020000);
@@ -544,12 +541,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
 }
 
 // ---- launch ---------------------------------------------------------------------------------------------------------------
-static std::atomic<int> g_split_tile{pmce_env_int("PMCE_SPLIT_TILE", -1)};
-static std::atomic<int> g_split_skew{pmce_env_int("PMCE_SPLIT_SKEW", -1)};
-extern "C" int pmce_gemm_split_set_skew(int units) {
-  g_split_skew.store(units, std::memory_order_relaxed);
-  return PMCE_OK;
-}
+static std::atomic<int> g_split_tile{-1};  // pmce_gemm_split_set_tuning (tests sweep the tile shapes through it); -1 = automatic
 extern "C" int pmce_gemm_split_set_tuning(int tile) {
   g_split_tile.store(tile, std::memory_order_relaxed);
   return PMCE_OK;
@@ -587,7 +579,6 @@ static bool small_k32_form_exists(int act, bool apack, bool opack, bool res, boo
   if (apack) return act == 0;
   return act == 0 && !res;
 }
-static const int g_split_k32 = pmce_env_int("PMCE_SPLIT_K32", 1);  // A/B knob, read once at load
 template <int TM, int TN>
 static int launch_cfg(SplitParams& p, int act, bool apack, bool opack, hipStream_t stream) {
   using Cfg = SplitCfg<TM, TN>;
@@ -669,15 +660,8 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
   p.ln1_w = p.ln1_b = p.ln2_w = p.ln2_b = nullptr; p.ln1_eps = p.ln2_eps = 0.f; p.out1 = p.out2 = nullptr;
   p.oflow = pmce_overflow_sink();
   p.clk = pmce_clock_sink();  // (thread-local: set while an entry point of a model with a clock probe runs)
-  {  // Start delay of a CU's second workgroup, in 4096-cycle units.  Round 2 introduced half a tile of matrix time ((K / 16) * 12 * 32 /
-     // 4096 + 1) so that one workgroup's epilogue falls into the other's k-loop (-8...-18 % then); with today's kernel (blocked weights,
-     // pre-split operands, residual prefetch) the two drift apart on their own and the delay only costs: none measures +1.1 % at
-     // C = 512, +0.3 % at C = 256 (profiles/r04_j_gemm_start_skew_ab.txt).  PMCE_SPLIT_SKEW / pmce_gemm_split_set_skew still set one.
-    const int knob = g_split_skew.load(std::memory_order_relaxed);
-    p.skew = knob >= 0 ? knob : 0;
-  }
   const int tile = pick_split_tile(M, N);
-  if (tile == 2 && g_split_k32 && g_split_tile.load(std::memory_order_relaxed) < 0 && K % 32 == 0 && K >= 128 &&
+  if (tile == 2 && g_split_tile.load(std::memory_order_relaxed) < 0 && K % 32 == 0 && K >= 128 &&
       (long long)((M + 63) / 64) * ((N + 127) / 128) <= 512 &&
       small_k32_form_exists(act, a_packed != 0, c_packed != 0, R != nullptr, rscale != nullptr)) {
     PMCE_TRY(launch_small_k32<2>(p, act, a_packed != 0, c_packed != 0, stream));  // small grid: two k-tiles per trip
@@ -748,10 +732,6 @@ extern "C" int pmce_gemm_nt_split_f16_ln(const float* Ap, const float* Wp, int w
   p.c_div = 0; p.c_lo = 0; p.c_hi = 0;
   p.oflow = pmce_overflow_sink();
   p.clk = pmce_clock_sink();
-  {
-    const int knob = g_split_skew.load(std::memory_order_relaxed);
-    p.skew = knob >= 0 ? knob : 0;
-  }
   p.ln1_w = ln1_w; p.ln1_b = ln1_b; p.ln1_eps = ln1_eps; p.out1 = out1;
   p.ln2_w = ln2_w; p.ln2_b = ln2_b; p.ln2_eps = ln2_eps; p.out2 = out2;
   p.ntm = (M + 63) / 64;

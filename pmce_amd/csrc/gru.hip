@@ -41,14 +41,10 @@ __device__ __forceinline__ void gru_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned 
       : "memory");
 }
 
-// NQ = K-slices (wave groups) per workgroup: 2 -> 4 waves staging 32 k per stage, 4 -> 8 waves (two per SIMD: one wave's
-// LDS / DMA waits hide under the other's MFMAs) staging 16 k per stage.  Either way the rings fill 128 KB of LDS.
-// SPLIT: gh on the f16 matrix pipe in the three-product form of gemm_split_f16.hip (fp32 h split in registers, W_hh packed once
-// as [row][k/16][16 hi | 16 lo] f16 of W * 2^s - the bytes and the 64-byte rows of the fp32 form, so the staging is unchanged):
-// 9 instead of 24 matrix instructions per 16-wide stage at a sixth of the pipe time each.  NQ = 4 only (16 k per stage).
-template <int NQ, bool SPLIT = false>
-__global__ __launch_bounds__(128 * NQ) void gru_step_kernel(GruStepArgs a) {
-  static_assert(!SPLIT || NQ == 4, "the split form stages exactly one 16-wide k-tile");
+// fp32 pipe (the split mode's step is gru_step_v2_kernel below).  NQ = 4 K-slices per workgroup: 8 waves (two per SIMD: one wave's
+// LDS / DMA waits hide under the other's MFMAs) staging 16 k per stage; the rings fill 128 KB of LDS.
+__global__ __launch_bounds__(512) void gru_step_kernel(GruStepArgs a) {
+  constexpr int NQ = 4;
   constexpr int KS = 64 / NQ;              // k per stage
   constexpr int ROWB = KS * 4;             // bytes per staged row
   constexpr int LPR = KS / 4;              // lanes (16-byte chunks) per row
@@ -127,48 +123,23 @@ __global__ __launch_bounds__(128 * NQ) void gru_step_kernel(GruStepArgs a) {
       if (kt + 1 < nk) {
         dma_stage(kt + 1);
         // all but the NA+NW just issued: stage kt has landed
-        if (NQ == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       const float* As = my + (kt & 1) * (STAGE / 4) + n0 * KS;
       const float* Bs = my + (kt & 1) * (STAGE / 4) + 32 * KS + n0 * KS;
-      if constexpr (SPLIT) {
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(As + 4 * ((2 * hb) ^ swz));      // k = 8 hb + [0, 4)
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(As + 4 * ((2 * hb + 1) ^ swz));  // k = 8 hb + [4, 8)
-        const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-        gru_f16x8 ahi, alo;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ahi[e] = (_Float16)xv[e];
+      for (int g8 = 0; g8 < KS / 8; ++g8) {
+        const int co = 4 * ((2 * g8 + hb) ^ swz);
+        const f32x4 av = *reinterpret_cast<const f32x4*>(As + co);
+        f32x4 bv[3];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) alo[e] = (_Float16)((xv[e] - (float)ahi[e]) * 2048.0f);
-        gru_f16x8 whi[3], wlo[3], wh2[3];
+        for (int g = 0; g < 3; ++g) bv[g] = *reinterpret_cast<const f32x4*>(Bs + g * 32 * KS + co);
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          whi[g] = *reinterpret_cast<const gru_f16x8*>(Bs + g * 32 * KS + 4 * (hb ^ swz));        // hi plane, k = 8 hb + [0, 8)
-          wlo[g] = *reinterpret_cast<const gru_f16x8*>(Bs + g * 32 * KS + 4 * ((2 + hb) ^ swz));  // lo plane
-          wh2[g] = whi[g] * (_Float16)0.00048828125f;
-        }
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, whi[g], acc[g], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, wlo[g], acc[g], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, wh2[g], acc[g], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int g8 = 0; g8 < KS / 8; ++g8) {
-          const int co = 4 * ((2 * g8 + hb) ^ swz);
-          const f32x4 av = *reinterpret_cast<const f32x4*>(As + co);
-          f32x4 bv[3];
-#pragma unroll
-          for (int g = 0; g < 3; ++g) bv[g] = *reinterpret_cast<const f32x4*>(Bs + g * 32 * KS + co);
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[g][s], acc[g], 0, 0, 0);
-        }
+          for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[g][s], acc[g], 0, 0, 0);
       }
     }
     __syncthreads();  // every wave is done with its private ring: the reduction below reuses the memory
@@ -204,9 +175,6 @@ __global__ __launch_bounds__(128 * NQ) void gru_step_kernel(GruStepArgs a) {
   // gate update on the D layout: unit = u0 + (lane & 31), batch row = m0 + rb*32 + (r&3) + 8*(r>>2) + 4*hb
   const float* __restrict__ bh = a.bhh[d];
   const float bhr = bh[u], bhz = bh[H + u], bhn = bh[2 * H + u];
-  // the packed W_hh rows carry 2^s(row): rows u, H + u, 2 H + u of direction d
-  const float wd_r = SPLIT ? a.wscale[d * 3 * H + u] : 1.f, wd_z = SPLIT ? a.wscale[d * 3 * H + H + u] : 1.f,
-              wd_n = SPLIT ? a.wscale[d * 3 * H + 2 * H + u] : 1.f;
   float* __restrict__ ho = a.hout[d];
 #pragma unroll
   for (int q = 0; q < RW; ++q) {
@@ -217,11 +185,6 @@ __global__ __launch_bounds__(128 * NQ) void gru_step_kernel(GruStepArgs a) {
       ar = sel ? acc[0][r] : ar;
       az = sel ? acc[1][r] : az;
       an = sel ? acc[2][r] : an;
-    }
-    if (SPLIT) {
-      ar *= wd_r;
-      az *= wd_z;
-      an *= wd_n;
     }
     const int r = RW * kq + q;
     const int m = m0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
@@ -414,16 +377,10 @@ static int gru_step_any(const float* gi0, const float* gi1, const float* whh0, c
   a.hprev[0] = hp0; a.hprev[1] = hp1; a.hout[0] = ho0; a.hout[1] = ho1;
   a.gi_rs = gi_rs; a.h_rs = h_rs; a.B = B; a.H = H; a.wscale = wscale;
   PMCE_REQUIRE((long long)B * h_rs * 4 < (1ll << 32) && 3ll * H * H * 4 < (1ll << 32), "gru_step: h or W_hh spans 4 GiB or more");
-  static const int nq = pmce_env_int("PMCE_GRU_NQ", 4);  // tuning knob, read once
-  static const int v2 = pmce_env_int("PMCE_GRU_V2", 1);  // A/B knob, read once: 0 = the round-2 kernel with private rings
-  if (wscale && v2)
+  if (wscale)
     hipLaunchKernelGGL(gru_step_v2_kernel, dim3(H / 32, (B + 63) / 64, ndir), dim3(512), 0, stream, a);
-  else if (wscale)
-    hipLaunchKernelGGL((gru_step_kernel<4, true>), dim3(H / 32, (B + 63) / 64, ndir), dim3(512), 0, stream, a);
-  else if (nq == 2)
-    hipLaunchKernelGGL((gru_step_kernel<2>), dim3(H / 32, (B + 63) / 64, ndir), dim3(256), 0, stream, a);
   else
-    hipLaunchKernelGGL((gru_step_kernel<4>), dim3(H / 32, (B + 63) / 64, ndir), dim3(512), 0, stream, a);
+    hipLaunchKernelGGL(gru_step_kernel, dim3(H / 32, (B + 63) / 64, ndir), dim3(512), 0, stream, a);
   return pmce_check_launch("gru_step");
 }
 extern "C" int pmce_gru_step_f32(const float* gi0, const float* gi1, const float* whh0, const float* whh1, const float* bhh0,

@@ -545,8 +545,7 @@ extern "C" int pmce_seq_attention_ex_f32(const float* qkv, float* out, int nseq,
   PMCE_REQUIRE(C == 256 || C == 512, "seq_attention: C must be 256 or 512 (8 heads of 32/64)");
   PMCE_REQUIRE(N >= 1 && N <= 32 && nseq > 0, "seq_attention: N must be in 1..32 (got %d)", N);
   if (seq_div <= 0) seq_div = 0x7fffffff;
-  static const int force_v1 = pmce_env_int("PMCE_SEQ_ATTN_V1", 0);  // A/B knob, read once
-  if (!force_v1) {  // the sequence lengths of the path: 16 frames, 17 (H36M) or 19 (COCO + pelvis, neck) joints
+  {  // the sequence lengths of the path: 16 frames, 17 (H36M) or 19 (COCO + pelvis, neck) joints
     // C = 512 only: at C = 256 both kernels sit at the same ~4 TB/s (the first one already has 16 waves per CU there)
 #define PMCE_PAIR(HD_, N_) \
   if (C == 8 * HD_ && N == N_) return launch_seq_attention_pair<HD_, N_>(qkv, out, nseq, seq_div, seq_lo, seq_hi, tok_stride, out_split, stream)

@@ -94,7 +94,6 @@ struct pmce_model {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
   hipEvent_t ev_lifter = nullptr;  // recorded by pmce_forward when its pose lifter is enqueued (pmce_model_wait_lifter)
   bool concurrent = true;  // pmce_model_set_concurrency
-  bool fused_ca = true;    // CrossAttentionBlock of the vertex stream as one launch (PMCE_VERTEX_FUSED=0 at create: two)
   // the large products on the f16 matrix pipe (three-product split, fp32 accuracy) instead of the fp32 one
   bool split_gemm = true;  // pmce_model_set_gemm_mode / PMCE_SPLIT_F16=0 at create
   std::shared_ptr<float> split_arena;  // every packed weight + its per-row 2^-s; shared by handles cloned onto the same weights.
@@ -113,11 +112,8 @@ struct pmce_model {
   // 3.4); the library therefore contains no packed-fp32 instruction at all (build.py), which makes its kernels safe next to each
   // other.  PMCE_SPLIT_OVERLAP=0 at create restores the strictly serial schedule of the split mode (diagnostic).
   bool split_overlap = true;
-  bool ffn_f16 = true;
-  bool ln_fused = true;                // C = 256, split mode: LayerNorm in the epilogue of the N = 256 products (PMCE_LN_FUSED=0: launches of their own)
   const float* ffn_img[3][2] = {};     // per vertex block: the LDS images of the two FFNs' f16 form (vca, vsa), in the split arena
-  const float* qkv_img[3] = {};        // per vertex block: the self-attention qkv weight's f16 form (adaln_qkv)
-  bool attn_f16 = true;  // the lifter's attention on the f16 matrix pipe in split mode (PMCE_ATTN_F16=0: the vector-pipe kernel, an A/B knob)
+  const float* qkv_img[3] = {};        // per vertex block: the self-attention qkv weight's f16 form (vertex_sab)
   bool split_now = false;  // decision for the call in progress (set by check_ws, the first thing every entry point does)
   // Sticky "a product of this model produced a non-finite value" word: 4 bytes of pinned host memory the device can write
   // (hipHostMalloc, mapped), so that reading it costs no synchronisation.  Set by the split-f16 products' epilogues (an activation
@@ -125,7 +121,6 @@ struct pmce_model {
   std::shared_ptr<unsigned> oflow;  // shared by handles cloned onto the same weights (pipeline lanes): one model, one flag
   bool strict_overflow = false;     // pmce_model_set_overflow_policy: refuse further calls while the word is set
   unsigned long long* clk = nullptr;  // pmce_model_set_clock_probe: two device words (null = off)
-  bool wblk = true;                 // the products' packed weights in the blocked layout (PMCE_SPLIT_WBLK=0 at create: row-major, an A/B knob)
   // regressor (optional)
   const int* jr_indptr = nullptr;
   const int* jr_indices = nullptr;
@@ -362,16 +357,15 @@ int gemm(const float* A, const float* W, const float* bias, const float* R, floa
 int lgemm(const pmce_model* m, const float* A, const float* W, const SplitW& sw, const float* bias, const float* R, float* Cc,
           int M, int N, int K, long long lda, long long ldc, int act, hipStream_t s, int a_packed = 0, int c_packed = 0) {
   if (m->split_now && sw.wp)
-    return m->wblk ? pmce_gemm_nt_split_f16_blk(A, nullptr, sw.wp, sw.scale, bias, R, Cc, M, N, K, lda, ldc, act, a_packed, c_packed, 0, 0, 0, s)
-                   : pmce_gemm_nt_split_f16_ex(A, sw.wp, sw.scale, bias, R, Cc, M, N, K, lda, ldc, act, a_packed, c_packed, s);
+    return pmce_gemm_nt_split_f16_blk(A, nullptr, sw.wp, sw.scale, bias, R, Cc, M, N, K, lda, ldc, act, a_packed, c_packed, 0, 0, 0, s);
   PMCE_REQUIRE(!a_packed && !c_packed, "lgemm: pre-split operands need the split-f16 form");
   return gemm(A, W, bias, R, Cc, M, N, K, lda, ldc, act, s);
 }
 // In the split-f16 form the producers of the lifter blocks' GEMM operands (LayerNorm -> XN, attention -> AO, fc1 -> Hid) write
 // them pre-split (hi | lo*2^11 f16 planes in the bytes of the fp32 row): the products then spend no vector work on splitting.
 inline int pk(const pmce_model* m) { return m->split_now ? 1 : 0; }
-// the decoder's FFNs in the same form (PMCE_FFN_F16=0 at create keeps them on the fp32 pipe: an A/B knob)
-inline int pkf(const pmce_model* m) { return m->split_now && m->ffn_f16 ? 1 : 0; }
+// the decoder's token-local kernels in the same form
+inline int pkf(const pmce_model* m) { return m->split_now ? 1 : 0; }
 
 // ---- GraphormerNet.forward --------------------------------------------------------------------------------
 // Everything up to and including SpatialBlocks[0] is PER FRAME (its attention runs over the J joints of one frame,
@@ -395,7 +389,7 @@ PostNorm post_norm_of(const pmce_model* m, int kind, int i) {
 }
 // C = 256 in split mode: the N = 256 products own whole rows (64 x 256 tiles), so the LayerNorm that follows them runs in their epilogue
 // (pmce_gemm_nt_split_f16_ln) instead of a launch of its own that re-reads the row.  (C = 512: a 512-wide tile does not fit)
-inline bool ln_in_product(const pmce_model* m) { return m->split_now && m->ln_fused && m->C == 256; }
+inline bool ln_in_product(const pmce_model* m) { return m->split_now && m->C == 256; }
 
 // attention + MLP of one block (pre-norm input in w.XN, residual stream in w.X); kind 0 spatial, 1 temporal.  post != nullptr: the
 // block's post-norm chain (without a position embedding) is part of this call - fused into fc2 where ln_in_product, a launch otherwise.
@@ -406,7 +400,7 @@ int lifter_block_body(pmce_model* m, int kind, int i, long long M, int nframes, 
   const LifterBlockSplit& sw = m->sblk[kind][i];
   // split mode: the attention runs on the f16 matrix pipe too (seq_attention_mfma.hip; reads the fp32 q, k, v, writes AO pre-split)
   const int N_seq = kind == 0 ? J : T;
-  const bool mfma_attn = m->split_now && m->attn_f16 && pmce_seq_attention_split_supported(N_seq, C);
+  const bool mfma_attn = m->split_now && pmce_seq_attention_split_supported(N_seq, C);
   RUN(P_GEMM_LIFTER, lgemm(m, w.XN, bw.qkv_w, sw.qkv, bw.qkv_b, nullptr, w.QKV,
                           (int)M, 3 * C, C, C, 3 * C, 0, stream, pk(m)));
   if (kind == 0) {  // sequences = frames, tokens j contiguous                      (PoseEstimation.py:78,101)
@@ -418,7 +412,7 @@ int lifter_block_body(pmce_model* m, int kind, int i, long long M, int nframes, 
   }
   const bool fuse = ln_in_product(m) && sw.proj.wp && sw.fc2.wp;
   if (fuse) {  // x += proj(attn); XN = norm2(x)
-    RUN(P_GEMM_LIFTER, pmce_gemm_nt_split_f16_ln(w.AO, sw.proj.wp, m->wblk, sw.proj.scale, bw.proj_b, w.X, (int)M, C, nullptr, nullptr, 0.f,
+    RUN(P_GEMM_LIFTER, pmce_gemm_nt_split_f16_ln(w.AO, sw.proj.wp, 1, sw.proj.scale, bw.proj_b, w.X, (int)M, C, nullptr, nullptr, 0.f,
                                                  w.X, bw.norm2_w, bw.norm2_b, 1e-6f, w.XN, stream));
   } else {
     RUN(P_GEMM_LIFTER, lgemm(m, w.AO, bw.proj_w, sw.proj, bw.proj_b, w.X, w.X, (int)M, C,
@@ -430,7 +424,7 @@ int lifter_block_body(pmce_model* m, int kind, int i, long long M, int nframes, 
   RUN(P_GEMM_LIFTER, lgemm(m, w.XN, bw.fc1_w, sw.fc1, bw.fc1_b, nullptr, Hid, (int)M,
                           2 * C, C, C, 2 * C, 1, stream, pk(m), pk(m)));
   if (fuse && post) {  // x = norm_s/t(x + fc2(h)); XN = next norm1(x)
-    RUN(P_GEMM_LIFTER, pmce_gemm_nt_split_f16_ln(Hid, sw.fc2.wp, m->wblk, sw.fc2.scale, bw.fc2_b, w.X, (int)M, 2 * C, post->w1, post->b1, 1e-6f,
+    RUN(P_GEMM_LIFTER, pmce_gemm_nt_split_f16_ln(Hid, sw.fc2.wp, 1, sw.fc2.scale, bw.fc2_b, w.X, (int)M, 2 * C, post->w1, post->b1, 1e-6f,
                                                  w.X, post->w2, post->b2, 1e-6f, post->w2 ? w.XN : nullptr, stream));
     return PMCE_OK;
   }
@@ -456,8 +450,7 @@ int prep_features(pmce_model* m, const float* img_feat, int nframes, LifterWs& w
 // a product on the row-scaled feature planes (optionally with mapped output rows)
 int rs_gemm(const pmce_model* m, const float* FS, const float* FR, const SplitW& sw, const float* bias, float* Cc, int M, int N,
             long long ldc, int c_div, long long c_lo, long long c_hi, hipStream_t s) {
-  return m->wblk ? pmce_gemm_nt_split_f16_blk(FS, FR, sw.wp, sw.scale, bias, nullptr, Cc, M, N, F, F, ldc, 0, 1, 0, c_div, c_lo, c_hi, s)
-                 : pmce_gemm_nt_split_f16_rs(FS, FR, sw.wp, sw.scale, bias, Cc, M, N, F, ldc, c_div, c_lo, c_hi, s);
+  return pmce_gemm_nt_split_f16_blk(FS, FR, sw.wp, sw.scale, bias, nullptr, Cc, M, N, F, F, ldc, 0, 1, 0, c_div, c_lo, c_hi, s);
 }
 
 // embedding + SpatialBlocks[0] over `nframes` frames; leaves the block output (before norm_s) in w.X
@@ -609,7 +602,7 @@ int joint_prep(pmce_model* m, int k, const float* joints, int B, DecoderWs& w, h
   const int ib = (k - 1) * 6, gbs = N_ADA * 128;
   // one launch: joint embedding + fold.  The f16 form of the fused vertex kernel reads the operands' image only (J <= 23); the fp32
   // form (and the two-launch fallback beyond J = 23) the fp32 operands.  jf is read by the joint stream of block 3 only.
-  const bool image = pkf(m) && m->fused_ca && J <= 23;
+  const bool image = pkf(m) && J <= 23;
   RUN(P_CA_FOLD, pmce_joint_prep_f32(joints, v.joint_proj_w, v.joint_proj_b, v.joint_pos, v.j2v_w, v.j2v_b, v.j2v_K,
                                      k == 3 ? w.JF[k - 1] : nullptr, w.GB, gbs, ib + 0, ib + 1, ib + 2, v.vca_wq_w, v.vca_wq_b, v.vca_wk_w,
                                      v.vca_wk_b, v.vca_wv_w, v.vca_wv_b, v.vca_proj_w, image ? nullptr : w.KF[k - 1],
@@ -639,28 +632,16 @@ int vertex_block(pmce_model* m, int k, const float* vt_cur, float* vt_next, int 
   const int J = m->J, gbs = N_ADA * 128;
   const VertexBlockW& v = m->w.vb[k - 1];
   const int ib = (k - 1) * 6;  // AdaLN instances: vca.normq,normk,normv,norm2, vsa.norm1,norm2
-  if (m->fused_ca) {  // CrossAttentionBlock (CoevoDecoder.py:82-87) in one launch, bit-identical to the two below
-    RUN(P_VERTEX_CA_MLP, pmce_vertex_ca_mlp_pk_f32(nullptr, vt_cur, v.vertx_proj_w, v.Eq, w.KF[k - 1], w.S0[k - 1], w.VF[k - 1],
-                                                   v.vca_proj_b, w.GB, gbs, ib + 3, v.vca_fc1_w, v.vca_fc1_b, v.vca_fc2_w,
-                                                   v.vca_fc2_b, w.F2, w.F1, B, J, pkf(m), m->ffn_img[k - 1][0], w.CAI[k - 1], stream));
-  } else {
-    RUN(P_VERTEX_CA, pmce_vertex_ca_f32(nullptr, vt_cur, v.vertx_proj_w, v.Eq, w.KF[k - 1], w.S0[k - 1], w.VF[k - 1],
-                                        v.vca_proj_b, w.F1, B, J, stream));
-    RUN(P_ADALN_MLP, pmce_adaln_mlp_pk_f32(w.F1, w.GB, gbs, ib + 3, v.vca_fc1_w, v.vca_fc1_b, v.vca_fc2_w, v.vca_fc2_b, w.F2, nullptr,
-                                           nullptr, nullptr, nullptr, B, pkf(m), m->ffn_img[k - 1][0], stream));
-  }
-#ifdef PMCE_AB_NO_SAB  // A/B builds only: the two-launch form
-  if (pkf(m) && m->qkv_img[k - 1]) {
-    RUN(P_ADALN_QKV, pmce_adaln_qkv_split_f32(w.F2, w.GB, gbs, ib + 4, m->qkv_img[k - 1], v.vsa_qkv_b, w.QKV, B, stream));
-    RUN(P_VERTEX_SA, pmce_vertex_sa_ex_f32(w.F2, w.QKV, v.vsa_proj_w, v.vsa_proj_b, w.F1, B, pkf(m), stream));
-  } else
-#endif
-  if (pkf(m) && m->qkv_img[k - 1]) {  // AdaLN + qkv + attention + proj + residual in one launch (coevo.hip vertex_sab)
+  // CrossAttentionBlock (CoevoDecoder.py:82-87) in one launch (J > 23: the launcher's two-launch form through F1)
+  RUN(P_VERTEX_CA_MLP, pmce_vertex_ca_mlp_pk_f32(nullptr, vt_cur, v.vertx_proj_w, v.Eq, w.KF[k - 1], w.S0[k - 1], w.VF[k - 1],
+                                                 v.vca_proj_b, w.GB, gbs, ib + 3, v.vca_fc1_w, v.vca_fc1_b, v.vca_fc2_w,
+                                                 v.vca_fc2_b, w.F2, w.F1, B, J, pkf(m), m->ffn_img[k - 1][0], w.CAI[k - 1], stream));
+  if (pkf(m)) {  // AdaLN + qkv + attention + proj + residual in one launch (coevo.hip vertex_sab)
     RUN(P_VERTEX_SA, pmce_vertex_sab_split_f32(w.F2, w.GB, gbs, ib + 4, m->qkv_img[k - 1], v.vsa_qkv_b, v.vsa_proj_w, v.vsa_proj_b, w.QKV,
                                                w.F1, B, stream));
   } else {
     RUN(P_ADALN_QKV, pmce_adaln_qkv_f32(w.F2, w.GB, gbs, ib + 4, v.vsa_qkv_w, v.vsa_qkv_b, w.QKV, B, stream));
-    RUN(P_VERTEX_SA, pmce_vertex_sa_ex_f32(w.F2, w.QKV, v.vsa_proj_w, v.vsa_proj_b, w.F1, B, pkf(m), stream));
+    RUN(P_VERTEX_SA, pmce_vertex_sa_f32(w.F2, w.QKV, v.vsa_proj_w, v.vsa_proj_b, w.F1, B, stream));
   }
   RUN(P_ADALN_MLP, pmce_adaln_mlp_pk_f32(w.F1, w.GB, gbs, ib + 5, v.vsa_fc1_w, v.vsa_fc1_b,
                                          v.vsa_fc2_w, v.vsa_fc2_b, nullptr,
@@ -815,8 +796,7 @@ int build_split_weights(pmce_model* m, hipStream_t stream) {
   if (items.empty()) return PMCE_OK;
   size_t floats = 0;
   for (auto& it : items) floats += split_item_floats(it.n, it.k);
-  const bool ffn_images = m->has_decoder && m->ffn_f16 && pmce_env_int("PMCE_FFN_IMAGE", 1) != 0;
-  if (m->has_decoder) floats += 6 * ffn_img_floats() + 3 * qkv_img_floats();  // (reserved whether or not they are made: pmce_model_split_bytes does not depend on env knobs)
+  if (m->has_decoder) floats += 6 * ffn_img_floats() + 3 * qkv_img_floats();
   if (m->caller_arena) {  // the caller's memory (its allocator, its lifetime): pmce_model_set_split_arena
     if (m->caller_arena_bytes < floats * sizeof(float)) {
       pmce_set_error("model_finalize: the split arena holds %zu bytes, the planes need %zu (pmce_model_split_bytes)", m->caller_arena_bytes,
@@ -842,12 +822,12 @@ int build_split_weights(pmce_model* m, hipStream_t stream) {
     p = wp + split_item_floats(it.n, it.k);
     // the products' weights in the blocked layout (a tile's k-slice contiguous); the recurrent weights row-major (gru_step's addressing)
     const bool recurrent = it.dst == &m->s_whh0 || it.dst == &m->s_whh1;
-    if (m->wblk && !recurrent) PMCE_TRY(pmce_gemm_pack_split_f16_blk(it.w, it.n, it.k, it.k, wp, sc, stream));
+    if (!recurrent) PMCE_TRY(pmce_gemm_pack_split_f16_blk(it.w, it.n, it.k, it.k, wp, sc, stream));
     else PMCE_TRY(pmce_gemm_pack_split_f16(it.w, it.n, it.k, it.k, wp, sc, stream));
     it.dst->wp = wp;
     it.dst->scale = sc;
   }
-  if (ffn_images)  // the decoder FFNs' LDS images (coevo.hip stage_ffn_any): every workgroup of the six launches copies one instead of converting
+  if (m->has_decoder)  // the decoder FFNs' and qkv weights' LDS images (coevo.hip): every workgroup of their launches copies one (LDS-DMA) instead of converting
     for (int k = 0; k < 3; ++k) {
       const VertexBlockW& v = m->w.vb[k];
       PMCE_TRY(pmce_ffn_pack_f16(v.vca_fc1_w, v.vca_fc2_w, p, stream));
@@ -856,10 +836,8 @@ int build_split_weights(pmce_model* m, hipStream_t stream) {
       PMCE_TRY(pmce_ffn_pack_f16(v.vsa_fc1_w, v.vsa_fc2_w, p, stream));
       m->ffn_img[k][1] = p;
       p += ffn_img_floats();
-      if (pmce_env_int("PMCE_QKV_F16", 1) != 0) {
-        PMCE_TRY(pmce_qkv_pack_f16(v.vsa_qkv_w, p, stream));
-        m->qkv_img[k] = p;
-      }
+      PMCE_TRY(pmce_qkv_pack_f16(v.vsa_qkv_w, p, stream));
+      m->qkv_img[k] = p;
       p += qkv_img_floats();
     }
   if (hipStreamSynchronize(stream) != hipSuccess) {
@@ -898,15 +876,10 @@ int pmce_model_create(int num_joint, int embed_dim, int depth, pmce_model** out)
   m->C = embed_dim;
   m->depth = depth;
   m->concurrent = getenv("PMCE_SINGLE_STREAM") == nullptr;
-  m->fused_ca = pmce_env_int("PMCE_VERTEX_FUSED", 1) != 0;
   m->split_gemm = pmce_env_int("PMCE_SPLIT_F16", 1) != 0;
   m->split_min_batch = pmce_env_int("PMCE_SPLIT_MIN_BATCH", 1);
-  m->ffn_f16 = pmce_env_int("PMCE_FFN_F16", 1) != 0;
-  m->ln_fused = pmce_env_int("PMCE_LN_FUSED", 1) != 0;
-  m->attn_f16 = pmce_env_int("PMCE_ATTN_F16", 1) != 0;
   m->split_overlap = pmce_env_int("PMCE_SPLIT_OVERLAP", 1) != 0;
   m->strict_overflow = pmce_env_int("PMCE_STRICT_OVERFLOW", 0) != 0;
-  m->wblk = pmce_env_int("PMCE_SPLIT_WBLK", 1) != 0;
   build_names(m);
   *out = m;
   return PMCE_OK;
@@ -1062,6 +1035,8 @@ int pmce_model_set_split_min_batch(pmce_model* m, int clips) {
 }
 // the values in force (their defaults come from the environment at create time: a caller that changes one temporarily restores THIS)
 int pmce_model_get_split_min_batch(const pmce_model* m) { return m ? m->split_min_batch : -1; }
+int pmce_model_get_concurrency(const pmce_model* m) { return m ? (m->concurrent ? 1 : 0) : -1; }
+int pmce_model_get_split_overlap(const pmce_model* m) { return m ? (m->split_overlap ? 1 : 0) : -1; }
 int pmce_model_get_overflow_policy(const pmce_model* m) { return m ? (m->strict_overflow ? 1 : 0) : -1; }
 
 size_t pmce_model_workspace_bytes(const pmce_model* m, int batch) {

@@ -274,42 +274,28 @@ def adaln_mlp(x, g, sd, p_norm, p_mlp, coor=None, vt_in=None, want_features=True
 
 def vertex_self_attn(x, g, sd, p, split_f16=False):
     """x + SA(AdaLN(x)) on [B,431,64], 2 heads (first line of Block.forward, CoevoDecoder.py:103); p = '...vertx_SA_FFN'.
-    split_f16: the attention's two contractions as three f16 matrix products each."""
+    fp32 pipe: two launches (adaln_qkv, vertex_sa), returns (y, qkv).  split_f16: ONE launch (pmce_vertex_sab_split_f32: AdaLN + qkv
+    product + attention + proj + residual, every contraction but the projection as three f16 matrix products; what a model in split_f16
+    mode runs), returns (y, None) - no fp32 qkv exists."""
     lib = _lib.load()
     x = _c(x)
     B = x.shape[0]
     GB = adaln_params(g, sd, [p + ".norm1"])
-    qkv = torch.empty(B, 431, 192, device=x.device)
     Wqkv = _c(sd[p + ".attn.qkv.weight"])
-    if split_f16:   # as a model in split_f16 mode: the qkv product in the three-product f16 form too, from the weight's pre-made image
+    y = torch.empty_like(x)
+    if split_f16:
         img = torch.empty(lib.pmce_qkv_image_floats(), device=x.device)
         _lib.check(lib.pmce_qkv_pack_f16(P(Wqkv), P(img), _st()), "qkv_pack_f16")
-        _lib.check(lib.pmce_adaln_qkv_split_f32(P(x), P(GB), GB.shape[1], 0, P(img), P(_c(sd[p + ".attn.qkv.bias"])), P(qkv), B, _st()),
-                   "adaln_qkv_split")
-    else:
-        _lib.check(lib.pmce_adaln_qkv_f32(P(x), P(GB), GB.shape[1], 0, P(Wqkv),
-                                          P(_c(sd[p + ".attn.qkv.bias"])), P(qkv), B, _st()), "adaln_qkv")
-    y = torch.empty_like(x)
-    _lib.check(lib.pmce_vertex_sa_ex_f32(P(x), P(qkv), P(_c(sd[p + ".attn.proj.weight"])), P(_c(sd[p + ".attn.proj.bias"])),
-                                         P(y), B, int(split_f16), _st()), "vertex_sa")
+        scratch = torch.empty(lib.pmce_vertex_sab_scratch_floats(B), device=x.device)
+        _lib.check(lib.pmce_vertex_sab_split_f32(P(x), P(GB), GB.shape[1], 0, P(img), P(_c(sd[p + ".attn.qkv.bias"])),
+                                                 P(_c(sd[p + ".attn.proj.weight"])), P(_c(sd[p + ".attn.proj.bias"])), P(scratch), P(y), B,
+                                                 _st()), "vertex_sab")
+        return y, None
+    qkv = torch.empty(B, 431, 192, device=x.device)
+    _lib.check(lib.pmce_adaln_qkv_f32(P(x), P(GB), GB.shape[1], 0, P(Wqkv), P(_c(sd[p + ".attn.qkv.bias"])), P(qkv), B, _st()), "adaln_qkv")
+    _lib.check(lib.pmce_vertex_sa_f32(P(x), P(qkv), P(_c(sd[p + ".attn.proj.weight"])), P(_c(sd[p + ".attn.proj.bias"])), P(y), B, _st()),
+               "vertex_sa")
     return y, qkv
-
-
-def vertex_self_attn_fused(x, g, sd, p):
-    """The same (split_f16 form) in ONE launch - AdaLN + qkv product + attention + proj + residual (pmce_vertex_sab_split_f32, what a
-    model in split_f16 mode runs); bit-identical to vertex_self_attn(..., split_f16=True)."""
-    lib = _lib.load()
-    x = _c(x)
-    B = x.shape[0]
-    GB = adaln_params(g, sd, [p + ".norm1"])
-    img = torch.empty(lib.pmce_qkv_image_floats(), device=x.device)
-    _lib.check(lib.pmce_qkv_pack_f16(P(_c(sd[p + ".attn.qkv.weight"])), P(img), _st()), "qkv_pack_f16")
-    scratch = torch.empty(lib.pmce_vertex_sab_scratch_floats(B), device=x.device)
-    y = torch.empty_like(x)
-    _lib.check(lib.pmce_vertex_sab_split_f32(P(x), P(GB), GB.shape[1], 0, P(img), P(_c(sd[p + ".attn.qkv.bias"])),
-                                             P(_c(sd[p + ".attn.proj.weight"])), P(_c(sd[p + ".attn.proj.bias"])), P(scratch), P(y), B,
-                                             _st()), "vertex_sab")
-    return y
 
 
 def joint_stream(xq, xk, xv, g, sd, blk, stage, jt=None):

@@ -91,6 +91,48 @@ def test_argument_validation_without_gpu(lib):
     lib.pmce_model_destroy(h)
 
 
+def test_the_five_environment_knobs(lib, monkeypatch):
+    """the library reads exactly five environment variables, all in pmce_model_create, each the initial value of a
+    setting with an API setter and getter (include/pmce_hip.h at pmce_model_create).  Every one is flipped here (creating a handle needs
+    no GPU), and no other PMCE_* name is read anywhere in the library's sources."""
+    import ctypes as C
+
+    def create():
+        h = C.c_void_p()
+        assert lib.pmce_model_create(17, 256, 3, C.byref(h)) == 0
+        st = dict(split=lib.pmce_model_gemm_mode(h), min_batch=lib.pmce_model_get_split_min_batch(h), strict=lib.pmce_model_get_overflow_policy(h),
+                  two_streams=lib.pmce_model_get_concurrency(h), overlap=lib.pmce_model_get_split_overlap(h))
+        lib.pmce_model_destroy(h)
+        return st
+
+    for k in ("PMCE_SPLIT_F16", "PMCE_SPLIT_MIN_BATCH", "PMCE_STRICT_OVERFLOW", "PMCE_SINGLE_STREAM", "PMCE_SPLIT_OVERLAP"):
+        monkeypatch.delenv(k, raising=False)
+    base = create()
+    assert base == dict(split=1, min_batch=1, strict=0, two_streams=1, overlap=1)
+    for var, val, key, want in (("PMCE_SPLIT_F16", "0", "split", 0), ("PMCE_SPLIT_MIN_BATCH", "48", "min_batch", 48),
+                                ("PMCE_STRICT_OVERFLOW", "1", "strict", 1), ("PMCE_SINGLE_STREAM", "1", "two_streams", 0),
+                                ("PMCE_SPLIT_OVERLAP", "0", "overlap", 0)):
+        monkeypatch.setenv(var, val)
+        st = create()
+        assert st[key] == want and all(st[k] == base[k] for k in st if k != key), (var, st)
+        monkeypatch.delenv(var)
+    # the API equivalents
+    h = C.c_void_p()
+    assert lib.pmce_model_create(17, 256, 3, C.byref(h)) == 0
+    assert lib.pmce_model_set_split_min_batch(h, 7) == 0 and lib.pmce_model_get_split_min_batch(h) == 7
+    assert lib.pmce_model_set_overflow_policy(h, 1) == 0 and lib.pmce_model_get_overflow_policy(h) == 1
+    assert lib.pmce_model_set_concurrency(h, 0) == 0 and lib.pmce_model_get_concurrency(h) == 0
+    lib.pmce_model_destroy(h)
+    # nothing else is read: every getenv / pmce_env_int in the sources names one of the five
+    from pmce_amd import build as B
+    names = set()
+    for f in os.listdir(B.CSRC):
+        if f.endswith((".hip", ".cpp", ".hpp")):
+            src = open(osp.join(B.CSRC, f)).read()
+            names |= set(re.findall(r'(?:getenv|pmce_env_int)\(\s*"([A-Z0-9_]+)"', src))
+    assert names == {"PMCE_SPLIT_F16", "PMCE_SPLIT_MIN_BATCH", "PMCE_STRICT_OVERFLOW", "PMCE_SINGLE_STREAM", "PMCE_SPLIT_OVERLAP"}, names
+
+
 def test_facade_keeps_reference_checkpoint_layout():
     from pmce_amd import _lib, models, synth
     spec = synth.pmce_spec(19, 256, 3)
