@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""Clip-sharded evaluation harness (BASELINE configs[3]/[4] with synthetic stand-ins: no datasets are available offline).
+"""Clip-sharded evaluation harness (BASELINE configs[3]/[4]).  Default: synthetic stand-ins (no datasets are available offline);
+with --data-dir the reference's own 3DPW files (data/PW3D/dataset.py:90-128: annotation, ViTPose detections, image features, joint
+files), read by pmce_amd/datasets.py into per-frame tables that are uploaded ONCE and windowed on the device.
 
-    python scripts/eval_sharded.py --clips 4096 --joints 19                    # 1 GPU
+    python scripts/eval_sharded.py --clips 4096 --joints 19                    # 1 GPU, synthetic
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 scripts/eval_sharded.py --clips 35515
+    python scripts/eval_sharded.py --data-dir /data/PW3D/pw3d_data [--checkpoint mesh_3dpw.pth.tar]   # real files
 
 Every rank owns a contiguous block of the clip range (weights replicated), runs the HIP forward in batches, computes the
 per-sample metrics on the device (pmce_amd.eval) against a synthetic ground truth, and the ranks meet in ONE reduction
@@ -38,21 +41,45 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--joints", type=int, default=19)          # 3DPW uses COCO input: J = 19 (PW3D/dataset.py:42,54-55)
     ap.add_argument("--seq-len", type=int, default=500, help="clips per synthetic sequence (for the acceleration error)")
+    ap.add_argument("--data-dir", default=None, help="directory holding the reference's 3DPW files (3DPW_latest_<split>.json, ...): "
+                                                     "evaluate the real stride-1 window list instead of the synthetic stand-in")
+    ap.add_argument("--split", default="test")
+    ap.add_argument("--checkpoint", default=None, help="a reference mesh_*.pth.tar (default: deterministic synthetic weights)")
     args = ap.parse_args()
     from pmce_amd import models, sharding, synth
     from pmce_amd.eval import Evaluator
+    table = win = None
+    if args.data_dir:
+        from pmce_amd import datasets
+        table = datasets.load_pw3d(args.data_dir, args.split)          # every rank parses the (host-side) files; the GPU work is sharded
+        win = table.windows(16, 1)
+        args.clips, args.joints = len(win), 19
     rank, local, world = sharding.init_from_env()
     if os.environ.get("PMCE_BENCH_SHARE_GPU"):      # plumbing runs of the N > 1 path on a box with fewer GPUs (ranks share devices)
         local = local % max(torch.cuda.device_count(), 1)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     J = args.joints
-    model = models.PMCE.get_model(J, 256, 3)
-    model.load_state_dict(synth.make_state_dict(synth.pmce_spec(J, 256, 3), seed=123))
+    if args.checkpoint:
+        from pmce_amd import checkpoint
+        sd, kind, Jc, Cc, depth = checkpoint.load_reference_checkpoint(args.checkpoint)
+        assert kind == "pmce" and Jc == J, f"{args.checkpoint}: a {kind} checkpoint with J = {Jc}; this run needs the full model with J = {J}"
+        model = models.PMCE.get_model(J, Cc, depth)
+        model.load_state_dict(sd)
+    else:
+        model = models.PMCE.get_model(J, 256, 3)
+        model.load_state_dict(synth.make_state_dict(synth.pmce_spec(J, 256, 3), seed=123))
     model = model.to(dev)
     ev = Evaluator(dev)
     lo, hi = sharding.shard_range(args.clips, rank, world)
     seq_ids = np.arange(args.clips) // args.seq_len
+    if table is not None:
+        from pmce_amd import datasets
+        mid = win[:, 0] + 8                                             # the window's middle frame carries the targets (dataset.py:245-251)
+        seq_ids = table.sequence_ids()[mid]
+        pose_fr, feat_fr = table.pose2d(dev), table.features_on(dev)    # per-frame tables, uploaded once (8 KB per frame, not 16 x per window)
+        gt_joints = torch.from_numpy(table.gt_joints_root_relative()[mid]).to(dev)
+        gt_mesh = None if table.gt_mesh_cam is None else table.gt_mesh_cam
     # synthetic inputs for this shard: one pool of `batch` clips, re-indexed (keeps host memory small)
     p_np, f_np = synth.make_inputs(args.batch, J, seed=7)
     p_pool, f_pool = torch.from_numpy(p_np).to(dev), torch.from_numpy(f_np).to(dev)
@@ -66,11 +93,21 @@ def main():
     def consume(item):
         ticket, b0 = item
         mesh = ticket.result()[0]
-        run.add(mesh, synthetic_gt(mesh, b0, pool))                                 # per-sample errors + 14x3 joints; the mesh is dropped
+        if table is None:
+            run.add(mesh, synthetic_gt(mesh, b0, pool))                             # per-sample errors + 14x3 joints; the mesh is dropped
+        else:   # annotated joints (mm, root-relative); the mesh target only if the caller supplied SMPL meshes (else MPVPE is void)
+            n = mesh.shape[0]
+            gm = mesh if gt_mesh is None else torch.from_numpy(np.ascontiguousarray(gt_mesh[mid[b0:b0 + n]])).to(dev) / 1000.0
+            run.add(mesh, gm, gt_joints[b0:b0 + n])
+
+    def inputs_of(b0, n):
+        if table is None:
+            return clip_inputs(p_pool, f_pool, b0, n)
+        return datasets.window_batch(pose_fr, feat_fr, win[b0:b0 + n])
 
     for b0 in range(lo, hi, args.batch):
         n = min(args.batch, hi - b0)
-        ticket = pipe.submit(*clip_inputs(p_pool, f_pool, b0, n), want_joints=False)   # two batches in flight
+        ticket = pipe.submit(*inputs_of(b0, n), want_joints=False)                  # two batches in flight
         if pending is not None:
             consume(pending)
         pending = (ticket, b0)
@@ -88,7 +125,7 @@ def main():
         nb = min(args.batch, args.clips)
         model.profile(True)
         for _ in range(3):
-            model(*clip_inputs(p_pool, f_pool, 0, nb))
+            model(*inputs_of(0, nb))
         torch.cuda.synchronize()
         prof = model.profile_read()
         model.profile(False)
@@ -99,7 +136,11 @@ def main():
                     "metric_reduction": {"collective": "all_reduce(SUM) of 4 fp64 partials + all_gather of 28x3 joints per clip",
                                          "backend": (torch.distributed.get_backend() if world > 1 else None)},
                     "roofline": bench.dominant_kernel_roofline(kernel_ms, launches, nb, J, 256, model.gemm_mode()),
-                    "data": "synthetic stand-in (no 3DPW/H36M files offline)"})
+                    "data": ("synthetic stand-in (no 3DPW/H36M files offline)" if table is None else
+                             f"{table.name}: {len(table)} frames, {len(win)} stride-1 windows from {args.data_dir}; targets = annotated h36m joints"
+                             + ("" if gt_mesh is not None else "; no ground-truth meshes supplied: MPVPE is void"))})
+        if table is not None and gt_mesh is None:
+            res["MPVPE"] = None
         print(json.dumps(res))
     if world > 1:
         sharding.barrier()
