@@ -107,18 +107,20 @@ def bind_rank_to_cpus(local: int, nlocal: int):
         return None
 
 
-def shared_state_dict(J, C, local, barrier):
+def shared_state_dict(J, C, local, barrier, nonce=""):
     """The synthetic weights (412 MB at C = 256, 6-7 s of host time to generate) made ONCE per node: local rank 0 writes them to
     /dev/shm, the other ranks map the file (torch.load(mmap=True)) instead of regenerating them 8 times.  `barrier` is a callable all
     ranks of the node call; the file is removed by its writer after the second barrier."""
     import torch
     from pmce_amd import synth
     tag = os.environ.get("MASTER_PORT", "0")
-    path = f"/dev/shm/pmce_bench_weights_J{J}_C{C}_{os.getuid()}_{tag}.pt"
-    sd = None
+    path = f"/dev/shm/pmce_bench_weights_J{J}_C{C}_{os.getuid()}_{tag}_{nonce}.pt"     # nonce: per run (rank 0's, broadcast): a file a crashed
+    sd = None                                                                             # earlier run left behind is never picked up
     if local == 0:
         sd = synth.make_state_dict(synth.pmce_spec(J, C, 3), seed=123)
         try:
+            if os.path.exists(path):
+                os.unlink(path)
             torch.save(sd, path + ".tmp")
             os.replace(path + ".tmp", path)
         except OSError:
@@ -156,14 +158,14 @@ def kernel_of(cls, gemm_mode):
     return cls
 
 
-def gemm_class_bytes(name, B, J, C, depth=3, T=16, F=2048, streaming=False):
+def gemm_class_bytes(name, B, J, C, depth=3, T=16, F=2048, streaming=False, gemm_mode="split_f16"):
     """ALGORITHMIC HBM bytes of a GEMM class: every operand and result once (fp32: A, W, C, + residual where there is one)."""
     GH = 1024
     M = B * T * J
     if name == "gemm_lifter":
         per_block = (M * C + 3 * M * C + 3 * C * C) + (M * C + 2 * M * C + C * C) + (M * C + 2 * M * C + 2 * C * C) + (2 * M * C + 2 * M * C + 2 * C * C)
-        if C == 256:   # proj and fc2 also write their consumer's pre-split LayerNorm output (pmce_gemm_nt_split_f16_ln: the ln_chain launches' result)
-            per_block += 2 * M * C
+        if C == 256 and gemm_mode == "split_f16":   # proj and fc2 also write their consumer's pre-split LayerNorm output
+            per_block += 2 * M * C                  # (pmce_gemm_nt_split_f16_ln: the ln_chain launches' result; the fp32 mode keeps those launches)
         if streaming:
             return 4.0 * (2 * depth - 1) * per_block
         return 4.0 * (B * T * F + B * T * C + F * C + 2 * depth * per_block)
@@ -258,10 +260,13 @@ def north_star_record(kernel_ms, launches, B, J, f16_ffn=False, C=512):
     ms = kernel_ms[name] / n
     byt = 229376.0 * B
     tiles = B * 14
-    # matrix-pipe cycles per 32-vertex wave tile: scores + output on the fp32 pipe (64 cycles per instruction), the FFN either
-    # 512 fp32 instructions or - in the split-f16 mode - 192 f16 ones of 32 cycles
-    ffn_cycles = 0 if name != "vertex_ca_mlp" else (192 * 32 if f16_ffn else 512 * 64)
-    cyc_per_tile = (64 + 16 * ((J + 7) // 8)) * 64 + ffn_cycles
+    # matrix-pipe cycles per 32-vertex wave tile.  fp32 pipe: 64 score + 16 per key group of 8 output + 512 FFN instructions of 64 cycles.
+    # split-f16 mode (round 5: the attention's two contractions in the three-product form too): 24 score + 12 per 16 keys output + 192 FFN
+    # instructions of 32 cycles.
+    if f16_ffn and name == "vertex_ca_mlp":
+        cyc_per_tile = (24 + 12 * ((J + 15) // 16) + 192) * 32
+    else:
+        cyc_per_tile = (64 + 16 * ((J + 7) // 8)) * 64 + (512 * 64 if name == "vertex_ca_mlp" else 0)
     t_hbm = byt / (PEAK_HBM_GBS * 1e9) * 1e3
     t_mfma = tiles * cyc_per_tile / N_SIMD / (CLOCK_GHZ * 1e9) * 1e3
     # vector-pipe floor: the kernel's measured vector instruction count (SQ_INSTS_VALU of the committed PMC pass, per clip), 4
@@ -281,7 +286,7 @@ def north_star_record(kernel_ms, launches, B, J, f16_ffn=False, C=512):
            "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "bytes_per_clip_dir_block": 229376,
            "avg_launch_ms": round(ms, 5), "hbm_floor_ms": round(t_hbm, 5), "mfma_floor_ms": round(t_mfma, 5),
            "frac_of_floor": round(floor / ms, 4),
-           "ffn_arithmetic": "3 x f16 MFMA per fp32 product" if (f16_ffn and name == "vertex_ca_mlp") else "fp32 MFMA"}
+           "arithmetic": "attention + FFN: 3 x f16 MFMA per fp32 product" if (f16_ffn and name == "vertex_ca_mlp") else "fp32 MFMA"}
     if t_valu is not None:
         rec.update({"valu_floor_ms": round(t_valu, 5), "serial_floor_ms": round(t_mfma + t_valu, 5),
                     "frac_of_serial_floor": round((t_mfma + t_valu) / ms, 4),
@@ -355,7 +360,7 @@ def dominant_kernel_roofline(kernel_ms, launches, B, J, C, gemm_mode, clk_ghz=No
             # dense f16 peak; the fp32-equivalent rate and the same launches against the HBM roofline (every operand and
             # result once) are printed beside it - at these shapes the two floors are within 15 % of each other
             ach = 3.0 * work / secs / 1e12
-            byt = sum(gemm_class_bytes(c, B, J, C, streaming=streaming) for c in dom_classes)
+            byt = sum(gemm_class_bytes(c, B, J, C, streaming=streaming, gemm_mode=gemm_mode) for c in dom_classes)
             common["algorithmic_per_launch"] = 3.0 * work / dom_launches
             roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_F16_TFLOPS, 4), **common,
@@ -394,7 +399,8 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
     t_load0 = time.perf_counter()
     # random-init weights of the named architecture; at N > 1 generated once per node and mapped by the other ranks
     if world > 1:
-        sd, shm_path = shared_state_dict(J, C, int(os.environ.get("LOCAL_RANK", rank)), sharding.barrier)
+        nonce = int(sharding.reduce_max(float(os.getpid() if rank == 0 else 0), dev))      # rank 0's pid, known to every rank
+        sd, shm_path = shared_state_dict(J, C, int(os.environ.get("LOCAL_RANK", rank)), sharding.barrier, nonce)
     else:
         sd, shm_path = synth.make_state_dict(synth.pmce_spec(J, C, 3), seed=123), None
     model = models.PMCE.get_model(J, C, 3)
@@ -559,7 +565,8 @@ def sustained_record(model, pipe, step, dev, B, world, seconds, burst_value, gem
 
     def smi():
         try:
-            return {"power_w": torch.cuda.power_draw() / 1000.0, "temp_c": torch.cuda.temperature()}
+            raw = float(torch.cuda.power_draw())      # documented as mW; torch 2.10 on ROCm returns W (1,100 - 1,400 here)
+            return {"power_w": raw if raw < 5000 else raw / 1000.0, "temp_c": torch.cuda.temperature()}
         except Exception:  # noqa: BLE001
             return None
 

@@ -59,8 +59,12 @@ def _torch_coo(d):
 def downsample_template(mean_vertices: np.ndarray, D) -> np.ndarray:
     """[6890,3] f32 -> [431,3] f32 by the two sparse down-sampling maps.  The reference runs ``torch.matmul(sparse COO,
     dense)`` in fp32 (mesh.py:81-96 via graph_layers.py:19,29); the same torch call on the same COO entries is used here, so
-    the template - and with it every near-tie ``argmin`` of ``vj_relation`` - has the reference's bits (a scipy ``csr @ x``
-    adds a multi-entry row's terms in another order: last-ulp differences, which can flip a tie)."""
+    the template - and with it every near-tie ``argmin`` of ``vj_relation`` - has the bits of the reference code EXECUTED ON CPU (a
+    scipy ``csr @ x`` adds a multi-entry row's terms in another order: last-ulp differences, which can flip a tie).  The reference
+    itself runs these products on CUDA (mesh.py:62 ``device=cuda``, CoevoDecoder.py:200,207 ``.cuda()``): cuSPARSE / cuBLAS summation
+    order is not reproducible here, so for a vertex whose two nearest joints tie to the last ulp the table may differ from the one a
+    real run built - a caller who has that run's ``vj_relation`` can pass it (``model.vj_relation = ...`` before ``.to(device)``).  The
+    golden test ties bit-equality to the installed torch's CPU sparse matmul (tests/test_assets_real_format.py says so)."""
     import torch
     x = torch.from_numpy(np.ascontiguousarray(mean_vertices, dtype=np.float32))
     for d in D[:2]:

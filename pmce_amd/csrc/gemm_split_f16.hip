@@ -651,8 +651,11 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
   PMCE_REQUIRE(c_div == 0 || R == nullptr, "gemm_split: a C row map cannot be combined with a residual");
   PMCE_REQUIRE(!c_packed || (a_packed && act == 1 && R == nullptr && c_div == 0 && N % 32 == 0 && ldc == N),
                "gemm_split: a packed result is supported for the packed-A + GELU form with N %% 32 == 0 and ldc == N");
-  PMCE_REQUIRE(!rscale || (a_packed && !c_packed && act == 0 && R == nullptr && K >= 64),
-               "gemm_split: a row-scaled A is a packed A with K >= 64; no activation, residual or packed result");
+  PMCE_REQUIRE(!rscale || (a_packed && !c_packed && act == 0 && R == nullptr && K >= 128),
+               "gemm_split: a row-scaled A is a packed A with K >= 128; no activation, residual or packed result");
+  // (K >= 128 is the RS epilogue's invariant: it reads the tile's row-scale slice from LDS at the END of the tile, while the DMA cursor runs
+  // NS - 1 <= 3 stages ahead across tile boundaries - a tile must span at least NS - 1 stages (K / (16 KSUB) >= 3 with KSUB <= 2), or tile t + 2's
+  // slice would land on tile t's scales before its epilogue.  ADVICE r04.)
   SplitParams p;
   p.A = A; p.W = Wp; p.wscale = wscale; p.bias = bias; p.R = R; p.C = C; p.rscale = rscale; p.wblk = w_blocked;
   p.M = M; p.N = N; p.K = K; p.lda = (unsigned)lda; p.ldc = (unsigned)ldc;

@@ -396,6 +396,9 @@ def test_bench_roofline_arithmetic():
     assert abs(rec["mfma_floor_ms"] - B * 14 * 624 * 64 / 1024 / 2.4e9 * 1e3) < 1e-5
     assert abs(rec["hbm_floor_ms"] - 229376.0 * B / 8e12 * 1e3) < 1e-5
     assert rec["kernel"] == "vertex_ca_mlp" and rec["bound"] == "mfma" and abs(rec["frac_of_floor"] - rec["mfma_floor_ms"] / 0.115) < 1e-3
+    rec16 = bench.north_star_record({"vertex_ca_mlp": 0.18}, {"vertex_ca_mlp": 3}, B, J, f16_ffn=True)
+    # split-f16 mode: 24 score + 12 * ceil(17/16) output + 192 FFN matrix instructions of 32 cycles per wave tile
+    assert abs(rec16["mfma_floor_ms"] - B * 14 * (24 + 24 + 192) * 32 / 1024 / 2.4e9 * 1e3) < 1e-5
     old = bench.north_star_record({"vertex_ca": 0.09}, {"vertex_ca": 3}, B, J)
     assert old["kernel"] == "vertex_ca" and abs(old["mfma_floor_ms"] - B * 14 * 112 * 64 / 1024 / 2.4e9 * 1e3) < 1e-5
     assert bench.north_star_record({"gemm_lifter": 1.0}, {"gemm_lifter": 25}, B, J) is None
