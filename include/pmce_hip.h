@@ -385,6 +385,13 @@ int pmce_vertex_sab_split_f32(const float* xin, const float* GB, int gb_stride, 
 int pmce_tokens_kv_f32(const float* xk, const float* xv, const float* vt, const float* Wv3, const float* Ev,
                        const float* Wv2j, const float* Ek, const float* GB, int gb_stride, int ik, int iv, const float* Wk,
                        const float* bk, const float* Wv, const float* bv, float* kv, int B, pmce_stream_t stream);
+/* The same with its three 64 x 64 products (proj_v2j_dim, wk, wv) in the three-product f16 form (what a model in split_f16 mode runs): tkv_img =
+ * pmce_tkv_pack_f16(Wv2j, Wk, Wv), pmce_tkv_image_floats() floats, 16-byte aligned, made once; NULL = the fp32 form above. */
+int pmce_tkv_image_floats(void);
+int pmce_tkv_pack_f16(const float* Wv2j, const float* Wk, const float* Wv, float* tkv_img, pmce_stream_t stream);
+int pmce_tokens_kv_pk_f32(const float* xk, const float* xv, const float* vt, const float* Wv3, const float* Ev,
+                          const float* Wv2j, const float* Ek, const float* GB, int gb_stride, int ik, int iv, const float* Wk,
+                          const float* bk, const float* Wv, const float* bv, float* kv, int B, const float* tkv_img, pmce_stream_t stream);
 /* Joint stream of a CoevoBlock (CoevoDecoder.py:183,187,189): stage 1 = joint<-vertex cross-attention +
  * residual only, 2 = + FFN, 3 = + self-attention block + coordinate head.  wptr: 18 weight pointers
  * (wq,bq,proj_w,proj_b,fc1_w,fc1_b,fc2_w,fc2_b,qkv_w,qkv_b,sproj_w,sproj_b,sfc1_w,sfc1_b,sfc2_w,sfc2_b,coor_w,coor_b);

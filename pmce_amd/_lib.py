@@ -103,6 +103,9 @@ PROTOTYPES = {
     "pmce_vertex_sab_scratch_floats": [_i],
     "pmce_vertex_sab_split_f32": [_f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _i, _s],
     "pmce_tokens_kv_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _f, _f, _f, _i, _s],
+    "pmce_tkv_image_floats": [],
+    "pmce_tkv_pack_f16": [_f, _f, _f, _f, _s],
+    "pmce_tokens_kv_pk_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _f, _f, _f, _i, _f, _s],
     "pmce_joint_stream_f32": [_f, _f, _f, _f, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_int), _f, _f, _f, _i, _i, _i, _s],
     "pmce_build_final_operand_f32": [_f, _f, _f, _i, _i, _s],
     "pmce_j_regress_f32": [_f, _f, _f, _f, _f, _i, _i, _i, _fl, _s],

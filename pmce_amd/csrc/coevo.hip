@@ -1600,25 +1600,77 @@ __global__ __launch_bounds__(448) void vertex_sab_kernel(const float* __restrict
 //   kv[tok][64:128] = Wv * AdaLN_v(xv) + bv     xv = vf
 // Generic form: xk/xv given ([B,431,64]).  Fused form (xk == nullptr): vf = Wv3*vt + Ev[v] formed on the fly
 // (Ev = vertx_proj.bias + vertx_pos_embed) and xk = Wv2j*vf + Ek[v] (Ek = proj_v2j_dim.bias + v2j_K_embed).
+// F16 (split mode, round 5): the three 64 x 64 products in the three-product f16 form of the FFN kernels - 72 matrix instructions of 32
+// cycles per 32-token tile instead of 192 of 64 - from an image of the three weights made once (pmce_tkv_pack_f16: per weight
+// stage_weight_split's rows of W * 2^s, then the three {2^s, 2^-s} pairs), staged by LDS-DMA; with that the kernel fits two workgroups
+// per CU (the fp32 form's 192 64-cycle instructions per tile are scheduled over 380 registers: one wave per SIMD).
 // ======================================================================================================
-__global__ __launch_bounds__(256) void tokens_kv_kernel(const float* __restrict__ xk_in, const float* __restrict__ xv_in,
+#define TKV_IMG_FLOATS (3 * 64 * LDW64 + 32)
+template <bool F16>
+__global__ __launch_bounds__(256, F16 ? 2 : 1) void tokens_kv_kernel(const float* __restrict__ xk_in, const float* __restrict__ xv_in,
                                                         const float* __restrict__ vt, const float* __restrict__ Wv3,
                                                         const float* __restrict__ Ev, const float* __restrict__ Wv2j,
                                                         const float* __restrict__ Ek, const float* __restrict__ GB,
                                                         int gb_stride, int ik, int iv, const float* __restrict__ Wk,
                                                         const float* __restrict__ bk, const float* __restrict__ Wv,
-                                                        const float* __restrict__ bv, float* __restrict__ kv, int B) {
-  __shared__ __attribute__((aligned(16))) float sWk[64 * LDW64];
-  __shared__ __attribute__((aligned(16))) float sWv[64 * LDW64];
-  __shared__ __attribute__((aligned(16))) float sW2[64 * LDW64];
+                                                        const float* __restrict__ bv, float* __restrict__ kv, int B,
+                                                        const float* __restrict__ img) {
+  __shared__ __attribute__((aligned(16))) float sW[3 * 64 * LDW64];  // [W2 | Wk | Wv]: fp32 rows, or (F16) the image's f16 planes
+  __shared__ float sSc[8];
+  float* sW2 = sW;
+  float* sWk = sW + 64 * LDW64;
+  float* sWv = sW + 2 * 64 * LDW64;
   const int tid = threadIdx.x;
-  stage_weight<64>(sWk, Wk, 64, tid, 256);
-  stage_weight<64>(sWv, Wv, 64, tid, 256);
-  if (!xk_in) stage_weight<64>(sW2, Wv2j, 64, tid, 256);
+  if constexpr (F16) {
+    static_assert(3 * 64 * LDW64 * 4 % 1024 == 0, "the image's planes are a whole number of KiB");
+    lds_dma_copy(sW, img, 3 * 64 * LDW64 * 4 / 1024, tid >> 6, 4, tid & 63);
+    if (tid < 6) sSc[tid] = img[3 * 64 * LDW64 + tid];
+    lds_dma_wait();
+  } else {
+    stage_weight<64>(sWk, Wk, 64, tid, 256);
+    stage_weight<64>(sWv, Wv, 64, tid, 256);
+    if (!xk_in) stage_weight<64>(sW2, Wv2j, 64, tid, 256);
+  }
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   const int n0 = lane & 31, hb = lane >> 5;
   const int ntiles = B * NTILE;
+  // y[s] = bias-or-embedding[s] + (W x)[s] for the 64 x 64 weight at `sw`: fp32 pipe, or the three-product f16 form (scale pair `isc`)
+  auto linear64 = [&](const float* sw, int isc, const float* x, const float* add, float* y) {
+    if constexpr (F16) {
+      const float down = sSc[2 * isc + 1];
+      tl_f16x8 xhi[4], xlo[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) split_slots8(x + 8 * s, xhi[s], xlo[s]);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x16 m, c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[r] = c[r] = 0.f;
+        const float* w = sw + (nt * 32 + n0) * LDW64 + hb * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const tl_f16x8 whi = *reinterpret_cast<const tl_f16x8*>(w + s * 16), wlo = *reinterpret_cast<const tl_f16x8*>(w + s * 16 + 4);
+          m = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, xhi[s], m, 0, 0, 0);
+          m = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xhi[s], m, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, xlo[s], c, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[16 * nt + r] = fmaf(fmaf(c[r], 0.00048828125f, m[r]), down, add[16 * nt + r]);
+      }
+    } else {
+      f32x16 t[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[nt][r] = add[16 * nt + r];
+      tl_gemm<8, 2, LDW64>(sw, x, t, n0, hb);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[16 * nt + r] = t[nt][r];
+    }
+  };
   for (int wt = blockIdx.x * 4 + wave; wt < ntiles; wt += gridDim.x * 4) {
     const int b = wt / NTILE, tile = wt % NTILE;
     const int v = tile * 32 + n0;
@@ -1640,49 +1692,36 @@ __global__ __launch_bounds__(256) void tokens_kv_kernel(const float* __restrict_
       }
       float e[32];
       load_slots(Ek + (long long)vc * 64, e, hb);
-      f32x16 t[2];
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t[nt][r] = e[16 * nt + r];
-      tl_gemm<8, 2, LDW64>(sW2, xv, t, n0, hb);
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xk[16 * nt + r] = t[nt][r];
+      linear64(sW2, 0, xv, e, xk);
     }
     const float* gb = GB + (long long)b * gb_stride;
-    float a[32];
-    f32x16 acc[2];
+    float a[32], bias[32], y[32];
     // k
     adaln_slots(xk, a, gb + ik * 128, hb);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nt][r] = bk[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb];
-    tl_gemm<8, 2, LDW64>(sWk, a, acc, n0, hb);
-    if (valid) {
-      float y[32];
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) y[16 * nt + r] = acc[nt][r];
-      store_slots(kv + tok * 128, y, hb);
-    }
+    for (int s = 0; s < 32; ++s) bias[s] = bk[slot_channel(s, hb)];
+    linear64(sWk, 1, a, bias, y);
+    if (valid) store_slots(kv + tok * 128, y, hb);
     // v
     adaln_slots(xv, a, gb + iv * 128, hb);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nt][r] = bv[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb];
-    tl_gemm<8, 2, LDW64>(sWv, a, acc, n0, hb);
-    if (valid) {
-      float y[32];
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) y[16 * nt + r] = acc[nt][r];
-      store_slots(kv + tok * 128 + 64, y, hb);
+    for (int s = 0; s < 32; ++s) bias[s] = bv[slot_channel(s, hb)];
+    linear64(sWv, 2, a, bias, y);
+    if (valid) store_slots(kv + tok * 128 + 64, y, hb);
+  }
+}
+// the three weights' f16 image: [W2j | Wk | Wv] rows as stage_weight_split writes them, then {2^s, 2^-s} per weight
+__global__ __launch_bounds__(256) void tkv_pack_kernel(const float* __restrict__ W2, const float* __restrict__ Wk, const float* __restrict__ Wv,
+                                                       float* __restrict__ img) {
+  __shared__ float red[16];
+  const float* W[3] = {W2, Wk, Wv};
+  for (int i = 0; i < 3; ++i) {
+    float up, down;
+    weight_scale(W[i], 64 * 64, red, threadIdx.x, 256, up, down);
+    stage_weight_split<64>(img + i * 64 * LDW64, W[i], 64, up, threadIdx.x, 256);
+    if (threadIdx.x == 0) {
+      img[3 * 64 * LDW64 + 2 * i] = up;
+      img[3 * 64 * LDW64 + 2 * i + 1] = down;
     }
   }
 }
@@ -2150,14 +2189,35 @@ extern "C" int pmce_vertex_sab_split_f32(const float* xin, const float* GB, int 
   return pmce_check_launch("vertex_sab");
 }
 
+extern "C" int pmce_tkv_image_floats(void) { return TKV_IMG_FLOATS; }
+extern "C" int pmce_tkv_pack_f16(const float* Wv2j, const float* Wk, const float* Wv, float* img, hipStream_t stream) {
+  PMCE_REQUIRE(Wv2j && Wk && Wv && img && (reinterpret_cast<uintptr_t>(img) & 15) == 0, "tkv_pack: null or unaligned pointer");
+  hipLaunchKernelGGL(tkv_pack_kernel, dim3(1), dim3(256), 0, stream, Wv2j, Wk, Wv, img);
+  return pmce_check_launch("tkv_pack_f16");
+}
+// tkv_img != null: the three 64 x 64 products in the three-product f16 form from the image of pmce_tkv_pack_f16(Wv2j, Wk, Wv) (Wv2j, Wk, Wv
+// themselves are then not read)
+extern "C" int pmce_tokens_kv_pk_f32(const float* xk, const float* xv, const float* vt, const float* Wv3, const float* Ev,
+                                     const float* Wv2j, const float* Ek, const float* GB, int gb_stride, int ik, int iv,
+                                     const float* Wk, const float* bk, const float* Wv, const float* bv, float* kv, int B,
+                                     const float* tkv_img, hipStream_t stream) {
+  PMCE_REQUIRE(((xk && xv) || (vt && Wv3 && Ev && Ek && (Wv2j || tkv_img))) && GB && bk && bv && kv && ((Wk && Wv) || tkv_img),
+               "tokens_kv: null pointer");
+  if (tkv_img) {
+    PMCE_REQUIRE((reinterpret_cast<uintptr_t>(tkv_img) & 15) == 0, "tokens_kv: unaligned image");
+    hipLaunchKernelGGL(tokens_kv_kernel<true>, dim3(tl_grid(B, 2)), dim3(256), 0, stream, xk, xv, vt, Wv3, Ev, Wv2j, Ek, GB, gb_stride, ik, iv,
+                       Wk, bk, Wv, bv, kv, B, tkv_img);
+  } else {
+    hipLaunchKernelGGL(tokens_kv_kernel<false>, dim3(tl_grid(B, 2)), dim3(256), 0, stream, xk, xv, vt, Wv3, Ev, Wv2j, Ek, GB, gb_stride, ik, iv,
+                       Wk, bk, Wv, bv, kv, B, nullptr);
+  }
+  return pmce_check_launch("tokens_kv");
+}
 extern "C" int pmce_tokens_kv_f32(const float* xk, const float* xv, const float* vt, const float* Wv3, const float* Ev,
                                   const float* Wv2j, const float* Ek, const float* GB, int gb_stride, int ik, int iv,
                                   const float* Wk, const float* bk, const float* Wv, const float* bv, float* kv, int B,
                                   hipStream_t stream) {
-  PMCE_REQUIRE(((xk && xv) || (vt && Wv3 && Ev && Wv2j && Ek)) && GB && Wk && bk && Wv && bv && kv, "tokens_kv: null pointer");
-  hipLaunchKernelGGL(tokens_kv_kernel, dim3(tl_grid(B, 2)), dim3(256), 0, stream, xk, xv, vt, Wv3, Ev, Wv2j, Ek, GB, gb_stride,
-                     ik, iv, Wk, bk, Wv, bv, kv, B);
-  return pmce_check_launch("tokens_kv");
+  return pmce_tokens_kv_pk_f32(xk, xv, vt, Wv3, Ev, Wv2j, Ek, GB, gb_stride, ik, iv, Wk, bk, Wv, bv, kv, B, nullptr, stream);
 }
 
 extern "C" int pmce_joint_stream_f32(const float* xq, const float* jQ, const float* kv, const float* GB, int gb_stride,

@@ -114,6 +114,7 @@ struct pmce_model {
   bool split_overlap = true;
   const float* ffn_img[3][2] = {};     // per vertex block: the LDS images of the two FFNs' f16 form (vca, vsa), in the split arena
   const float* qkv_img[3] = {};        // per vertex block: the self-attention qkv weight's f16 form (vertex_sab)
+  const float* tkv_img = nullptr;      // the joint<-vertex direction's three 64 x 64 weights (tokens_kv), block 3
   bool split_now = false;  // decision for the call in progress (set by check_ws, the first thing every entry point does)
   // Sticky "a product of this model produced a non-finite value" word: 4 bytes of pinned host memory the device can write
   // (hipHostMalloc, mapped), so that reading it costs no synchronisation.  Set by the split-f16 products' epilogues (an activation
@@ -616,10 +617,10 @@ int joint_branch(pmce_model* m, const float* joints, const float* vt_in, float* 
                  hipStream_t stream) {
   const int J = m->J, gbs = N_ADA * 128;
   const JointBlockW& jw = m->w.jb;
-  RUN(P_TOKENS_KV, pmce_tokens_kv_f32(nullptr, nullptr, vt_in, m->w.vb[2].vertx_proj_w, jw.Ev,
-                                      jw.v2j_w, jw.Ek, w.GB, gbs, 19, 20,
-                                      jw.jca_wk_w, jw.jca_wk_b, jw.jca_wv_w,
-                                      jw.jca_wv_b, w.KVJ, B, stream));
+  RUN(P_TOKENS_KV, pmce_tokens_kv_pk_f32(nullptr, nullptr, vt_in, m->w.vb[2].vertx_proj_w, jw.Ev,
+                                         jw.v2j_w, jw.Ek, w.GB, gbs, 19, 20,
+                                         jw.jca_wk_w, jw.jca_wk_b, jw.jca_wv_w,
+                                         jw.jca_wv_b, w.KVJ, B, pkf(m) ? m->tkv_img : nullptr, stream));
   const int inst[4] = {18, 21, 22, 23};
   RUN(P_JOINT_STREAM, pmce_joint_stream_f32(w.JF[2], jw.j_Q, w.KVJ, w.GB, gbs, jw.stream, inst, joints, nullptr,
                                             cam_pose, B, J, 3, stream));
@@ -746,6 +747,7 @@ struct SplitItem { const float* w; int n, k; SplitW* dst; };
 size_t split_item_floats(int n, int k) { return ((((size_t)n + 63) & ~(size_t)63) * k) + (((size_t)n + 63) & ~(size_t)63); }  // planes (rows padded to the 64-row blocks of the blocked layout) + 2^-s per row
 size_t ffn_img_floats() { return ((size_t)pmce_ffn_image_floats() + 63) & ~(size_t)63; }  // one FFN's LDS image (coevo.hip), 256-byte granules
 size_t qkv_img_floats() { return ((size_t)pmce_qkv_image_floats() + 63) & ~(size_t)63; }
+size_t tkv_img_floats() { return ((size_t)pmce_tkv_image_floats() + 63) & ~(size_t)63; }
 // bytes of the planes of a model with / without lifter and decoder
 size_t split_bytes_for(int C, int depth, bool lifter, bool decoder) {
   size_t f = 0;
@@ -755,7 +757,8 @@ size_t split_bytes_for(int C, int depth, bool lifter, bool decoder) {
   }
   if (decoder)
     f += split_item_floats(6 * GH, F) + split_item_floats(6 * GH, 2 * GH) + 2 * split_item_floats(6 * GH, GH) +
-         split_item_floats(N_ADA * 128, 2 * GH) + split_item_floats(NVF * 3, FINAL_K) + 6 * ffn_img_floats() + 3 * qkv_img_floats();
+         split_item_floats(N_ADA * 128, 2 * GH) + split_item_floats(NVF * 3, FINAL_K) + 6 * ffn_img_floats() + 3 * qkv_img_floats() +
+         tkv_img_floats();
   return f * sizeof(float);
 }
 int build_split_weights(pmce_model* m, hipStream_t stream) {
@@ -770,6 +773,7 @@ int build_split_weights(pmce_model* m, hipStream_t stream) {
   m->s_ie = m->s_wih0 = m->s_wih1 = m->s_whh0 = m->s_whh1 = m->s_ada = m->s_final = SplitW{};
   for (auto& b : m->ffn_img) b[0] = b[1] = nullptr;
   for (auto& q : m->qkv_img) q = nullptr;
+  m->tkv_img = nullptr;
   if (!m->split_gemm) return PMCE_OK;
   const int C = m->C;
   std::vector<SplitItem> items;
@@ -796,7 +800,7 @@ int build_split_weights(pmce_model* m, hipStream_t stream) {
   if (items.empty()) return PMCE_OK;
   size_t floats = 0;
   for (auto& it : items) floats += split_item_floats(it.n, it.k);
-  if (m->has_decoder) floats += 6 * ffn_img_floats() + 3 * qkv_img_floats();
+  if (m->has_decoder) floats += 6 * ffn_img_floats() + 3 * qkv_img_floats() + tkv_img_floats();
   if (m->caller_arena) {  // the caller's memory (its allocator, its lifetime): pmce_model_set_split_arena
     if (m->caller_arena_bytes < floats * sizeof(float)) {
       pmce_set_error("model_finalize: the split arena holds %zu bytes, the planes need %zu (pmce_model_split_bytes)", m->caller_arena_bytes,
@@ -840,6 +844,11 @@ int build_split_weights(pmce_model* m, hipStream_t stream) {
       m->qkv_img[k] = p;
       p += qkv_img_floats();
     }
+  if (m->has_decoder) {
+    PMCE_TRY(pmce_tkv_pack_f16(m->w.jb.v2j_w, m->w.jb.jca_wk_w, m->w.jb.jca_wv_w, p, stream));
+    m->tkv_img = p;
+    p += tkv_img_floats();
+  }
   if (hipStreamSynchronize(stream) != hipSuccess) {
     pmce_set_error("model_finalize: packing the split weights failed");
     return PMCE_ERR_LAUNCH;
@@ -1003,6 +1012,7 @@ int pmce_model_share_split_weights(pmce_model* dst, const pmce_model* src) {
   dst->s_ie = src->s_ie; dst->s_wih0 = src->s_wih0; dst->s_wih1 = src->s_wih1; dst->s_whh0 = src->s_whh0; dst->s_whh1 = src->s_whh1;
   dst->s_ada = src->s_ada; dst->s_final = src->s_final;
   for (int k = 0; k < 3; ++k) dst->ffn_img[k][0] = src->ffn_img[k][0], dst->ffn_img[k][1] = src->ffn_img[k][1], dst->qkv_img[k] = src->qkv_img[k];
+  dst->tkv_img = src->tkv_img;
   dst->split_gemm = true;
   dst->split_adopted = true;
   dst->oflow = src->oflow;  // lanes of one model report to one word

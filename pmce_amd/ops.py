@@ -298,19 +298,24 @@ def vertex_self_attn(x, g, sd, p, split_f16=False):
     return y, qkv
 
 
-def joint_stream(xq, xk, xv, g, sd, blk, stage, jt=None):
+def joint_stream(xq, xk, xv, g, sd, blk, stage, jt=None, split_f16=False):
     """Joint stream of a CoevoBlock given explicit q/k/v token sets (xq[B,J,64], xk/xv[B,431,64]):
-    stage 1 = xq + CA (CoevoDecoder.py:83), 2 = + FFN (:85-86), 3 = + joint_SA_FFN (:187) (+ coords if jt)."""
+    stage 1 = xq + CA (CoevoDecoder.py:83), 2 = + FFN (:85-86), 3 = + joint_SA_FFN (:187) (+ coords if jt).
+    split_f16: the k / v products over the 431 vertex tokens (tokens_kv) in the three-product f16 form from the weights' image."""
     lib = _lib.load()
     xq, xk, xv = _c(xq), _c(xk), _c(xv)
     B, J, _ = xq.shape
     ca, sa = blk + ".joint_CA_FFN", blk + ".joint_SA_FFN"
     GB = adaln_params(g, sd, [ca + ".normq", ca + ".normk", ca + ".normv", ca + ".norm2", sa + ".norm1", sa + ".norm2"])
     kv = torch.empty(B, 431, 128, device=xq.device)
-    _lib.check(lib.pmce_tokens_kv_f32(P(xk), P(xv), None, None, None, None, None, P(GB), GB.shape[1], 1, 2,
-                                      P(_c(sd[ca + ".attn.wk.weight"])), P(_c(sd[ca + ".attn.wk.bias"])),
-                                      P(_c(sd[ca + ".attn.wv.weight"])), P(_c(sd[ca + ".attn.wv.bias"])), P(kv), B, _st()),
-               "tokens_kv")
+    Wk, Wv = _c(sd[ca + ".attn.wk.weight"]), _c(sd[ca + ".attn.wv.weight"])
+    img = None
+    if split_f16:   # (the generic form does not use proj_v2j_dim: any 64 x 64 weight fills the image's first slot)
+        img = torch.empty(lib.pmce_tkv_image_floats(), device=xq.device)
+        _lib.check(lib.pmce_tkv_pack_f16(P(Wk), P(Wk), P(Wv), P(img), _st()), "tkv_pack_f16")
+    _lib.check(lib.pmce_tokens_kv_pk_f32(P(xk), P(xv), None, None, None, None, None, P(GB), GB.shape[1], 1, 2,
+                                         P(Wk), P(_c(sd[ca + ".attn.wk.bias"])), P(Wv), P(_c(sd[ca + ".attn.wv.bias"])), P(kv), B,
+                                         P(img), _st()), "tokens_kv")
     names = [ca + ".attn.wq.weight", ca + ".attn.wq.bias", ca + ".attn.proj.weight", ca + ".attn.proj.bias",
              ca + ".mlp.fc1.weight", ca + ".mlp.fc1.bias", ca + ".mlp.fc2.weight", ca + ".mlp.fc2.bias",
              sa + ".attn.qkv.weight", sa + ".attn.qkv.bias", sa + ".attn.proj.weight", sa + ".attn.proj.bias",

@@ -499,6 +499,17 @@ def test_joint_stream(golden, stage):
     e = maxabs(y, ref)
     print(f"joint_stream stage {stage}: {e:.2e}")
     assert e < 2e-5
+    # round 5: the k / v products over the 431 vertex tokens (tokens_kv) in the three-product f16 form, as a model in split_f16 mode runs
+    # them: k | v against the oracle's Linear(AdaLN(.)) next to the fp32 form's, and the stream's result with them
+    y16, pose16, kv16 = ops.joint_stream(xj.to(dev()), xv.to(dev()), xv.to(dev()), g.to(dev()), sdd, BLK, stage,
+                                         jt=jt.to(dev()) if stage == 3 else None, split_f16=True)
+    with torch.no_grad():
+        kref = O.linear(O.ada_layer_norm(xv.double(), g.double(), sd, ca + ".normk", torch.float64), sd, ca + ".attn.wk", torch.float64)
+        vref = O.linear(O.ada_layer_norm(xv.double(), g.double(), sd, ca + ".normv", torch.float64), sd, ca + ".attn.wv", torch.float64)
+        kvref = torch.cat([kref, vref], -1)
+    e16, e32 = maxabs(kv16, kvref), maxabs(kv, kvref)
+    print(f"   tokens_kv vs the fp64 oracle: three-product f16 form {e16:.2e}, fp32 pipe {e32:.2e}; stream with it {maxabs(y16, ref):.2e}")
+    assert e16 <= 1.5 * e32 + 1e-6 and maxabs(y16, ref) < 2e-5
 
 
 def test_j_regress(golden):
