@@ -93,7 +93,7 @@ int pmce_model_set_split_arena(pmce_model* m, void* arena, size_t bytes);
  * model packs for itself at finalize, 0 = the fp32 matrix pipe.  Both meet fp32 accuracy (tests/test_gpu_ops.py measures
  * each against an fp64 product); may be called at any time between forwards.  In split_f16 mode the GRU recurrence, the decoder's
  * FFNs and 431x431 self-attention and the lifter's attention (pmce_seq_attention_split_f16, for J = 17 / 19) use the same
- * three-product form; A/B knobs read once at create: PMCE_FFN_F16=0, PMCE_ATTN_F16=0 keep those on the fp32 / vector pipes. */
+ * three-product form. */
 int pmce_model_set_gemm_mode(pmce_model* m, int split_f16);
 /* The same with the packing (when the mode changes on a finalized model) on `stream`; it first waits for the whole device
  * (forwards in flight may read the planes it frees), so it must not be called during a stream capture. */

@@ -1,12 +1,13 @@
 #!/bin/bash
-# GPU session script: bash scripts/gpu_session.sh [tests] [bench] [order_ab] [prof] [pmc] [quick "<pytest -k expr>"] (any subset, in this order).
-# Everything lands under gpurun_out/r04/.
+# GPU session script: bash scripts/gpu_session.sh [tests] [bench] [ab_r4] [prof] [pmc] [counters] [quick "<pytest -k expr>"] (any subset, in this order).
+# Everything lands under gpurun_out/$PMCE_ROUND (default r05); summaries are copied to profiles/ by hand afterwards.
 set -u
-R=${PMCE_ROUND:-r04}
+R=${PMCE_ROUND:-r05}
 mkdir -p gpurun_out/$R
 O=gpurun_out/$R
 export TMPDIR=/tmp PMCE_SYNTHETIC_BASE_DATA=1
-python -c "import pmce_amd.build as b; print(b.build()); print(b.build_diag())" > $O/build.log 2>&1 || { cat $O/build.log; exit 1; }
+python -c "import pmce_amd.build as b; print(b.build()); print(b.build_diag()); from pmce_amd import _lib; print('build id', _lib.build_id())" > $O/build.log 2>&1 || { cat $O/build.log; exit 1; }
+tail -n 1 $O/build.log
 QUICK="--no-variant --no-cpu-baseline --no-latency --no-host-fed --steps 20 --warmup 5 --windows 3"
 while [[ $# -gt 0 ]]; do
 what=$1; shift
@@ -27,15 +28,22 @@ bench)
   echo "bench exit: $?"; python scripts/show_bench.py $O/bench.json 2>/dev/null | head -120 || head -c 3000 $O/bench.json
   tail -n 5 $O/bench.err | grep -v amdgpu.ids || true
   ;;
-order_ab)
-  for i in 1 2; do for o in 0 1; do
-    PMCE_SPLIT_ORDER=$o timeout 300 python bench.py $QUICK > $O/bench_order${o}_$i.json 2>> $O/order_ab.err
-    python - <<PY
-import json
-d=json.loads(open("$O/bench_order${o}_$i.json").read().strip().splitlines()[-1])
-print("order $o run $i: ms/step", d["ms_per_step"], "gemm_lifter", d["kernel_ms_per_step"].get("gemm_lifter"), "gemm_gru_in", d["kernel_ms_per_step"].get("gemm_gru_in"), "clock", d["roofline"].get("sustained_clock_ghz"))
+ab_r4)
+  # the round-4 tree (git archive 4bbd38d into .r4tree, library prebuilt) against this tree, A/B/A/B on THIS box, both widths
+  rm -f $O/ab_r4_vs_r5.txt
+  for C in 512 256; do for i in 1 2; do for T in r4 r5; do
+    if [[ $T == r4 ]]; then (cd .r4tree && timeout 300 python bench.py --embed-dim $C $QUICK 2>> ../$O/ab_r4.err) > $O/ab_tmp.json
+    else timeout 300 python bench.py --embed-dim $C $QUICK --sustained-seconds 0 > $O/ab_tmp.json 2>> $O/ab_r4.err; fi
+    T=$T C=$C python - <<PY | tee -a $O/ab_r4_vs_r5.txt
+import json, os
+d = json.loads(open("$O/ab_tmp.json").read().strip().splitlines()[-1])
+k = d["kernel_ms_per_step"]
+dec = sum(k.get(n, 0) for n in ("joint_embed", "ca_fold", "vertex_ca_mlp", "adaln_qkv", "vertex_sa", "adaln_mlp"))
+print(os.environ["T"], "C=" + os.environ["C"], "clips/s", d["value"], "ms/step", d["ms_per_step"], "| vertex stream per CoevoBlock us", round(dec / 3 * 1e3, 1),
+      "| gemm_lifter", k.get("gemm_lifter"), "ln_chain", k.get("ln_chain"), "seq_attention", k.get("seq_attention"), "tokens_kv", k.get("tokens_kv"),
+      "| single-stream sum", d["kernel_ms_total_single_stream"], "clock", d["roofline"].get("sustained_clock_ghz"))
 PY
-  done; done
+  done; done; done
   ;;
 prof)
   for C in 512 256; do
@@ -54,8 +62,17 @@ pmc)
       (cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OLDPWD/$O/pmc$C/$c -o pmc -- python $OLDPWD/bench.py --embed-dim $C --steps 2 --warmup 1 --windows 1 --no-cpu-baseline --no-latency --no-variant --single-stream > $OLDPWD/$O/pmc$C.$c.log 2>&1)
       echo "pmc C=$C $c exit $?"
     done
-    python scripts/pmc_summary.py $O/pmc$C $O/pmc_hbm_traffic_per_launch_C$C.json
+    python scripts/pmc_summary.py $O/pmc$C $O/pmc_hbm_traffic_per_launch_C$C.json | grep -v "at::\|rocclr" | head -40
     find $O/pmc$C -name "*.csv" -size +8M -delete
+  done
+  ;;
+counters)
+  # SQ counters per kernel (matrix-pipe busy, VALU instruction counts, wait cycles, LDS conflicts) of the whole forward, both widths
+  for C in 512 256; do
+    PMCE_PMC_C=$C bash scripts/pmc_kernels.sh "." > $O/pmc_counters_C$C.txt 2>&1
+    cp gpurun_out/kpmc/summary.json $O/pmc_counters_per_kernel_C$C.json
+    grep -A1 "vertex_ca_mlp\|gemm_split_kernel<2, 4, 0, true" $O/pmc_counters_C$C.txt | head -8
+    grep "matrix pipe busy" $O/pmc_counters_C$C.txt | wc -l
   done
   ;;
 esac
