@@ -120,12 +120,13 @@ __device__ __forceinline__ void lin_tiled(const float* in, int ild, const float*
 // AdaLN over J tokens of 64 channels held in LDS: one wavefront per token (8 waves), lane = channel.
 __device__ __forceinline__ void adaln_small8(const float* in, float* out, const float* __restrict__ gb, int J, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
+  const float gam = gb[lane], bet = gb[64 + lane];  // (one global load each, ahead of the token loop)
   for (int i = wave; i < J; i += 8) {
     const float x = in[i * JLD + lane];
     const float mean = wave_sum(x) * (1.0f / 64.0f);
     const float d = x - mean;
     const float var = wave_sum(d * d) * (1.0f / 63.0f);
-    out[i * JLD + lane] = gb[lane] * d / (sqrtf(var) + 1e-6f) + gb[64 + lane];
+    out[i * JLD + lane] = gam * d / (sqrtf(var) + 1e-6f) + bet;
   }
 }
 
@@ -190,19 +191,37 @@ __global__ __launch_bounds__(JS_THREADS) void ca_fold_kernel(CaFoldArgs a) {
     jtile_store(s_wp, prep, tid);
     __syncthreads();
   } else {  // joint_embed: jf -> s_b ; proj_j2v_dim(jf) + j2v_K_embed -> s_a
-    for (int idx = tid; idx < J * 64; idx += JS_THREADS) {
-      const int i = idx >> 6, c = idx & 63;
-      const float* p = a.jt + ((long long)b * J + i) * 3;
-      const float v = ((a.Wj[c * 3] * p[0] + a.Wj[c * 3 + 1] * p[1] + a.Wj[c * 3 + 2] * p[2]) + a.bj[c]) + a.jpos[i * 64 + c];
-      s_b[i * JLD + c] = v;
-      if (a.jf_out) a.jf_out[((long long)b * J + i) * 64 + c] = v;
+    // 512 threads = 8 tokens x 64 channels per pass, at most 4 passes (J <= 32); a thread's channel is the same in every pass.  Every
+    // load of the phase is issued before its first use (as plain loops each pass waited for its own dependent loads).
+    const int c = tid & 63, i0 = tid >> 6;
+    const float w0 = a.Wj[c * 3], w1 = a.Wj[c * 3 + 1], w2 = a.Wj[c * 3 + 2], bjc = a.bj[c];
+    float px[4], py[4], pz[4], pe[4], ke[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 8 * u;
+      if (i < J) {
+        const float* p = a.jt + ((long long)b * J + i) * 3;
+        px[u] = p[0]; py[u] = p[1]; pz[u] = p[2];
+        pe[u] = a.jpos[i * 64 + c];
+        ke[u] = a.j2vK[i * 64 + c];   // (needed after the product below: in flight meanwhile)
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 8 * u;
+      if (i < J) {
+        const float v = ((w0 * px[u] + w1 * py[u] + w2 * pz[u]) + bjc) + pe[u];
+        s_b[i * JLD + c] = v;
+        if (a.jf_out) a.jf_out[((long long)b * J + i) * 64 + c] = v;
+      }
     }
     jtile_store(s_wp, prep, tid);
     lin_tiled<64, 64>(s_b, JLD, a.Wj2v, a.bj2v, s_k, JLD, J, tid, false, s_w, pre, a.Wk, 64);  // (its first barrier publishes s_b and s_wp)
     __syncthreads();
-    for (int idx = tid; idx < J * 64; idx += JS_THREADS) {
-      const int i = idx >> 6, c = idx & 63;
-      s_a[i * JLD + c] = s_k[i * JLD + c] + a.j2vK[i * 64 + c];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 8 * u;
+      if (i < J) s_a[i * JLD + c] = s_k[i * JLD + c] + ke[u];
     }
     __syncthreads();
   }
@@ -671,11 +690,16 @@ __global__ __launch_bounds__(64 * NW) void adaln_mlp_kernel(const float* __restr
   float* sW2 = sW1 + 256 * LDW64;       // [64][260]
   float* sB1 = sW2 + 64 * LDW256;       // [256]
   float* sB2 = sB1 + 256;               // [64]
-  float* sSc = sB2 + 64;                // [4 + 16] scales of the f16 form + reduction scratch
+  float* sSc = sB2 + 64;                // [4 + 16] scales of the f16 form + reduction scratch (+ 12 pad)
+  float* sWc = sSc + 32;                // [3][64] coordinate head + [3] its bias (fetched once, not per tile after the FFN)
   const int tid = threadIdx.x;
   stage_ffn_any<F16>(sW1, sW2, sSc, W1, W2, ffn_img, tid, 64 * NW);
   if (tid < 256) sB1[tid] = b1[tid];
   if (tid < 64) sB2[tid] = b2[tid];
+  if (vt_out) {
+    if (tid < 192) sWc[tid] = Wc[tid];
+    if (tid < 3) sWc[192 + tid] = bc[tid];
+  }
   lds_dma_wait();
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
@@ -703,9 +727,9 @@ __global__ __launch_bounds__(64 * NW) void adaln_mlp_kernel(const float* __restr
       float d0 = 0.f, d1 = 0.f, d2 = 0.f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc + 8 * q + 4 * hb);
-        const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wc + 64 + 8 * q + 4 * hb);
-        const f32x4 w2 = *reinterpret_cast<const f32x4*>(Wc + 128 + 8 * q + 4 * hb);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(sWc + 8 * q + 4 * hb);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(sWc + 64 + 8 * q + 4 * hb);
+        const f32x4 w2 = *reinterpret_cast<const f32x4*>(sWc + 128 + 8 * q + 4 * hb);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int s = 4 * q + i;
@@ -721,9 +745,9 @@ __global__ __launch_bounds__(64 * NW) void adaln_mlp_kernel(const float* __restr
       if (valid && hb == 0) {
         const float* pi = vt_in + tok * 3;
         float* po = vt_out + tok * 3;
-        po[0] = (d0 + bc[0]) + pi[0];
-        po[1] = (d1 + bc[1]) + pi[1];
-        po[2] = (d2 + bc[2]) + pi[2];
+        po[0] = (d0 + sWc[192]) + pi[0];
+        po[1] = (d1 + sWc[193]) + pi[1];
+        po[2] = (d2 + sWc[194]) + pi[2];
       }
     }
   }
@@ -1307,6 +1331,7 @@ __global__ __launch_bounds__(448) void vertex_sab_kernel(const float* __restrict
   __shared__ __attribute__((aligned(16))) float sVv[2][64 * SA_VTLD];
   __shared__ __attribute__((aligned(16))) float sQ[QT == 2 ? 7 * 8 * 64 * 4 : 4];  // the second query tile's 8 q fragments per wave
   __shared__ float sB[192];
+  __shared__ __attribute__((aligned(16))) float sGB[128];  // the clip's AdaLN gamma | beta (every tile of the workgroup uses them)
   __shared__ float sSc[2];
   const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -1315,8 +1340,9 @@ __global__ __launch_bounds__(448) void vertex_sab_kernel(const float* __restrict
   lds_dma_copy(sW, qkv_img, 192 * LDW64 * 4 / 1024, wave, 7, lane);  // 51 KiB, every piece in flight at once
   if (tid < 2) sSc[tid] = qkv_img[192 * LDW64 + tid];
   if (tid < 192) sB[tid] = bqkv[tid];
+  if (tid >= 192 && tid < 320) sGB[tid - 192] = GB[(long long)b * gb_stride + inst * 128 + tid - 192];
   float* kvw = kvs + (size_t)(b * G + g) * (NTILE * SAB_TILE_FLOATS);  // this workgroup's scratch (plain pointer: written, then read)
-  const float* gb = GB + (long long)b * gb_stride + inst * 128;
+  const float* gb = sGB;
 
   // ---- phase 1 -----------------------------------------------------------------------------------------------------------
   // one 32 x 32 tile of the 64 -> 192 product: nt = output channels 32 nt .. +31; exchanged = operands swapped (D[token][channel])
@@ -2083,7 +2109,7 @@ extern "C" int pmce_adaln_mlp_pk_f32(const float* xin, const float* GB, int gb_s
                                      const float* ffn_img, hipStream_t stream) {
   PMCE_REQUIRE(xin && GB && W1 && b1 && W2 && b2 && (yout || vt_out), "adaln_mlp: null pointer");
   PMCE_REQUIRE(!vt_out || (Wc && bc && vt_in), "adaln_mlp: coordinate head needs Wc, bc, vt_in");
-  const size_t lds = (size_t)(256 * LDW64 + 64 * LDW256 + 256 + 64 + 32) * sizeof(float);
+  const size_t lds = (size_t)(256 * LDW64 + 64 * LDW256 + 256 + 64 + 32 + 256) * sizeof(float);
   static std::atomic<unsigned long long> attr{0}, attr_s{0};
   if (split_f16) {
     PMCE_TRY(pmce_opt_in_lds((const void*)adaln_mlp_kernel<true, MLP_WAVES>, (int)lds, attr_s, "adaln_mlp"));
