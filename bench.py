@@ -275,8 +275,9 @@ def north_star_record(kernel_ms, launches, B, J, f16_ffn=False, C=512):
     # little overlaps them: `serial_floor_ms` = matrix + vector time is the realistic floor, max(...) the optimistic one.
     t_valu = None
     pmc, pmc_meta = _pmc_counters(C)
-    key = "void vertex_ca_mlp_kernel<true>" if f16_ffn else "void vertex_ca_mlp_kernel<false>"
-    if name == "vertex_ca_mlp" and pmc and key in pmc and pmc[key].get("SQ_INSTS_VALU") and pmc[key].get("SQ_WAVES"):
+    want = "vertex_ca_mlp_kernel<true" if f16_ffn else "vertex_ca_mlp_kernel<false"      # (template arguments after the first vary with the build)
+    key = next((k_ for k_ in pmc if want in k_), None) if pmc else None
+    if name == "vertex_ca_mlp" and key and pmc[key].get("SQ_INSTS_VALU") and pmc[key].get("SQ_WAVES"):
         per_clip = pmc[key]["SQ_INSTS_VALU"] / (pmc[key]["SQ_WAVES"] / 7.0)      # 7 waves per clip (14 wave tiles, 2 per wave)
         t_valu = per_clip * B * 4 / N_SIMD / (CLOCK_GHZ * 1e9) * 1e3
     floor = max(t_hbm, t_mfma, t_valu or 0.0)
@@ -290,6 +291,9 @@ def north_star_record(kernel_ms, launches, B, J, f16_ffn=False, C=512):
     if t_valu is not None:
         rec.update({"valu_floor_ms": round(t_valu, 5), "serial_floor_ms": round(t_mfma + t_valu, 5),
                     "frac_of_serial_floor": round((t_mfma + t_valu) / ms, 4),
+                    # the nominal 4 cycles per wave instruction; plain fp32 FMAs measure 2.4 (profiles/r05_a_f16_mfma_vs_valu_overlap.txt)
+                    "valu_floor_at_measured_issue_rate_ms": round(t_valu * 2.4 / 4.0, 5),
+                    "note": "f16 matrix instructions and fp32 vector FMAs do not overlap on gfx950 (same file): the serial floor is the realistic one",
                     "valu_source": f"{pmc_meta['file']} (SQ_INSTS_VALU per launch at B = 256, scaled per clip)",
                     "valu_counters_build_id": pmc_meta["build_id"], "library_build_id": pmc_meta["library_build_id"],
                     "stale": pmc_meta["stale"],
