@@ -303,6 +303,13 @@ int pmce_gru_step_f32(const float* gi0, const float* gi1, const float* whh0, con
 int pmce_gru_step_split_f32(const float* gi0, const float* gi1, const float* whh0p, const float* whh1p, const float* wscale,
                             const float* bhh0, const float* bhh1, const float* hp0, const float* hp1, float* ho0, float* ho1,
                             long long gi_rs, long long h_rs, int B, int H, int ndir, pmce_stream_t stream);
+/* The same on a W_hh packed by pmce_gemm_pack_split_f16_blk (the blocked layout: the 16 rows a DMA instruction fetches are 1 KB contiguous;
+ * whh0b / whh1b = the first row of each direction, a multiple of 64 rows apart): what the model runs.  B <= 64 runs a small-batch kernel (a
+ * workgroup per 8 hidden units: 256 workgroups whatever the batch), larger batches 64 rows x 32 units per workgroup - same numbers, bit for
+ * bit, in both layouts and at every batch size. */
+int pmce_gru_step_split_blk_f32(const float* gi0, const float* gi1, const float* whh0b, const float* whh1b, const float* wscale,
+                                const float* bhh0, const float* bhh1, const float* hp0, const float* hp1, float* ho0, float* ho1,
+                                long long gi_rs, long long h_rs, int B, int H, int ndir, pmce_stream_t stream);
 /* y = x / denom (PMCE.py:18). */
 int pmce_div_scalar_f32(const float* x, float* y, long long n, float denom, pmce_stream_t stream);
 

@@ -83,6 +83,7 @@ PROTOTYPES = {
     "pmce_lifter_head_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _s],
     "pmce_gru_step_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _l, _l, _i, _i, _i, _s],
     "pmce_gru_step_split_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _l, _l, _i, _i, _i, _s],
+    "pmce_gru_step_split_blk_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _l, _l, _i, _i, _i, _s],
     "pmce_div_scalar_f32": [_f, _f, _l, _fl, _s],
     "pmce_vertex_init_gather_f32": [_f, _f, _f, _i, _i, _s],
     "pmce_ca_image_floats": [],

@@ -64,3 +64,7 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+
+// gemm_split_small.hip: the small-grid form (one 64 x 128 tile per workgroup, eight waves, at most one round of workgroups)
+bool pmce_gemm_split_small_applies(int M, int N, int K, int act, bool apack, bool opack, bool res, bool rs);
+int pmce_gemm_split_small_launch(SplitParams& p, int act, bool apack, bool opack, hipStream_t stream);

@@ -664,6 +664,12 @@ static int gemm_split_any(const float* A, const float* Wp, const float* wscale, 
   p.oflow = pmce_overflow_sink();
   p.clk = pmce_clock_sink();  // (thread-local: set while an entry point of a model with a clock probe runs)
   const int tile = pick_split_tile(M, N);
+  // at most one round of 64 x 128 tiles: the small-grid kernel (gemm_split_small.hip: eight waves per tile, a deep ring, no tile stream)
+  if (tile == 2 && g_split_tile.load(std::memory_order_relaxed) < 0 &&
+      pmce_gemm_split_small_applies(M, N, K, act, a_packed != 0, c_packed != 0, R != nullptr, rscale != nullptr)) {
+    PMCE_TRY(pmce_gemm_split_small_launch(p, act, a_packed != 0, c_packed != 0, stream));
+    return pmce_check_launch("gemm_nt_split_f16 (small grid)");
+  }
   if (tile == 2 && g_split_tile.load(std::memory_order_relaxed) < 0 && K % 32 == 0 && K >= 128 &&
       (long long)((M + 63) / 64) * ((N + 127) / 128) <= 512 &&
       small_k32_form_exists(act, a_packed != 0, c_packed != 0, R != nullptr, rscale != nullptr)) {

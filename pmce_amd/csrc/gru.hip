@@ -28,6 +28,9 @@ struct GruStepArgs {
   long long gi_rs, h_rs;
   int B, H;
   const float* wscale;    // SPLIT form: [2 * 3H] 2^-s per row of the packed W_hh (direction-major, as packed: pmce_gemm_pack_split_f16)
+  int wblk;               // SPLIT form: the packed W_hh is in the BLOCKED layout [3H / 64][H / 16][64 rows][16 hi | 16 lo] (pmce_gemm_pack_split_f16_blk): a
+                          // DMA instruction's 16 rows of a k-tile are 1 KB contiguous (8 full cache lines) instead of 16 half lines one weight row apart -
+                          // with every CU streaming, the L2 -> LDS path delivers 58 instead of 30 B/clk per CU (scripts/microbench/dma_patterns.hip)
 };
 
 typedef _Float16 gru_f16x8 __attribute__((ext_vector_type(8)));
@@ -259,17 +262,19 @@ __global__ __launch_bounds__(512) void gru_step_v2_kernel(GruStepArgs a) {
     for (int i = 0; i < 3; ++i) {
       const int r2 = 48 * rb + 16 * i + (lane >> 2);  // gate = r2 >> 5, unit = r2 & 31
       const int c = (lane & 3) ^ ((r2 >> 2) & 3);
-      woff[i] = (unsigned)(((long long)((r2 >> 5) * H + u0 + (r2 & 31)) * H + 4 * c) * 4);
+      const int wr = (r2 >> 5) * H + u0 + (r2 & 31);  // row of this direction's [3H][H]
+      woff[i] = a.wblk ? (unsigned)(((long long)(wr >> 6) * (H / 16) * 1024 + (wr & 63) * 16 + 4 * c) * 4) : (unsigned)(((long long)wr * H + 4 * c) * 4);
     }
+    const int wks = a.wblk ? 4096 : 64;  // bytes from one k-tile of a W row (block) to the next
     const unsigned lds_q =
         __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)smem) + kq * (NS * STAGE);
     auto dma_stage = [&](int kt) {
-      const int soff = (kq * Kq + kt * 16) * 4;
+      const int soff = (kq * Kq + kt * 16) * 4, soff_w = (kq * (Kq / 16) + kt) * wks;
       const unsigned dst = lds_q + (kt % NS) * STAGE;
 #pragma unroll
       for (int i = 0; i < 2; ++i) gru_dma16(rsrc_h, hoff[i], soff, dst + (32 * rb + 16 * i) * 64);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) gru_dma16(rsrc_w, woff[i], soff, dst + (64 + 48 * rb + 16 * i) * 64);
+      for (int i = 0; i < 3; ++i) gru_dma16(rsrc_w, woff[i], soff_w, dst + (64 + 48 * rb + 16 * i) * 64);
     };
     const int nk = Kq / 16;
     const float* ring = smem + kq * (NS * STAGE / 4);
@@ -365,9 +370,164 @@ __global__ __launch_bounds__(512) void gru_step_v2_kernel(GruStepArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Round 5: the split-f16 step for SMALL batches (B <= 64: the decoder-only configuration at batch 64, streaming, single clips).  gru_step_v2
+// gives a workgroup 32 units x 64 rows: B <= 64 is 64 workgroups on 256 CUs, each pulling 0.65 MB through ONE CU's L2 port behind 80 KB of
+// requests in flight - 8 dependent round trips, 12-16 us per step whatever the batch.  Here a workgroup owns 8 units x {r, z, n} of one
+// direction - the 24 W_hh rows are ONE 32-column matrix operand [r 8 | z 8 | n 8 | -] - for ALL batch rows: 256 workgroups, one per CU, each
+// streaming 98 KB of W_hh + B x 4 KB of h.  Four waves = the four K-quarters of gru_step_v2, each with a PRIVATE ring (no barrier in the
+// loop) of 8 / 5 stages of [32 NT h rows | 32 W rows] x 64 B, all but one stage in flight (112 / 96 KB per CU).  The arithmetic per output
+// element is gru_step_v2's, operation for operation - the same k-tiles in the same order per K-quarter, the quarters met in the same order
+// (the quarter that owns accumulator row r = the one v2's wave kq finishes) - so the result is bit-identical to it
+// (test_gru_step_small_batch_equals_v2): a clip's numbers do not depend on the batch it rode in.
+// ------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void gru_step_small_kernel(GruStepArgs a) {
+  constexpr int NQ = 4;
+  constexpr int NS = NT == 1 ? 8 : 5;
+  constexpr int ROWS = 32 * NT + 32;           // rows of 64 B per stage: the h rows of NT batch tiles, then the 32 W rows
+  constexpr int STAGE = ROWS * 64;             // bytes
+  constexpr int NI = 2 * NT + 2;               // DMA instructions per stage
+  __shared__ __attribute__((aligned(16))) float smem[NQ * NS * STAGE / 4];   // 128 KB / 120 KB
+  const int d = blockIdx.z, u0 = blockIdx.x * 8;
+  const int tid = threadIdx.x, lane = tid & 63, kq = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = lane & 31, hb = lane >> 5;
+  const int H = a.H, Kq = H / NQ;
+  const float* __restrict__ hp = a.hprev[d];
+  const float* __restrict__ W = a.whh[d];
+  const float* __restrict__ gi = a.gi[d];
+
+  // the gate phase's operands, requested before the loop: thread t finishes (row 32 nt + t / 8, unit u0 + t % 8)
+  const int gm = tid >> 3, gu = u0 + (tid & 7);
+  float gir[NT], giz[NT], gin[NT], hpv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int m = min(32 * nt + gm, a.B - 1);
+    const float* g = gi + (long long)m * a.gi_rs + gu;
+    gir[nt] = g[0];
+    giz[nt] = g[H];
+    gin[nt] = g[2 * H];
+    hpv[nt] = hp ? hp[(long long)m * a.h_rs + gu] : 0.f;
+  }
+  const float* __restrict__ bh = a.bhh[d];
+  const float bhr = bh[gu], bhz = bh[H + gu], bhn = bh[2 * H + gu];
+  const float wd_r = a.wscale[d * 3 * H + gu], wd_z = a.wscale[d * 3 * H + H + gu], wd_n = a.wscale[d * 3 * H + 2 * H + gu];
+
+  float fin[NT][3];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) fin[nt][0] = fin[nt][1] = fin[nt][2] = 0.f;
+
+  if (hp) {
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hp), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 0xffffffff, 0x00020000);
+    // DMA instruction = 16 rows x 64 B (4 lanes per row); lane L lands at row + L / 4, PHYSICAL chunk L % 4, and fetches logical chunk
+    // (L % 4) ^ ((row >> 2) & 3) (conflict-free ds_read_b128 on unpadded rows), as in gru_step_v2.
+    unsigned hoff[2 * NT], woff[2];
+#pragma unroll
+    for (int i = 0; i < 2 * NT; ++i) {
+      const int row = 16 * i + (lane >> 2);
+      const int c = (lane & 3) ^ ((row >> 2) & 3);
+      const int m = min(row, a.B - 1);
+      hoff[i] = (unsigned)(((long long)m * a.h_rs + 4 * c) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int col = 16 * i + (lane >> 2);          // operand column: gate = col >> 3 (3 = unused: a copy of n), unit = col & 7
+      const int c = (lane & 3) ^ ((col >> 2) & 3);
+      const int wr = min(col >> 3, 2) * H + u0 + (col & 7);
+      woff[i] = a.wblk ? (unsigned)(((long long)(wr >> 6) * (H / 16) * 1024 + (wr & 63) * 16 + 4 * c) * 4) : (unsigned)(((long long)wr * H + 4 * c) * 4);
+    }
+    const int wks = a.wblk ? 4096 : 64;
+    const unsigned lds_q =
+        __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)smem) + kq * (NS * STAGE);
+    auto dma_stage = [&](int kt) {
+      const int soff = (kq * Kq + kt * 16) * 4, soff_w = (kq * (Kq / 16) + kt) * wks;
+      const unsigned dst = lds_q + (kt % NS) * STAGE;
+#pragma unroll
+      for (int i = 0; i < 2 * NT; ++i) gru_dma16(rsrc_h, hoff[i], soff, dst + 16 * i * 64);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) gru_dma16(rsrc_w, woff[i], soff_w, dst + (32 * NT + 16 * i) * 64);
+    };
+    const int nk = Kq / 16;
+    const float* ring = smem + kq * (NS * STAGE / 4);
+    const int swz = (n0 >> 2) & 3;
+    for (int kt = 0; kt < NS - 1 && kt < nk; ++kt) dma_stage(kt);
+    for (int kt = 0; kt < nk; ++kt) {
+      // tile kt has landed when at most the NS - 2 tiles issued after it are in flight (in-order completion); the tail waits for all
+      if (kt + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (kt + NS - 1 < nk) dma_stage(kt + NS - 1);  // into the stage tile kt - 1 occupied (its fragment reads were issued an iteration ago)
+      const float* st = ring + (kt % NS) * (STAGE / 4);
+      const float* Bs = st + (32 * NT + n0) * 16;
+      const gru_f16x8 whi = *reinterpret_cast<const gru_f16x8*>(Bs + 4 * (hb ^ swz));        // hi plane, k = 8 hb + [0, 8)
+      const gru_f16x8 wlo = *reinterpret_cast<const gru_f16x8*>(Bs + 4 * ((2 + hb) ^ swz));  // lo plane
+      const gru_f16x8 wh2 = whi * (_Float16)0.00048828125f;
+      gru_f16x8 ahi[NT], alo[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float* As = st + (32 * nt + n0) * 16;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(As + 4 * ((2 * hb) ^ swz));
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(As + 4 * ((2 * hb + 1) ^ swz));
+        const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ahi[nt][e] = (_Float16)xv[e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) alo[nt][e] = (_Float16)((xv[e] - (float)ahi[nt][e]) * 2048.0f);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[nt], whi, acc[nt], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[nt], wlo, acc[nt], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[nt], wh2, acc[nt], 0, 0, 0);
+    }
+    __syncthreads();  // every wave is done with its ring: the exchange below reuses the memory
+    float* red = smem;  // [kq][nt][r][lane]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((kq * NT + nt) * 16 + r) * 64 + lane] = acc[nt][r];
+    __syncthreads();
+    // row gm of a batch tile is accumulator register r = (gm & 3) + 4 ((gm >> 3) & 3) of the lanes hb = (gm >> 2) & 1; gru_step_v2's wave
+    // kq = r / 4 finishes it as  own + ((0 + other_0) + other_1) + other_2  with the other quarters in ascending order.
+    const int r = (gm & 3) + 4 * ((gm >> 3) & 3), own = (gm >> 3) & 3, lhb = 32 * ((gm >> 2) & 1);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const int ln = 8 * g + (tid & 7) + lhb;
+        float sum = 0.f, mine = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const float v = red[((q * NT + nt) * 16 + r) * 64 + ln];
+          if (q == own) mine = v;
+          else sum += v;
+        }
+        fin[nt][g] = mine + sum;
+      }
+  }
+  float* __restrict__ ho = a.hout[d];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int m = 32 * nt + gm;
+    if (m < a.B) {
+      const float ar = fin[nt][0] * wd_r, az = fin[nt][1] * wd_z, an = fin[nt][2] * wd_n;
+      const float rr = sigmoidf_acc(gir[nt] + (ar + bhr));
+      const float zz = sigmoidf_acc(giz[nt] + (az + bhz));
+      const float nn = tanhf(gin[nt] + rr * (an + bhn));
+      ho[(long long)m * a.h_rs + gu] = (1.0f - zz) * nn + zz * hpv[nt];
+    }
+  }
+}
+
 static int gru_step_any(const float* gi0, const float* gi1, const float* whh0, const float* whh1, const float* wscale,
                         const float* bhh0, const float* bhh1, const float* hp0, const float* hp1, float* ho0, float* ho1,
-                        long long gi_rs, long long h_rs, int B, int H, int ndir, hipStream_t stream) {
+                        long long gi_rs, long long h_rs, int B, int H, int ndir, hipStream_t stream, int wblk = 0) {
   PMCE_REQUIRE(ndir == 1 || ndir == 2, "gru_step: ndir must be 1 or 2");
   PMCE_REQUIRE(gi0 && whh0 && bhh0 && ho0 && B > 0, "gru_step: null pointer");
   PMCE_REQUIRE(ndir == 1 || (gi1 && whh1 && bhh1 && ho1), "gru_step: second direction pointers missing");
@@ -375,9 +535,13 @@ static int gru_step_any(const float* gi0, const float* gi1, const float* whh0, c
   GruStepArgs a;
   a.gi[0] = gi0; a.gi[1] = gi1; a.whh[0] = whh0; a.whh[1] = whh1; a.bhh[0] = bhh0; a.bhh[1] = bhh1;
   a.hprev[0] = hp0; a.hprev[1] = hp1; a.hout[0] = ho0; a.hout[1] = ho1;
-  a.gi_rs = gi_rs; a.h_rs = h_rs; a.B = B; a.H = H; a.wscale = wscale;
+  a.gi_rs = gi_rs; a.h_rs = h_rs; a.B = B; a.H = H; a.wscale = wscale; a.wblk = wblk;
   PMCE_REQUIRE((long long)B * h_rs * 4 < (1ll << 32) && 3ll * H * H * 4 < (1ll << 32), "gru_step: h or W_hh spans 4 GiB or more");
-  if (wscale)
+  if (wscale && B <= 32)
+    hipLaunchKernelGGL(gru_step_small_kernel<1>, dim3(H / 8, 1, ndir), dim3(256), 0, stream, a);
+  else if (wscale && B <= 64)
+    hipLaunchKernelGGL(gru_step_small_kernel<2>, dim3(H / 8, 1, ndir), dim3(256), 0, stream, a);
+  else if (wscale)
     hipLaunchKernelGGL(gru_step_v2_kernel, dim3(H / 32, (B + 63) / 64, ndir), dim3(512), 0, stream, a);
   else
     hipLaunchKernelGGL(gru_step_kernel, dim3(H / 32, (B + 63) / 64, ndir), dim3(512), 0, stream, a);
@@ -396,6 +560,17 @@ extern "C" int pmce_gru_step_split_f32(const float* gi0, const float* gi1, const
                                        int ndir, hipStream_t stream) {
   PMCE_REQUIRE(wscale, "gru_step_split: null wscale");
   return gru_step_any(gi0, gi1, whh0p, whh1p, wscale, bhh0, bhh1, hp0, hp1, ho0, ho1, gi_rs, h_rs, B, H, ndir, stream);
+}
+
+// The same on a W_hh packed by pmce_gemm_pack_split_f16_blk (both directions' rows in ONE call, N = 6H, or one direction's 3H: a direction
+// starts on a 64-row block either way): what the model runs - a DMA instruction's rows are contiguous.  Same numbers, bit for bit.
+extern "C" int pmce_gru_step_split_blk_f32(const float* gi0, const float* gi1, const float* whh0b, const float* whh1b,
+                                           const float* wscale, const float* bhh0, const float* bhh1, const float* hp0,
+                                           const float* hp1, float* ho0, float* ho1, long long gi_rs, long long h_rs, int B, int H,
+                                           int ndir, hipStream_t stream) {
+  PMCE_REQUIRE(wscale, "gru_step_split_blk: null wscale");
+  PMCE_REQUIRE(H % 64 == 0, "gru_step_split_blk: H must be a multiple of 64");
+  return gru_step_any(gi0, gi1, whh0b, whh1b, wscale, bhh0, bhh1, hp0, hp1, ho0, ho1, gi_rs, h_rs, B, H, ndir, stream, 1);
 }
 
 // joints(m) = pose3d(mm) / 1000   (reference PMCE.py:18 — a true division, kept as one)

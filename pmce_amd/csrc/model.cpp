@@ -527,7 +527,7 @@ int gru_layer(pmce_model* m, int layer, const float* gi_f, const float* gi_b, lo
   auto step = [&](const float* gi0, const float* gi1, const float* w0, const float* w1, const float* b0, const float* b1,
                   const float* hp0, const float* hp1, float* ho0, float* ho1, int ndir) {
     const float* scale = split ? sw.scale + (w0 == whh ? 0 : 3 * GH) : nullptr;
-    return split ? pmce_gru_step_split_f32(gi0, gi1, w0, w1, scale, b0, b1, hp0, hp1, ho0, ho1, gi_rs, 2 * GH, B, GH, ndir, stream)
+    return split ? pmce_gru_step_split_blk_f32(gi0, gi1, w0, w1, scale, b0, b1, hp0, hp1, ho0, ho1, gi_rs, 2 * GH, B, GH, ndir, stream)
                  : pmce_gru_step_f32(gi0, gi1, w0, w1, b0, b1, hp0, hp1, ho0, ho1, gi_rs, 2 * GH, B, GH, ndir, stream);
   };
   const long long YS = (long long)B * 2 * GH;
@@ -824,10 +824,8 @@ int build_split_weights(pmce_model* m, hipStream_t stream) {
     float* wp = p;
     float* sc = p + ((((size_t)it.n + 63) & ~(size_t)63) * it.k);
     p = wp + split_item_floats(it.n, it.k);
-    // the products' weights in the blocked layout (a tile's k-slice contiguous); the recurrent weights row-major (gru_step's addressing)
-    const bool recurrent = it.dst == &m->s_whh0 || it.dst == &m->s_whh1;
-    if (!recurrent) PMCE_TRY(pmce_gemm_pack_split_f16_blk(it.w, it.n, it.k, it.k, wp, sc, stream));
-    else PMCE_TRY(pmce_gemm_pack_split_f16(it.w, it.n, it.k, it.k, wp, sc, stream));
+    // every weight in the blocked layout (what a tile - or a GRU step's workgroup - fetches per k-tile is contiguous)
+    PMCE_TRY(pmce_gemm_pack_split_f16_blk(it.w, it.n, it.k, it.k, wp, sc, stream));
     it.dst->wp = wp;
     it.dst->scale = sc;
   }

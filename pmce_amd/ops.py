@@ -131,6 +131,24 @@ def gemm_nt_split_rs(Ap, rscale, Wp, wscale, bias=None, out=None, rowmap=None):
     return out
 
 
+def gru_step_split(gi, whh, bhh, h_prev, blocked=True):
+    """One GRU time step of ONE direction in the three-product f16 form (nn.GRU gate order r, z, n; CoevoDecoder.py:216-221): gi [B, 3H] =
+    W_ih x + b_ih, whh [3H, H], bhh [3H], h_prev [B, H] or None (h = 0) -> h' [B, H].  B <= 64 runs the small-batch kernel, larger batches
+    gru_step_v2 - same numbers, bit for bit."""
+    lib = _lib.load()
+    gi, whh, bhh = _c(gi), _c(whh), _c(bhh)
+    B, H = gi.shape[0], whh.shape[1]
+    if blocked:     # the layout the model packs W_hh in
+        Wp, wscale, _ = pack_split_f16_blk(whh)
+    else:
+        Wp, wscale = pack_split_f16(whh)
+    hp = None if h_prev is None else _c(h_prev)
+    out = torch.empty(B, H, device=gi.device, dtype=torch.float32)
+    _lib.check((lib.pmce_gru_step_split_blk_f32 if blocked else lib.pmce_gru_step_split_f32)(P(gi), None, P(Wp), None, P(wscale), P(bhh), None, P(hp), None, P(out), None, 3 * H, H, B, H, 1,
+                                           _st()), "gru_step_split")
+    return out
+
+
 def ln_chain(x, w1=None, b1=None, eps1=1e-6, add=None, add_div=1, add_mod=1, want_out1=True, w2=None, b2=None, eps2=1e-6,
              out2_split=False):
     lib = _lib.load()

@@ -24,7 +24,10 @@ def timeit(fn, reps=20):
 
 shapes = [("gi1 B=256", 2304, 3072, 2048), ("gi1 B=64", 576, 3072, 2048), ("ada B=256", 256, 3072, 2048), ("final B=256", 256, 20670, 3360),
           ("final B=64", 64, 20670, 3360), ("ie B=256 (fp32 A)", 4096, 512, 2048), ("qkv B=1", 272, 1536, 512), ("qkv B=8", 2176, 1536, 512),
-          ("fc2 B=8", 2176, 512, 1024)]
+          ("fc2 B=8", 2176, 512, 1024), ("proj B=1", 272, 512, 512), ("fc1 B=1", 272, 2048, 512), ("K=1024 B=1", 272, 512, 1024), ("fc2 B=1", 272, 512, 2048),
+          ("K=4096 B=1", 272, 512, 4096)]
+if len(sys.argv) > 1:   # only the shapes whose name contains the argument, e.g. "B=1"
+    shapes = [s for s in shapes if sys.argv[1] in s[0]]
 for name, M, N, K in shapes:
     g = torch.Generator().manual_seed(3)
     A = torch.randn(M, K, generator=g).to(dev)

@@ -122,6 +122,53 @@ def test_gemm_nt_split(M, N, K, act, res, tile):
     assert e < 2e-5 and e <= 1.5 * e32 + 1e-7
 
 
+@pytest.mark.parametrize("M,N,K", [(272, 1536, 512), (272, 512, 2048), (1, 3072, 2048), (3, 20670, 3360), (16, 6144, 2048), (300, 160, 128),
+                                   (1088, 768, 256), (64, 128, 64), (65, 129, 96)])
+def test_gemm_split_small_grid_equals_persistent(M, N, K):
+    """Round 5: the small-grid kernel (one 64 x 128 tile per workgroup, eight waves; what every product of a single-clip forward runs) against the
+    persistent kernel forced to the same tile shape: every operand / epilogue form the model uses, bit for bit."""
+    from pmce_amd import _lib, ops
+    lib = _lib.load()
+    A = rnd("gemm.A", (M, K)).to(dev())
+    A[::5] *= 1e-3
+    W = rnd("gemm.W", (N, K), scale=K ** -0.5).to(dev())
+    b = rnd("gemm.b", (N,)).to(dev())
+    R = rnd("gemm.R", (M, N)).to(dev())
+    Wb, ws, _ = ops.pack_split_f16_blk(W)
+    Wp, ws2 = ops.pack_split_f16(W)
+    Ap = ops.split_rows_f16(A)
+    Ars, rs = ops.split_rows_scaled_f16(A * 1e4)
+
+    def forms():
+        out = {"fp32 A": ops.gemm_nt_split_blk(A, Wb, ws, N, b),
+               "fp32 A, row-major W, no bias": ops.gemm_nt_split(A, Wp, ws2),
+               "packed A": ops.gemm_nt_split_blk(Ap, Wb, ws, N, b, a_packed=True),
+               "packed A + residual": ops.gemm_nt_split_blk(Ap, Wb, ws, N, b, R, a_packed=True),
+               }
+        if K >= 128:      # (the row-scaled form's own requirement)
+            out["row-scaled A"] = ops.gemm_nt_split_blk(Ars, Wb, ws, N, b, rscale=rs)
+            out["row-scaled A, row-major W"] = ops.gemm_nt_split_rs(Ars, rs, Wp, ws2, b)
+        if N % 32 == 0:
+            out["packed A, GELU, packed result"] = ops.gemm_nt_split_blk(Ap, Wb, ws, N, b, None, 1, a_packed=True, c_packed=True)
+        if M % 16 == 0 and K >= 128:   # mapped output rows ((b, t) rows written time-major, as the GRU layer-0 projection does)
+            out["row-scaled A, mapped rows"] = ops.gemm_nt_split_blk(Ars, Wb, ws, N, b, rscale=rs, rowmap=(16, (M // 16) * N, N))
+        return out
+
+    small = forms()
+    lib.pmce_gemm_split_set_tuning(2)
+    try:
+        persistent = forms()
+    finally:
+        lib.pmce_gemm_split_set_tuning(-1)
+    for k in small:
+        nd = int((small[k].view(torch.int32) != persistent[k].view(torch.int32)).sum())
+        assert nd == 0, f"{M}x{N}x{K} {k}: {nd} of {small[k].numel()} elements differ from the persistent kernel"
+    ref = A.double() @ W.double().t() + b.double()
+    e = float((small["packed A"].double() - ref).abs().max())
+    print(f"small-grid split gemm {M}x{N}x{K}: {len(small)} forms bit-identical to the persistent kernel; max-abs vs fp64 {e:.2e}")
+    assert e < 2e-5
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(4352, 512, 256), (1000, 1024, 512), (69650, 1024, 512), (300, 160, 128)])
 def test_gemm_split_packed_result(M, N, K, tile):
@@ -606,6 +653,38 @@ def test_gru_all_steps_fixture(golden):
     e_8 = maxabs(y1[8], T(golden("modules_J17_C256.npz")["gru_y8"]))
     print(f"GRU layer-1 steps vs reference: forward t<=8 {e_f:.2e}, backward t>=8 {e_b:.2e}, y[8] (both clips) {e_8:.2e}")
     assert e_f < 5e-5 and e_b < 5e-5 and e_8 < 5e-5
+
+
+def test_gru_step_small_batch_equals_v2():
+    """The small-batch GRU step (B <= 32: one batch tile per wave, B <= 64: two) against gru_step_v2 (B > 64) on the same rows: bit-identical -
+    a clip's hidden state does not depend on the batch it rode in - and both against the fp64 step (nn.GRU's formulas)."""
+    from pmce_amd import ops
+    g = torch.Generator().manual_seed(77)
+    H = 1024
+    gi = torch.randn(64, 3 * H, generator=g)
+    whh = torch.randn(3 * H, H, generator=g) * H ** -0.5
+    whh[5] *= 300.0                                   # rows of different magnitude: per-row scales
+    bhh = torch.randn(3 * H, generator=g) * 0.1
+    h = torch.tanh(torch.randn(64, H, generator=g))
+    ref_gh = h.double() @ whh.double().T + bhh.double()
+    r = torch.sigmoid(gi[:, :H].double() + ref_gh[:, :H]); z = torch.sigmoid(gi[:, H:2 * H].double() + ref_gh[:, H:2 * H])
+    n = torch.tanh(gi[:, 2 * H:].double() + r * ref_gh[:, 2 * H:])
+    ref = ((1 - z) * n + z * h.double())
+    d = dev()
+    big = ops.gru_step_split(torch.cat([gi, gi]).to(d), whh.to(d), bhh.to(d), torch.cat([h, h]).to(d)).cpu()       # B = 128: gru_step_v2
+    assert torch.equal(big[:64], big[64:])
+    big_rm = ops.gru_step_split(torch.cat([gi, gi]).to(d), whh.to(d), bhh.to(d), torch.cat([h, h]).to(d), blocked=False).cpu()
+    assert torch.equal(big, big_rm), "blocked and row-major W_hh give different numbers"
+    for B in (64, 33, 32, 7, 1):
+        for blocked in (True, False):
+            out = ops.gru_step_split(gi[:B].to(d), whh.to(d), bhh.to(d), h[:B].to(d), blocked=blocked).cpu()
+            assert torch.equal(out, big[:B]), f"B = {B}, blocked = {blocked}: small-batch step differs from gru_step_v2 by {maxabs(out, big[:B]):.2e}"
+    e = (big[:64].double() - ref).abs().max().item()
+    first_big = ops.gru_step_split(torch.cat([gi, gi]).to(d), whh.to(d), bhh.to(d), None).cpu()
+    first = ops.gru_step_split(gi[:5].to(d), whh.to(d), bhh.to(d), None).cpu()
+    assert torch.equal(first, first_big[:5])
+    print(f"GRU step (three-product f16 form) vs fp64: {e:.2e}; B = 64 / 33 / 32 / 7 / 1 and the first step bit-identical to the large-batch kernel")
+    assert e < 5e-6
 
 
 def test_lifter_block_fixture(golden):
