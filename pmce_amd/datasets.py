@@ -13,8 +13,13 @@ the annotation file is plain COCO-style JSON.
 What is NOT here: the SMPL layer that turns ``smpl_param`` into ground-truth meshes (``PW3D.get_smpl_coord``; SMPL model files are
 out of scope) - ground-truth joints come from ``3DPW_<split>_joint_h36m_cam.json`` as the reference's ``reg_pose3d`` target
 (dataset.py:229-230,249), and a ground-truth mesh table can be supplied as ``<data_path>/3DPW_<split>_gt_mesh_cam.npy`` ([N, 6890, 3]
-float32 mm, root-relative, in the table's frame order) by whoever holds the SMPL files.  The Human3.6M loader
-(data/Human36M/dataset.py:194-350: per-subject annotation / camera / SMPL-fit files, bounding-box processing) is not restated.
+float32 mm, root-relative, in the table's frame order) by whoever holds the SMPL files.
+
+``load_h36m`` does the same for ``data/Human36M/dataset.py:105-130,194-350`` (``Human36M.load_data`` + ``load_pose2d_det``; test split,
+the 'human36' input joint set of config/test_mesh_h36m.yml): per-subject annotation / camera / world-joint / SMPL-fit files, the joblib
+feature database walked with each video's start index, the CPN detections, every second frame, the reference's drops (one sequence by name,
+empty bounding boxes), world -> camera -> pixel projection of the annotated joints.  The 'coco' joint set of the training configs (NeuralAnnot
+COCO joints + noise files) is not restated.
 """
 from __future__ import annotations
 
@@ -45,16 +50,21 @@ class FrameTable:
     gt_joints_img_coco: np.ndarray   # float32 [N, 17|19, 2|3]
     smpl: dict = field(default_factory=dict)     # 'pose' [N,72], 'shape' [N,10], 'trans' [N,3], 'gender' str [N]
     gt_mesh_cam: np.ndarray = None   # optional float32 [N, 6890, 3] mm, root-relative (see the module docstring)
-    skipped: int = 0                 # annotations without a feature entry (dataset.py:148-151)
+    skipped: int = 0                 # annotations without a feature entry (dataset.py:148-151) / dropped by the Human3.6M rules
+    joints_name: tuple = None        # names of the keypoints' joints (default: COCO-17) and how many joints the model input appends to them
+    extra_joints: int = 2            # (2: pelvis + neck, the COCO-19 input; 0: the Human3.6M 17-joint input)
+    mid_valid: np.ndarray = None     # bool [N]: the frame has an SMPL fit - a window whose middle frame has none is dropped (lib/_img_utils.py:75)
+    cam_idxs: np.ndarray = None      # int [N]: Human3.6M camera of the frame (the evaluation keeps camera 4, Human36M/dataset.py:742-744)
+    extras: dict = field(default_factory=dict)   # whatever else the reference's load_data returns (bboxs, joint_imgs, camera parameters)
 
     def __len__(self):
         return len(self.img_paths)
 
     def windows(self, seqlen: int = 16, stride: int = 1) -> np.ndarray:
-        """``self.vid_indices`` of the reference dataset (dataset.py:62): every 3DPW frame carries a full SMPL pose, so no window is
-        dropped for an invalid middle frame."""
+        """``self.vid_indices`` of the reference dataset (PW3D/dataset.py:62, Human36M/dataset.py:98-101): every 3DPW frame carries a full
+        SMPL pose; a Human3.6M window whose middle frame has no SMPL fit is dropped."""
         from .staging import mesh_window_table
-        return mesh_window_table(list(self.img_paths), seqlen, stride, None)
+        return mesh_window_table(list(self.img_paths), seqlen, stride, self.mid_valid)
 
     def sequence_ids(self) -> np.ndarray:
         """int id of every frame's video (first appearance order): the grouping key of the acceleration error."""
@@ -64,10 +74,11 @@ class FrameTable:
         return rank[inv]
 
     def pose2d(self, device):
-        """[N, 19, 2] model input coordinates on `device`: pelvis / neck appended, ``X / w * 2 - [1, h / w]`` (one kernel)."""
+        """[N, J, 2] model input coordinates on `device`: pelvis / neck appended for the COCO-19 input, ``X / w * 2 - [1, h / w]`` (one kernel)."""
         import torch
         from .staging import prepare_pose2d
-        return prepare_pose2d(torch.from_numpy(self.keypoints).to(device), torch.from_numpy(self.img_shapes).to(device), COCO_JOINTS, 2)
+        return prepare_pose2d(torch.from_numpy(np.ascontiguousarray(self.keypoints)).to(device), torch.from_numpy(self.img_shapes).to(device),
+                              self.joints_name or COCO_JOINTS, self.extra_joints)
 
     def features_on(self, device):
         import torch
@@ -117,6 +128,114 @@ def load_pw3d(data_path: str, split: str = "test") -> FrameTable:
             raise ValueError(f"{mesh_file}: expected shape {(len(table), 6890, 3)} (the table's frame order), got {m.shape}")
         table.gt_mesh_cam = m
     return table
+
+
+H36M_JOINTS = ('Pelvis', 'R_Hip', 'R_Knee', 'R_Ankle', 'L_Hip', 'L_Knee', 'L_Ankle', 'Torso', 'Neck', 'Nose', 'Head',
+               'L_Shoulder', 'L_Elbow', 'L_Wrist', 'R_Shoulder', 'R_Elbow', 'R_Wrist')
+H36M_TEST_SUBJECTS = {1: (11,), 2: (9, 11)}          # protocol -> subjects (Human36M/dataset.py:184-188)
+H36M_DROPPED_SEQUENCE = "s_11_act_02_subact_02_ca_0"  # (dataset.py:255-256)
+
+
+def _sanitized_bbox(bbox, aspect_ratio):
+    """``process_bbox`` (lib/coord_utils.py:66-90): None for an empty box, else the aspect-ratio preserving box (float64, as there)."""
+    x, y, w, h = bbox
+    x1, y1, x2, y2 = x, y, x + (w - 1), y + (h - 1)
+    if not (w * h > 0 and x2 >= x1 and y2 >= y1):
+        return None
+    b = np.array([x1, y1, x2 - x1, y2 - y1])
+    w, h = b[2], b[3]
+    cx, cy = b[0] + w / 2., b[1] + h / 2.
+    if w > aspect_ratio * h:
+        h = w / aspect_ratio
+    elif w < aspect_ratio * h:
+        w = h * aspect_ratio
+    b[2], b[3] = w, h
+    b[0], b[1] = cx - b[2] / 2., cy - b[3] / 2.
+    return b
+
+
+def load_h36m(data_path: str, split: str = "test", protocol: int = 2, sampling_ratio: int = 2, aspect_ratio: float = 288 / 384) -> FrameTable:
+    """Parse what ``Human36M('test')`` reads with ``input_joint_set = 'human36'`` (Human36M/dataset.py:105-130,194-350) into per-frame tables
+    in the reference's frame order (annotation order of subject 9's file, then subject 11's).  ``aspect_ratio`` = cfg.MODEL.input_shape[1] /
+    input_shape[0] (core/config.py:63; it only shapes the stored boxes - an EMPTY box drops the frame whatever the ratio)."""
+    import joblib
+    if split != "test":
+        raise ValueError("load_h36m restates the test split (detections from Human36M_test_cpn_joint_2d.json)")
+    annot = osp.join(data_path, "annotations")
+    subjects = H36M_TEST_SUBJECTS[protocol]
+    need = [osp.join(data_path, f"h36m_{split}_imgfeat_db_concat.pt"), osp.join(data_path, f"Human36M_{split}_start_idx_tight.json"),
+            osp.join(data_path, f"Human36M_{split}_cpn_joint_2d.json")]
+    need += [osp.join(annot, f"Human36M_subject{s}_{kind}.json") for s in subjects for kind in ("data", "camera", "joint_3d", "SMPL_NeuralAnnot")]
+    missing = [p for p in need if not osp.exists(p)]
+    if missing:
+        raise FileNotFoundError("Human3.6M files missing under %s: %s" % (data_path, ", ".join(osp.basename(p) for p in missing)))
+    load = lambda p: json.load(open(p))
+    img_db = joblib.load(need[0])
+    feat_names = np.asarray(img_db["img_name"])
+    perm = np.argsort(feat_names)
+    img_feats, feat_names = np.asarray(img_db["features"])[perm], feat_names[perm]
+    start_idx = load(need[1])
+    images, anns, cameras, joints, smpl = {}, [], {}, {}, {}
+    for s in subjects:                                              # (the reference concatenates the subjects' lists in this order)
+        d = load(osp.join(annot, f"Human36M_subject{s}_data.json"))
+        images.update({im["id"]: im for im in d["images"]})
+        anns += d["annotations"]
+        cameras[str(s)] = load(osp.join(annot, f"Human36M_subject{s}_camera.json"))
+        joints[str(s)] = load(osp.join(annot, f"Human36M_subject{s}_joint_3d.json"))
+        smpl[str(s)] = load(osp.join(annot, f"Human36M_subject{s}_SMPL_NeuralAnnot.json"))
+    rows, skipped = [], 0
+    feat_cnt = -sampling_ratio
+    for ann in {a["id"]: a for a in anns}.values():                 # pycocotools: a dict of annotation id, in file order
+        img = images[ann["image_id"]]
+        name = img["file_name"].split("/")[-1]
+        frame = img["frame_idx"]
+        if frame % sampling_ratio != 0:
+            continue
+        feat_cnt += sampling_ratio
+        if name[:-12] == H36M_DROPPED_SEQUENCE:
+            skipped += 1
+            continue
+        s, a, sa, c = str(img["subject"]), str(img["action_idx"]), str(img["subaction_idx"]), str(img["cam_idx"])
+        cam = cameras[s][c]
+        R, t, f, cc = (np.array(cam[k], dtype=np.float32) for k in ("R", "t", "f", "c"))
+        fit = smpl[s].get(a, {}).get(sa, {}).get(str(frame))
+        bbox = _sanitized_bbox(np.array(ann["bbox"], dtype=np.float32), aspect_ratio)
+        if bbox is None:
+            skipped += 1
+            continue
+        world = np.array(joints[s][a][sa][str(frame)], dtype=np.float32)
+        jcam = np.dot(R, world.transpose(1, 0)).transpose(1, 0) + t.reshape(1, 3)                       # world2cam (coord_utils.py:136-138)
+        jimg = np.concatenate(((jcam[:, 0] / jcam[:, 2] * f[0] + cc[0])[:, None], (jcam[:, 1] / jcam[:, 2] * f[1] + cc[1])[:, None],
+                               jcam[:, 2][:, None]), 1)                                                 # cam2pixel (:128-133)
+        if frame == 0:
+            feat_cnt = start_idx[s][a][sa][c]
+        if feat_names[feat_cnt].split("/")[-1] != name:
+            raise ValueError(f"feature database out of step with the annotations: entry {feat_cnt} is {feat_names[feat_cnt]}, the frame is {name}")
+        rows.append((name, (img["height"], img["width"]), np.asarray(img_feats[feat_cnt], dtype=np.float32), jcam.astype(np.float32),
+                     jimg.astype(np.float32), bbox.astype(np.float32), img["cam_idx"], fit, f, cc, R, t))
+    names = np.array([r[0] for r in rows])
+    # the CPN detections: sorted by name, every sampling_ratio-th image index kept (dataset.py:110-130); the reference indexes them with the
+    # dataset index and asserts the names - here they are matched by name, which is the same thing on consistent files and says so on others
+    det = load(need[2])
+    det = {k.split("/")[-1]: v for k, v in det.items() if (int(k[-10:-4]) - 1) % sampling_ratio == 0}
+    absent = [n for n in names if n not in det]
+    if absent:
+        raise ValueError(f"{len(absent)} frames have no CPN detection (first: {absent[0]})")
+    if list(np.sort(np.array(list(det)))) != list(names):
+        raise ValueError("the detection file and the annotations do not list the same frames in the same (sorted) order - the reference's "
+                         "index-aligned detection table would be out of step (its own assert, dataset.py:559-560)")
+    keypoints = np.stack([np.asarray(det[n], dtype=np.float32) for n in names])
+    col = lambda i, dt=np.float32: np.asarray([r[i] for r in rows], dtype=dt)
+    valid = np.array([r[7] is not None for r in rows])
+    z72, z10, z3 = [0.0] * 72, [0.0] * 10, [0.0] * 3
+    return FrameTable(
+        name=f"Human3.6M {split} (protocol {protocol})", img_paths=names, vid_names=np.array([n[:-11] for n in names]), img_shapes=col(1, np.int32),
+        keypoints=keypoints, features=col(2), joints_cam_h36m=col(3), joints_cam_coco=np.zeros((len(rows), 0, 3), np.float32),
+        gt_joints_img_coco=col(4),
+        smpl={"pose": np.asarray([r[7]["pose"] if r[7] else z72 for r in rows], np.float32), "shape": np.asarray([r[7]["shape"] if r[7] else z10 for r in rows], np.float32),
+              "trans": np.asarray([r[7]["trans"] if r[7] else z3 for r in rows], np.float32), "gender": np.array(["neutral"] * len(rows))},
+        skipped=skipped, joints_name=H36M_JOINTS, extra_joints=0, mid_valid=valid, cam_idxs=col(6, np.int64),
+        extras={"bboxs": col(5), "cam_focals": col(8), "cam_princpts": col(9), "cam_Rs": col(10), "cam_ts": col(11)})
 
 
 def window_frames(win: np.ndarray, seqlen: int = 16) -> np.ndarray:

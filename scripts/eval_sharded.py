@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Clip-sharded evaluation harness (BASELINE configs[3]/[4]).  Default: synthetic stand-ins (no datasets are available offline);
 with --data-dir the reference's own 3DPW files (data/PW3D/dataset.py:90-128: annotation, ViTPose detections, image features, joint
-files), read by pmce_amd/datasets.py into per-frame tables that are uploaded ONCE and windowed on the device.
+files) or, with --dataset h36m, its Human3.6M files (data/Human36M/dataset.py:194-269), read by pmce_amd/datasets.py into per-frame tables
+that are uploaded ONCE and windowed on the device.
 
     python scripts/eval_sharded.py --clips 4096 --joints 19                    # 1 GPU, synthetic
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 scripts/eval_sharded.py --clips 35515
     python scripts/eval_sharded.py --data-dir /data/PW3D/pw3d_data [--checkpoint mesh_3dpw.pth.tar]   # real files
+    python scripts/eval_sharded.py --dataset h36m --data-dir /data/Human36M/h36m_data [--checkpoint mesh_h36m.pth.tar]
 
 Every rank owns a contiguous block of the clip range (weights replicated), runs the HIP forward in batches, computes the
 per-sample metrics on the device (pmce_amd.eval) against a synthetic ground truth, and the ranks meet in ONE reduction
@@ -43,6 +45,8 @@ def main():
     ap.add_argument("--seq-len", type=int, default=500, help="clips per synthetic sequence (for the acceleration error)")
     ap.add_argument("--data-dir", default=None, help="directory holding the reference's 3DPW files (3DPW_latest_<split>.json, ...): "
                                                      "evaluate the real stride-1 window list instead of the synthetic stand-in")
+    ap.add_argument("--dataset", default="pw3d", choices=("pw3d", "h36m"), help="format of --data-dir: the reference's 3DPW files (J = 19) or its "
+                                                                              "Human3.6M files (J = 17; the windows of camera 4, as Human36M.evaluate keeps them)")
     ap.add_argument("--split", default="test")
     ap.add_argument("--checkpoint", default=None, help="a reference mesh_*.pth.tar (default: deterministic synthetic weights)")
     args = ap.parse_args()
@@ -51,9 +55,12 @@ def main():
     table = win = None
     if args.data_dir:
         from pmce_amd import datasets
-        table = datasets.load_pw3d(args.data_dir, args.split)          # every rank parses the (host-side) files; the GPU work is sharded
+        # every rank parses the (host-side) files; the GPU work is sharded
+        table = datasets.load_pw3d(args.data_dir, args.split) if args.dataset == "pw3d" else datasets.load_h36m(args.data_dir, args.split)
         win = table.windows(16, 1)
-        args.clips, args.joints = len(win), 19
+        if args.dataset == "h36m":                                      # Human36M.evaluate skips every sample whose middle frame is not camera 4
+            win = win[table.cam_idxs[win[:, 0] + 8] == 4]               # (data/Human36M/dataset.py:742-744): they are not run at all here
+        args.clips, args.joints = len(win), 19 if args.dataset == "pw3d" else 17
     rank, local, world = sharding.init_from_env()
     if os.environ.get("PMCE_BENCH_SHARE_GPU"):      # plumbing runs of the N > 1 path on a box with fewer GPUs (ranks share devices)
         local = local % max(torch.cuda.device_count(), 1)

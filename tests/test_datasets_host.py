@@ -61,3 +61,72 @@ def test_missing_files_are_named(tmp_path):
     from pmce_amd import datasets
     with pytest.raises(FileNotFoundError, match="3DPW_latest_test.json"):
         datasets.load_pw3d(str(tmp_path))
+
+
+# ---- Human3.6M (round 5): the reference's Human36M('test') class on tests/golden/h36m_files.py's directory (make_golden_datasets_h36m.py) ----
+
+@pytest.fixture(scope="module")
+def h36m(tmp_path_factory):
+    import h36m_files
+    from pmce_amd import datasets
+    root = str(tmp_path_factory.mktemp("h36m"))
+    return datasets.load_h36m(h36m_files.write(root), "test")
+
+
+@pytest.fixture(scope="module")
+def gold_h36m():
+    return np.load(osp.join(HERE, "golden", "datasets_h36m.npz"))
+
+
+def test_h36m_frame_tables_equal_the_reference_loader(h36m, gold_h36m):
+    """Every second frame, the sequence dropped by name and the empty bounding box gone, features walked from each video's start index,
+    joints projected world -> camera -> pixel, detections in the dataset's order: every array the reference's load_data returns."""
+    g = gold_h36m
+    assert len(h36m) == len(g["img_names"]) == 155 and h36m.skipped == 18 + 1
+    assert list(h36m.img_paths) == list(g["img_names"])
+    assert np.array_equal(h36m.img_shapes, g["img_hws"])
+    assert np.array_equal(h36m.features[:, ::64], g["features_sub"])
+    assert np.array_equal(h36m.joints_cam_h36m, g["joint_cams"]) and np.array_equal(h36m.gt_joints_img_coco, g["joint_imgs"])
+    assert np.array_equal(h36m.extras["bboxs"], g["bboxs"])
+    assert np.array_equal(h36m.cam_idxs, g["cam_idxs"]) and np.array_equal(h36m.mid_valid, g["smpl_valid"])
+    assert np.array_equal(h36m.smpl["pose"][h36m.mid_valid], g["poses_valid"])
+    for k, name in (("cam_focals", "cam_focals"), ("cam_princpts", "cam_princpts"), ("cam_Rs", "cam_Rs"), ("cam_ts", "cam_ts")):
+        assert np.array_equal(h36m.extras[k], g[name]), k
+    assert np.array_equal(h36m.keypoints, g["pose2d_det"]) and list(h36m.img_paths) == list(g["pose2d_det_name"])
+
+
+def test_h36m_window_list_and_model_inputs_equal_the_reference_dataset(h36m, gold_h36m):
+    """vid_indices (windows whose middle frame has no SMPL fit dropped) and, for sampled windows, what __getitem__ hands the model and the
+    joint targets of the middle frame."""
+    from oracle import staging_oracle as S
+    from pmce_amd import datasets
+    g = gold_h36m
+    win = h36m.windows(16, 1)
+    assert np.array_equal(win, g["vid_indices"]) and len(win) == int(g["n_items"]) == 76
+    pose2d = np.stack([np.asarray(S.normalize_screen_coordinates(h36m.keypoints[i][:, :2], w=h36m.img_shapes[i][1], h=h36m.img_shapes[i][0]), dtype=np.float32)
+                       for i in range(len(h36m))])
+    gt = h36m.gt_joints_root_relative()
+    frames = datasets.window_frames(win)
+    for k in g["sample_windows"]:
+        idx = frames[k]
+        assert np.array_equal(pose2d[idx], g[f"item{k}_pose2d"])
+        assert np.array_equal(h36m.features[idx][:, ::64], g[f"item{k}_img_feature_sub"])
+        assert np.array_equal(gt[idx[8]], g[f"item{k}_reg_pose3d"]) and np.array_equal(gt[idx[8]], g[f"item{k}_lift_pose3d"])
+    assert h36m.extra_joints == 0 and len(h36m.joints_name) == 17
+    cam4 = h36m.cam_idxs[frames[:, 8]] == 4                         # what Human36M.evaluate keeps
+    assert 0 < cam4.sum() < len(win)
+
+
+def test_h36m_inconsistent_files_are_refused(tmp_path):
+    import json
+    import h36m_files
+    from pmce_amd import datasets
+    path = h36m_files.write(str(tmp_path))
+    with pytest.raises(FileNotFoundError, match="Human36M_subject9_data.json"):
+        datasets.load_h36m(str(tmp_path / "nowhere"))
+    f = osp.join(path, "Human36M_test_cpn_joint_2d.json")
+    det = json.load(open(f))
+    det.pop(sorted(det)[0])
+    json.dump(det, open(f, "w"))
+    with pytest.raises(ValueError, match="no CPN detection"):
+        datasets.load_h36m(path)

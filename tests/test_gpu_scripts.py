@@ -119,6 +119,40 @@ def test_eval_sharded_script_on_reference_format_files(tmp_path):
         assert abs(got[k] - ref[r]) < 2e-3 * max(1.0, abs(ref[r]) / 100), (k, got[k], ref[r])          # millimetres
 
 
+def test_eval_sharded_script_on_reference_format_h36m_files(tmp_path):
+    """Round 5: `eval_sharded.py --dataset h36m --data-dir` on a directory in the reference's Human3.6M file formats (tests/golden/h36m_files.py;
+    the reader is pinned against the reference's own Human36M class in tests/test_datasets_host.py): two ranks, J = 17, the stride-1 windows
+    whose middle frame is camera 4 (what Human36M.evaluate keeps) - against the metrics oracle on predictions recomputed unsharded here from
+    host-assembled windows."""
+    from oracle import metrics_oracle as MO
+    from oracle import staging_oracle as S
+    from pmce_amd import assets, datasets, models, synth
+    sys.path.insert(0, osp.join(HERE, "golden"))
+    import h36m_files
+    path = h36m_files.write(str(tmp_path))
+    got = _run_script("eval_sharded.py", ["--dataset", "h36m", "--data-dir", path, "--batch", "16"], world=2)
+    table = datasets.load_h36m(path)
+    win = table.windows()
+    win = win[table.cam_idxs[win[:, 0] + 8] == 4]
+    assert got["n_gpus"] == 2 and got["samples"] == len(win) and 0 < len(win) < 76 and got["J"] == 17 and got["MPVPE"] is None and "Human3.6M test" in got["data"]
+    assets.allow_synthetic_base_data()
+    dev = torch.device("cuda:0")
+    model = models.PMCE.get_model(17, 256, 3)
+    model.load_state_dict(synth.make_state_dict(synth.pmce_spec(17, 256, 3), seed=123))
+    model = model.to(dev)
+    pose2d = np.stack([np.asarray(S.normalize_screen_coordinates(table.keypoints[i][:, :2], w=table.img_shapes[i][1], h=table.img_shapes[i][0]), dtype=np.float32)
+                       for i in range(len(table))])
+    fr = datasets.window_frames(win)
+    mesh = model(torch.from_numpy(pose2d[fr]).to(dev), torch.from_numpy(table.features[fr]).to(dev))[0]
+    pred = mesh.double().cpu().numpy() * 1000
+    jr = assets.load_j_regressor("h36m").astype(np.float32)
+    mid = win[:, 0] + 8
+    ref = MO.evaluate_samples(pred, pred, jr[:1], 0, jr, table.sequence_ids()[mid], gt_joints=table.gt_joints_root_relative()[mid].astype(np.float64))
+    print("2 ranks:", {k: got[k] for k in ("MPJPE", "PA-MPJPE", "ACCEL")}, "\noracle :", {k: ref[k] for k in ("MPJPE", "PA_MPJPE", "ACCEL")})
+    for k, r in (("MPJPE", "MPJPE"), ("PA-MPJPE", "PA_MPJPE"), ("ACCEL", "ACCEL")):
+        assert abs(got[k] - ref[r]) < 2e-3 * max(1.0, abs(ref[r]) / 100), (k, got[k], ref[r])          # millimetres
+
+
 def test_stream_bench_script():
     from pmce_amd import streaming
     L = 700
