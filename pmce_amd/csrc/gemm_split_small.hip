@@ -1,31 +1,43 @@
-// The three-product f16 GEMM of gemm_split_f16.hip for SMALL GRIDS (round 5): one 64 x 128 tile per workgroup, at most one round of
-// workgroups on the chip - the shape of every product of a single-clip forward (M = 272 tokens, 16 frames, 1 row) and of the small-M products
-// of any batch (AdaLN parameters, the final product, the layer-1 GRU projections).
+// The three-product f16 GEMM of gemm_split_f16.hip for SMALL GRIDS (round 5): ONE tile per workgroup, at most one round of workgroups on the
+// chip - the shape of every product of a single-clip forward (M = 272 tokens, 16 frames, 1 row) and of the small-M products of any batch (AdaLN
+// parameters, the final product, the GRU projections of small batches).
 //
-// Such a launch is not bound by any throughput: measured (scripts/microbench/chain_latency.hip, dma_patterns.hip, small_m_tiles.py) a
-// dependent v_mfma_f32_32x32x16_f16 issues after 44 cycles, an LDS-DMA instruction costs a CU 16 cycles whatever its row pattern, an L2 round
-// trip is 300 cycles - and the persistent kernel's 64 x 128 tile took 1,510 cycles per pair of k-tiles: four waves, ONE per SIMD, each
-// walking its ~200 instructions per trip (the tile-stream bookkeeping, six DMA issues, twelve fragment reads, two chains of three dependent
-// matrix instructions) with nothing on the SIMD to issue in the gaps.  This kernel gives the tile EIGHT waves (two per SIMD, one 32 x 32
-// accumulator each: a wave's dependent chain overlaps its SIMD partner's), no tile stream (one tile: the loop is wait - barrier - issue -
-// multiply), bias / scales / residual requested before the first k-tile instead of after the last, and a ring of six 24 KB stages - five in
-// flight, 120 KB: the weights of a single-clip forward come from HBM (0.6 GB per forward pass through the caches), a microsecond away.
+// Such a launch is bound by no throughput: measured (scripts/microbench/chain_latency.hip, dma_patterns.hip, small_m_tiles.py) a dependent
+// v_mfma_f32_32x32x16_f16 issues after 44 cycles, an LDS-DMA instruction costs a lone workgroup's CU 16 cycles whatever its row pattern, an L2
+// round trip is 300 cycles - and the persistent kernel's 64 x 128 tile took 1,510 cycles per pair of k-tiles: four waves, ONE per SIMD, each
+// walking its ~200 instructions per trip (tile-stream bookkeeping, six DMA issues, twelve fragment reads, two chains of three dependent matrix
+// instructions) with nothing on the SIMD to issue in the gaps; and the weights of a single-clip forward come from HBM (0.6 GB pass through the
+// caches per forward), where what a CU receives is its requests in flight divided by a microsecond.
+// Here a SIMD always holds TWO waves with ONE 32 x 32 accumulator each (a wave's dependent chain overlaps its partner's): a 64 x 128 tile of
+// eight waves, or - when 256 of them cover the product, or 512 for products of at most 32 rows (pure weight streaming: twice the workgroups
+// keep twice the requests in flight) - a 64 x 64 tile of four waves with two workgroups per CU.  No tile stream (the loop is wait - barrier -
+// issue - multiply), bias / scales / residual requested before the first k-tile instead of after the last, a ring of six 24 KB or four 16 KB
+// stages of two k-tiles each.
 // Arithmetic: the same k-tiles in the same order into one fp32 accumulator per element, the same epilogue expressions - results are
 // bit-identical to the persistent kernel's (tests: batch invariance B = 4 against B = 64; test_gemm_split_small_grid_equals_persistent).
 #include <atomic>
 
 #include "gemm_split_common.hpp"
 
-namespace {
-constexpr int S_BM = 64, S_BN = 128, S_NS = 6;
-constexpr int S_SUBF = (S_BM + S_BN) * 16;  // floats of one 16-wide k-tile in LDS: 192 rows x 64 B
-constexpr int S_SF = 2 * S_SUBF;            // a stage = two k-tiles = 24 KB
-constexpr int S_LDS = S_NS * S_SF * 4;      // 144 KB
-}  // namespace
+// NWN = 4: 64 x 128 tile, eight waves (2 x 4), six stages of 24 KB, one workgroup per CU.  NWN = 2: 64 x 64 tile, four waves (2 x 2), four stages
+// of 16 KB, two workgroups per CU - for products of at most 64 rows, which are pure weight streaming (the final product of a single clip reads
+// 278 MB): twice the workgroups keep twice the requests in flight towards HBM.
+template <int NWN>
+struct SmallCfg {
+  static constexpr int BM = 64, BN = 32 * NWN, NW = 2 * NWN;
+  static constexpr int SUBF = (BM + BN) * 16;   // floats of one 16-wide k-tile in LDS: BM + BN rows of 64 B
+  static constexpr int SF = 2 * SUBF;           // a stage = two k-tiles = 24 / 16 KB
+  static constexpr int NS = NWN == 4 ? 6 : 4;   // 144 KB / 64 KB
+  static constexpr int LDS = NS * SF * 4;
+  static constexpr int GPS = (BM + BN) / 16;    // 16-row groups (DMA instructions) per k-tile: 12 / 8
+  static constexpr int DPW = 2 * GPS / NW;      // per wave and stage: 3 / 4
+};
 
-template <int ACT, bool RES, bool APACK, bool OPACK, bool RS>
-__global__ __launch_bounds__(512) void gemm_split_small_kernel(SplitParams p) {
+template <int NWN, int ACT, bool RES, bool APACK, bool OPACK, bool RS>
+__global__ __launch_bounds__(128 * NWN) void gemm_split_small_kernel(SplitParams p) {
   static_assert(!RS || (APACK && !OPACK && !RES && ACT == 0), "a row-scaled A is a packed A; no packed result, residual or activation");
+  using Cfg = SmallCfg<NWN>;
+  constexpr int S_BM = Cfg::BM, S_BN = Cfg::BN, S_SUBF = Cfg::SUBF, S_SF = Cfg::SF, S_NS = Cfg::NS, GPS = Cfg::GPS, DPW = Cfg::DPW, NW = Cfg::NW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n0 = lane & 31, hb = lane >> 5;
@@ -58,19 +70,19 @@ __global__ __launch_bounds__(512) void gemm_split_small_kernel(SplitParams p) {
   }
   asm volatile("" ::: "memory");
 
-  // ---- DMA side: 24 instructions of 16 rows x 64 B per stage, three per wave: instruction j = wave + 8 q is row group g = j % 12 (0-3: A,
-  // 4-11: W) of the stage's k-tile j / 12; lane L -> row 16 g + (L >> 2), PHYSICAL chunk L & 3 = logical chunk (L & 3) ^ ((L >> 4) & 3) ----
+  // ---- DMA side: 2 GPS instructions of 16 rows x 64 B per stage, DPW per wave: instruction j = wave + NW q is row group g = j % GPS (0-3: A,
+  // the rest: W) of the stage's k-tile j / GPS; lane L -> row 16 g + (L >> 2), PHYSICAL chunk L & 3 = logical chunk (L & 3) ^ ((L >> 4) & 3) ----
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, 0xffffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, 0xffffffff, 0x00020000);
   const int drow = lane >> 2;
   const unsigned dchunk = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) * 4);  // floats
   const int kstep_w = p.wblk ? 4096 : 64;  // bytes from one k-tile of a W row (block) to the next
-  unsigned doff[3];
-  int dlds[3], dks[3], dk0[3];
-  bool d_is_a[3];
+  unsigned doff[DPW];
+  int dlds[DPW], dks[DPW], dk0[DPW];
+  bool d_is_a[DPW];
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int j = wave + 8 * q, sub = j / 12, g = j % 12;
+  for (int q = 0; q < DPW; ++q) {
+    const int j = wave + NW * q, sub = j / GPS, g = j % GPS;
     d_is_a[q] = g < 4;
     if (g < 4)
       doff[q] = ((unsigned)min(m_base + 16 * g + drow, p.M - 1) * p.lda + dchunk) * 4u;
@@ -86,7 +98,7 @@ __global__ __launch_bounds__(512) void gemm_split_small_kernel(SplitParams p) {
   int i_s = 0, i_slot = 0;  // next stage to request (k-tiles 2 s, 2 s + 1) and its ring slot
   auto issue_next = [&]() {
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < DPW; ++q)
       sdma16(d_is_a[q] ? rsrc_a : rsrc_w, doff[q], dk0[q] + 2 * i_s * dks[q], lds0 + i_slot * (S_SF * 4) + dlds[q]);
     ++i_s;
     i_slot = i_slot + 1 == S_NS ? 0 : i_slot + 1;
@@ -109,12 +121,12 @@ __global__ __launch_bounds__(512) void gemm_split_small_kernel(SplitParams p) {
   }
   int slot = 0;
   for (int it = 0; it < nk; ++it) {
-    // stage `it` has landed when at most the younger stages' DMAs (three per wave each) are in flight
+    // stage `it` has landed when at most the younger stages' DMAs (DPW per wave each) are in flight
     const int younger = min(nk - 1 - it, S_NS - 2);
-    if (younger >= 4) wait_vm<12>();
-    else if (younger == 3) wait_vm<9>();
-    else if (younger == 2) wait_vm<6>();
-    else if (younger == 1) wait_vm<3>();
+    if (S_NS >= 6 && younger >= 4) wait_vm<4 * DPW>();
+    else if (S_NS >= 5 && younger == 3) wait_vm<3 * DPW>();
+    else if (younger == 2) wait_vm<2 * DPW>();
+    else if (younger == 1) wait_vm<DPW>();
     else wait_vm<0>();
     __syncthreads();  // every wave's part of stage `it` is in LDS; every wave is done reading stage it - 1
     if (i_s < nk) issue_next();
@@ -200,32 +212,49 @@ __global__ __launch_bounds__(512) void gemm_split_small_kernel(SplitParams p) {
   report_nonfinite(p.oflow, bad);
 }
 
-template <int ACT, bool RES, bool APACK, bool OPACK, bool RS>
+template <int NWN, int ACT, bool RES, bool APACK, bool OPACK, bool RS>
 static int launch_small(const SplitParams& p, hipStream_t stream) {
   static std::atomic<unsigned long long> done{0};
-  PMCE_TRY(pmce_opt_in_lds(reinterpret_cast<const void*>(&gemm_split_small_kernel<ACT, RES, APACK, OPACK, RS>), S_LDS, done, "gemm_split_small"));
+  constexpr int LDS = SmallCfg<NWN>::LDS;
+  PMCE_TRY(pmce_opt_in_lds(reinterpret_cast<const void*>(&gemm_split_small_kernel<NWN, ACT, RES, APACK, OPACK, RS>), LDS, done, "gemm_split_small"));
   const int grid = ((p.ntm * p.ntn + 7) / 8) * 8;
-  hipLaunchKernelGGL((gemm_split_small_kernel<ACT, RES, APACK, OPACK, RS>), dim3(grid), dim3(512), S_LDS, stream, p);
+  hipLaunchKernelGGL((gemm_split_small_kernel<NWN, ACT, RES, APACK, OPACK, RS>), dim3(grid), dim3(128 * NWN), LDS, stream, p);
   return PMCE_OK;
 }
 
-// Is there a small-grid form for this product?  (K in whole pairs of k-tiles; at most one workgroup per CU; the operand / epilogue
-// combinations the model's small products use.)
+// Which tile?  64 x 64 (two workgroups per CU) when one round of at most 256 such tiles covers the product, or - products of at most 32 rows:
+// pure weight streaming - at most 512 of them; else 64 x 128 if one round of at most 256 covers it; else none (0).  Measured, same box
+// (profiles/r05_e_small_grid_gemm_ab.txt): 64 x 64 for every product of a single-clip forward -3.7 % per forward at C = 512, the AdaLN product
+// 49 -> 37 us, the final product 82 -> 76 us up to B = 8 (at B = 64 its 323 tiles of 64 x 64 are slower than 162 of 64 x 128: hence the 32 rows).
+static int small_nwn_for(int M, int N) {
+  const long long t64 = (long long)((M + 63) / 64) * ((N + 63) / 64), t128 = (long long)((M + 63) / 64) * ((N + 127) / 128);
+  if (t64 <= 256 || (M <= 32 && t64 <= 512)) return 2;
+  return t128 <= 256 ? 4 : 0;
+}
+
+// Is there a small-grid form for this product?  (K in whole pairs of k-tiles; one round of workgroups; the operand / epilogue combinations
+// the model's small products use.)
 bool pmce_gemm_split_small_applies(int M, int N, int K, int act, bool apack, bool opack, bool res, bool rs) {
   if (K % 32 != 0 || K < 64) return false;
-  if ((long long)((M + S_BM - 1) / S_BM) * ((N + S_BN - 1) / S_BN) > 256) return false;
+  if (small_nwn_for(M, N) == 0) return false;
   if (rs) return true;
   if (opack) return act == 1;
   if (apack) return act == 0;
   return act == 0 && !res;
 }
 
-int pmce_gemm_split_small_launch(SplitParams& p, int act, bool apack, bool opack, hipStream_t stream) {
-  p.ntm = (p.M + S_BM - 1) / S_BM;
-  p.ntn = (p.N + S_BN - 1) / S_BN;
+template <int NWN>
+static int launch_small_cfg(SplitParams& p, bool apack, bool opack, hipStream_t stream) {
+  p.ntm = (p.M + SmallCfg<NWN>::BM - 1) / SmallCfg<NWN>::BM;
+  p.ntn = (p.N + SmallCfg<NWN>::BN - 1) / SmallCfg<NWN>::BN;
   const bool res = p.R != nullptr;
-  if (p.rscale) return launch_small<0, false, true, false, true>(p, stream);
-  if (opack) return launch_small<1, false, true, true, false>(p, stream);
-  if (apack) return res ? launch_small<0, true, true, false, false>(p, stream) : launch_small<0, false, true, false, false>(p, stream);
-  return launch_small<0, false, false, false, false>(p, stream);
+  if (p.rscale) return launch_small<NWN, 0, false, true, false, true>(p, stream);
+  if (opack) return launch_small<NWN, 1, false, true, true, false>(p, stream);
+  if (apack) return res ? launch_small<NWN, 0, true, true, false, false>(p, stream) : launch_small<NWN, 0, false, true, false, false>(p, stream);
+  return launch_small<NWN, 0, false, false, false, false>(p, stream);
+}
+
+int pmce_gemm_split_small_launch(SplitParams& p, int act, bool apack, bool opack, hipStream_t stream) {
+  (void)act;
+  return small_nwn_for(p.M, p.N) == 2 ? launch_small_cfg<2>(p, apack, opack, stream) : launch_small_cfg<4>(p, apack, opack, stream);
 }
