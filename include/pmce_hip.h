@@ -408,6 +408,8 @@ int pmce_joint_stream_f32(const float* xq, const float* jQ, const float* kv, con
                           int J, int stage, pmce_stream_t stream);
 /* Operand of the packed upsample+residual product: A[b] = [relu(g[b]) | vt[b] flattened | 0-pad] (CoevoDecoder.py:238-244). */
 int pmce_build_final_operand_f32(const float* g, const float* vt, float* A, int B, int KP, pmce_stream_t stream);
+/* packed != 0 (KP % 16 == 0): the rows are written pre-split - the A operand of pmce_gemm_nt_split_f16*(a_packed = 1); what the model runs. */
+int pmce_build_final_operand_pk_f32(const float* g, const float* vt, float* A, int B, int KP, int packed, pmce_stream_t stream);
 /* lib/core/base.py:223-225 — out[b][r][:] = sum_nz data * (mesh[b][col][:] * scale); CSR regressor [R,6890]. */
 int pmce_j_regress_f32(const float* mesh, const int* indptr, const int* indices, const float* data, float* out, int B,
                        int R, int NVF, float scale, pmce_stream_t stream);

@@ -109,6 +109,7 @@ PROTOTYPES = {
     "pmce_tokens_kv_pk_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _f, _f, _f, _i, _f, _s],
     "pmce_joint_stream_f32": [_f, _f, _f, _f, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_int), _f, _f, _f, _i, _i, _i, _s],
     "pmce_build_final_operand_f32": [_f, _f, _f, _i, _i, _s],
+    "pmce_build_final_operand_pk_f32": [_f, _f, _f, _i, _i, _i, _s],
     "pmce_j_regress_f32": [_f, _f, _f, _f, _f, _i, _i, _i, _fl, _s],
     "pmce_sample_errors_f32": [_f, _f, _fl, _i, _f, _f, _f, _f, _i, _f, _f, _i, _i, _f, _f, _f, _f, _f, _i, _s],
     "pmce_accel_error_f32": [_f, _f, _f, _f, _i, _i, _s],

@@ -2000,6 +2000,10 @@ __global__ __launch_bounds__(JS_THREADS) void joint_stream_kernel(const float* _
 // tail: build the packed operand of the final GEMM and the J_regressor projection
 // ======================================================================================================
 // A'[b][0:2048] = relu(g[b]) ; A'[b][2048 + 3v + l] = vt[b][v][l] ; A'[b][3341:KP] = 0   (CoevoDecoder.py:238-244)
+// PACKED: the row is written pre-split ([KP/16][16 f16 hi | 16 f16 lo*2^11] in the bytes of the fp32 row, the layout the lifter's producers
+// write): the final product then spends no vector instruction on splitting its A operand (the split is the same two roundings either way:
+// bit-identical results).
+template <bool PACKED>
 __global__ __launch_bounds__(256) void build_final_operand_kernel(const float* __restrict__ g, const float* __restrict__ vt,
                                                                   float* __restrict__ A, int B, int KP) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2010,7 +2014,14 @@ __global__ __launch_bounds__(256) void build_final_operand_kernel(const float* _
     v = fmaxf(g[(long long)b * 2048 + k], 0.f);
   else if (k < 2048 + NV * 3)
     v = vt[(long long)b * NV * 3 + (k - 2048)];
-  A[idx] = v;
+  if constexpr (PACKED) {
+    _Float16* row = reinterpret_cast<_Float16*>(A + (long long)b * KP);
+    const _Float16 h = (_Float16)v;
+    row[(k >> 4) * 32 + (k & 15)] = h;
+    row[(k >> 4) * 32 + 16 + (k & 15)] = (_Float16)((v - (float)h) * 2048.0f);
+  } else {
+    A[idx] = v;
+  }
 }
 
 // joints_mm[b][j][l] = sum_nz data * (mesh[b][col][l] * 1000)   (lib/core/base.py:223-225), CSR regressor
@@ -2264,11 +2275,15 @@ extern "C" int pmce_joint_stream_f32(const float* xq, const float* jQ, const flo
   return pmce_check_launch("joint_stream");
 }
 
-extern "C" int pmce_build_final_operand_f32(const float* g, const float* vt, float* A, int B, int KP, hipStream_t stream) {
-  PMCE_REQUIRE(g && vt && A && KP >= 2048 + NV * 3, "build_final_operand: bad args");
+extern "C" int pmce_build_final_operand_pk_f32(const float* g, const float* vt, float* A, int B, int KP, int packed, hipStream_t stream) {
+  PMCE_REQUIRE(g && vt && A && KP >= 2048 + NV * 3 && (!packed || KP % 16 == 0), "build_final_operand: bad args");
   const long long n = (long long)B * KP;
-  hipLaunchKernelGGL(build_final_operand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, vt, A, B, KP);
+  if (packed) hipLaunchKernelGGL(build_final_operand_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, vt, A, B, KP);
+  else hipLaunchKernelGGL(build_final_operand_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, vt, A, B, KP);
   return pmce_check_launch("build_final_operand");
+}
+extern "C" int pmce_build_final_operand_f32(const float* g, const float* vt, float* A, int B, int KP, hipStream_t stream) {
+  return pmce_build_final_operand_pk_f32(g, vt, A, B, KP, 0, stream);
 }
 
 extern "C" int pmce_j_regress_f32(const float* mesh, const int* indptr, const int* indices, const float* data, float* out,

@@ -690,9 +690,11 @@ int coevo_part(pmce_model* m, const float* joints, float* cam_pose, float* cam_m
     vt_cur = vt_next;
   }
   // ---- 431 -> 6890 upsample conv + 3 residual Linear(2048->6890) as ONE product (CoevoDecoder.py:238-244) ----
-  RUN(P_FINAL_OP, pmce_build_final_operand_f32(g, vt_cur, w.FA, B, FINAL_K, stream));
+  // (split mode: the operand is written pre-split - the product's k-loop spends no vector instruction on splitting it)
+  const int fa_packed = (m->split_now && m->s_final.wp) ? 1 : 0;
+  RUN(P_FINAL_OP, pmce_build_final_operand_pk_f32(g, vt_cur, w.FA, B, FINAL_K, fa_packed, stream));
   RUN(P_GEMM_FINAL, lgemm(m, w.FA, m->w.final_w, m->s_final, m->w.final_b, nullptr, cam_mesh, B, NVF * 3, FINAL_K,
-                          FINAL_K, NVF * 3, 0, stream));
+                          FINAL_K, NVF * 3, 0, stream, fa_packed));
   if (side) PMCE_TRY(ev_wait(stream, m->ev_d, "coevo join d"));  // cam_pose is written by the side stream
   return PMCE_OK;
 }

@@ -655,6 +655,21 @@ def test_gru_all_steps_fixture(golden):
     assert e_f < 5e-5 and e_b < 5e-5 and e_8 < 5e-5
 
 
+def test_final_operand_pre_split_is_the_same_split():
+    """The final product's operand written pre-split by its builder (what the model runs in split mode) against the fp32 operand split afterwards: the
+    same bits, hence the same product."""
+    from pmce_amd import _lib, ops
+    lib = _lib.load()
+    B, KP = 5, 3360
+    g = rnd("fin.g", (B, 2048)).to(dev())
+    vt = rnd("fin.vt", (B, 431, 3)).to(dev())
+    A = torch.empty(B, KP, device=dev()); Ap = torch.empty(B, KP, device=dev())
+    _lib.check(lib.pmce_build_final_operand_pk_f32(_lib.ptr(g), _lib.ptr(vt), _lib.ptr(A), B, KP, 0, _lib.current_stream()), "build_final_operand")
+    _lib.check(lib.pmce_build_final_operand_pk_f32(_lib.ptr(g), _lib.ptr(vt), _lib.ptr(Ap), B, KP, 1, _lib.current_stream()), "build_final_operand")
+    assert torch.equal(ops.split_rows_f16(A).view(torch.int32), Ap.view(torch.int32))
+    assert torch.equal(A[:, :2048], torch.relu(g)) and torch.equal(A[:, 2048:2048 + 1293], vt.reshape(B, -1)) and not A[:, 3341:].any()
+
+
 def test_gru_step_small_batch_equals_v2():
     """The small-batch GRU step (B <= 32: one batch tile per wave, B <= 64: two) against gru_step_v2 (B > 64) on the same rows: bit-identical -
     a clip's hidden state does not depend on the batch it rode in - and both against the fp64 step (nn.GRU's formulas)."""
