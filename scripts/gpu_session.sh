@@ -1,5 +1,6 @@
 #!/bin/bash
-# GPU session script: bash scripts/gpu_session.sh [tests] [bench] [ab_r4] [prof] [pmc] [counters] [quick "<pytest -k expr>"] (any subset, in this order).
+# GPU session script: bash scripts/gpu_session.sh [tests] [prof] [pmc] [counters] [install] [bench] [ab_r4] [quick "<pytest -k expr>"] (any subset, any order;
+# `install` after pmc / counters and before bench makes the bench line read the PMC summaries of its own build).
 # Everything lands under gpurun_out/$PMCE_ROUND (default r05); summaries are copied to profiles/ by hand afterwards.
 set -u
 R=${PMCE_ROUND:-r05}
@@ -65,6 +66,16 @@ pmc)
     python scripts/pmc_summary.py $O/pmc$C $O/pmc_hbm_traffic_per_launch_C$C.json | grep -v "at::\|rocclr" | head -40
     find $O/pmc$C -name "*.csv" -size +8M -delete
   done
+  ;;
+install)
+  # the PMC summaries of THIS session become the files bench.py reads (profiles/ on the box; the same copies are committed afterwards), so that
+  # the bench line of the session carries roofline fields of its own build (stale: false)
+  for C in 512 256; do
+    [[ -s $O/pmc_hbm_traffic_per_launch_C$C.json ]] && cp $O/pmc_hbm_traffic_per_launch_C$C.json profiles/pmc_hbm_traffic_per_launch_C$C.json
+    [[ -s $O/pmc_counters_per_kernel_C$C.json ]] && cp $O/pmc_counters_per_kernel_C$C.json profiles/pmc_counters_per_kernel_C$C.json
+  done
+  [[ -s $O/pmc_counters_per_kernel_C512.json ]] && cp $O/pmc_counters_per_kernel_C512.json profiles/pmc_counters_per_kernel.json
+  python -c "import bench; print('bench will read:', bench._pmc_file(512), bench.library_build_id())" 2>/dev/null || true
   ;;
 counters)
   # SQ counters per kernel (matrix-pipe busy, VALU instruction counts, wait cycles, LDS conflicts) of the whole forward, both widths

@@ -1,2 +1,2 @@
-export PMCE_ROUND=r05
-bash scripts/gpu_session.sh tests bench ab_r4 prof pmc counters
+export PMCE_ROUND=${PMCE_ROUND:-r05f}
+bash scripts/gpu_session.sh tests prof pmc counters install bench
