@@ -2213,7 +2213,12 @@ extern "C" int pmce_vertex_sa_f32(const float* xin, const float* qkv, const floa
 // The attention half of the vertex stream's AdaLN Block in one launch (split mode): AdaLN + qkv product + 431 x 431 attention + proj +
 // residual.  scratch: pmce_vertex_sab_scratch_floats(B) floats, 16-byte aligned (the clip's key tiles as f16 planes; contents are
 // meaningless outside the call).  qkv_img: pmce_qkv_pack_f16(Wqkv).
-extern "C" long long pmce_vertex_sab_scratch_floats(int B) { return (long long)B * (B > 128 ? 1 : 2) * NTILE * SAB_TILE_FLOATS; }
+// Non-decreasing in B (two tile sets per clip up to B = 128, one beyond - never less than the 256 sets of B = 128): a caller that sizes
+// once for its largest batch holds enough for every smaller one.
+extern "C" long long pmce_vertex_sab_scratch_floats(int B) {
+  const long long sets = B > 128 ? (B > 256 ? B : 256) : 2LL * B;
+  return sets * NTILE * SAB_TILE_FLOATS;
+}
 extern "C" int pmce_vertex_sab_split_f32(const float* xin, const float* GB, int gb_stride, int inst, const float* qkv_img,
                                          const float* bqkv, const float* Wp, const float* bp, float* scratch, float* yout, int B,
                                          hipStream_t stream) {

@@ -115,8 +115,9 @@ class HipEngine:
         return other
 
     def workspace(self, batch: int):
-        if self.ws is None or batch > self.ws_batch or self.ws.device != self.device:
-            nbytes = self.lib.pmce_model_workspace_bytes(self.handle, batch)
+        # compared in BYTES, not batch counts: the library's answer is what check_ws enforces
+        nbytes = self.lib.pmce_model_workspace_bytes(self.handle, batch)
+        if self.ws is None or nbytes > self.ws.numel() or self.ws.device != self.device:
             if self.ws is not None and self.ws.is_cuda:
                 # forwards enqueued on this stream may still be using the old buffer: the allocator must not hand it out
                 # to another stream before they are done

@@ -3,7 +3,7 @@
 # `install` after pmc / counters and before bench makes the bench line read the PMC summaries of its own build).
 # Everything lands under gpurun_out/$PMCE_ROUND (default r05); summaries are copied to profiles/ by hand afterwards.
 set -u
-R=${PMCE_ROUND:-r05}
+R=${PMCE_ROUND:-r06}
 mkdir -p gpurun_out/$R
 O=gpurun_out/$R
 export TMPDIR=/tmp PMCE_SYNTHETIC_BASE_DATA=1
@@ -25,8 +25,9 @@ quick)
   echo "pytest quick exit: $?"; tail -n 40 $O/pytest_quick.log
   ;;
 bench)
-  timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err
-  echo "bench exit: $?"; python scripts/show_bench.py $O/bench.json 2>/dev/null | head -120 || head -c 3000 $O/bench.json
+  timeout 1200 python bench.py --detail-file $O/bench_detail.json > $O/bench_line.json 2> $O/bench.err
+  echo "bench exit: $?"; echo "stdout: $(wc -l < $O/bench_line.json) line(s), $(wc -c < $O/bench_line.json) bytes"; cat $O/bench_line.json
+  python scripts/show_bench.py $O/bench_detail.json 2>/dev/null | head -120 || head -c 3000 $O/bench_detail.json
   tail -n 5 $O/bench.err | grep -v amdgpu.ids || true
   ;;
 ab_r4)
@@ -34,7 +35,7 @@ ab_r4)
   rm -f $O/ab_r4_vs_r5.txt
   for C in 512 256; do for i in 1 2; do for T in r4 r5; do
     if [[ $T == r4 ]]; then (cd .r4tree && timeout 300 python bench.py --embed-dim $C $QUICK 2>> ../$O/ab_r4.err) > $O/ab_tmp.json
-    else timeout 300 python bench.py --embed-dim $C $QUICK --sustained-seconds 0 > $O/ab_tmp.json 2>> $O/ab_r4.err; fi
+    else timeout 300 python bench.py --embed-dim $C $QUICK --sustained-seconds 0 --detail-file $O/ab_tmp.json > /dev/null 2>> $O/ab_r4.err; fi
     T=$T C=$C python - <<PY | tee -a $O/ab_r4_vs_r5.txt
 import json, os
 d = json.loads(open("$O/ab_tmp.json").read().strip().splitlines()[-1])

@@ -51,6 +51,60 @@ def test_failed_rank_takes_the_job_down():
     assert r.returncode != 0 and not lines
 
 
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", osp.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_the_printed_line_is_compact_and_complete(tmp_path, capsys):
+    """BENCH_r05.json came back `parsed: null`: the one stdout line had grown to 24.7 KB of nested child records.  The line bench.py prints
+    is now a compact record (hard bound 4 KB) - the contract's fields + roofline + cpu_baseline - and everything else goes to the detail
+    file.  Checked on the full record of a real run (committed), inflated to an 8-rank job with every optional record present."""
+    bench = _bench_module()
+    full = json.load(open(osp.join(REPO, "profiles", "r05_f_bench_B256.json")))
+    assert len(json.dumps(full)) > 20000                                   # the record that did not parse
+    full["n_gpus"] = 8
+    for k in ("per_rank_clips_s", "per_rank_ms_per_step", "per_rank_sustained_clock_ghz", "per_rank_weights_load_s", "per_rank_first_step_s"):
+        full[k] = full[k] * 8
+    full["cpu_baseline"]["sample"] = full["cpu_baseline"]["sample"] * 20     # however wordy a nested record gets
+    detail = tmp_path / "detail.json"
+    bench.emit(full, str(detail))
+    out = capsys.readouterr().out
+    assert out.count("\n") == 1 and out.endswith("\n")                      # ONE line on stdout, the last one
+    assert len(out) <= bench.COMPACT_LIMIT < 8192
+    d = json.loads(out)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in d, k
+    assert d["config"]["workload"] and d["config"]["embed_dim"] == 512 and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_per_step", "source"):
+        assert k in r, k
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["source"]["achieved"].startswith("HIP events") and r["source"]["traffic"].startswith("committed profile")
+    c = d["cpu_baseline"]
+    assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] in ("port", "reference") and len(c["sample"]) <= 160
+    assert len(d["per_rank_clips_s"]) == 8 and d["detail_file"] == "detail.json"
+    assert json.load(open(detail)) == full                                  # nothing is lost: the full record is in the detail file
+
+
+def test_roofline_frac_is_the_algorithmic_fraction():
+    """`roofline.frac` of the split-f16 product kernel = 2MNK of the fp32 products the reference asks for / time / the dense f16 peak (SURVEY
+    §8d's algorithmic work); the three-times-larger rate of the f16 products the kernel ISSUES is carried as `frac_issued`."""
+    bench = _bench_module()
+    B, J, C = 256, 17, 512
+    kernel_ms = {"gemm_lifter": 5.85, "gemm_gru_in": 0.52, "gemm_ada": 0.04, "gemm_final": 0.17, "ln_chain": 0.7}
+    launches = {"gemm_lifter": 25, "gemm_gru_in": 3, "gemm_ada": 1, "gemm_final": 1, "ln_chain": 13}
+    r = bench.dominant_kernel_roofline(kernel_ms, launches, B, J, C, "split_f16", clk_ghz=1.78)
+    work = sum(bench.class_work(c, B, J, C)[0] for c in bench.GEMM_CLASSES)
+    secs = (5.85 + 0.52 + 0.04 + 0.17) * 1e-3
+    assert r["kernel"] == "gemm_split_kernel" and r["bound"] == "mfma" and r["peak"] == 2500.0
+    assert abs(r["achieved"] - work / secs / 1e12) < 0.1 and abs(r["frac"] - work / secs / 1e12 / 2500.0) < 1e-3
+    assert abs(r["frac_issued"] - 3 * r["frac"]) < 2e-3 and abs(r["algorithmic_per_launch"] - work / 30) < 1.0
+
+
 def test_roofline_records_of_the_non_gemm_kernels():
     """bench.py's records for the HBM-bound attention kernel and the north-star cross-attention kernel: pure functions of the measured
     kernel times and of the committed PMC summaries (no GPU)."""

@@ -823,3 +823,29 @@ def test_other_depths_vs_oracle(depth):
     e = (maxabs(mesh, rm), maxabs(pose, rp), maxabs(pose3d, rl))
     print(f"depth {depth} vs oracle: mesh %.2e m, pose %.2e m, pose3d %.2e mm" % e)
     assert e[0] < TIGHT_M and e[1] < TIGHT_M and e[2] < TOL_MM
+
+
+def test_smaller_batch_after_a_larger_one_reuses_the_workspace():
+    """B = 130 then B = 128 on one engine.  The self-attention scratch used to make the workspace of 129..132 clips
+    SMALLER than that of 128, and the engine regrew by batch count: the second call failed check_ws.  Sizes are monotonic now, the engine
+    compares bytes, and the B = 128 result is bit-identical to a B = 128 call on a fresh engine's own workspace."""
+    from pmce_amd import synth
+    J, C = 17, 256
+    model = get_model(J, C)
+    model.set_gemm_mode("split_f16", min_batch=1)
+    try:
+        eng = model._engine
+        eng.ws = None
+        p, f = synth.make_inputs(130, J, 4242)
+        p, f = T(p).to(dev()), T(f).to(dev())
+        big = [t.clone() for t in model.forward_with_joints(p, f)]
+        n130 = eng.ws.numel()
+        small = [t.clone() for t in model.forward_with_joints(p[:128], f[:128])]       # must not raise PMCE_ERR_WORKSPACE
+        assert eng.ws.numel() >= eng.lib.pmce_model_workspace_bytes(eng.handle, 128) and eng.ws.numel() >= n130
+        eng.ws = None
+        fresh = [t.clone() for t in model.forward_with_joints(p[:128], f[:128])]
+        for a, b, c in zip(small, fresh, big):
+            assert torch.equal(a, b)
+            assert torch.equal(a, c[:128])                                             # and a clip's result does not depend on the batch
+    finally:
+        model.set_gemm_mode(None)

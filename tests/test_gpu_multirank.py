@@ -75,11 +75,11 @@ def test_bench_two_ranks_on_this_box():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--windows", "2", "--batch",
-                        "32", "--embed-dim", "256", "--cpu-seconds", "2"], cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+                        "32", "--embed-dim", "256", "--cpu-seconds", "2", "--sustained-seconds", "1", "--detail-file", "/tmp/pmce_bench_detail_2r.json"],
+                       cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = lines[0]
+    assert r.stdout.count("\n") == 1 and len(r.stdout) < 8192, r.stdout[:2000]     # ONE compact line is all of stdout
+    d = json.loads(r.stdout)
     print({k: d[k] for k in ("value", "n_gpus", "ms_per_step", "outputs_finite")})
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 64 and d["outputs_finite"] and d["value"] > 0
     assert d["roofline"] is not None and d["cpu_baseline"]["value"] > 0           # rank 0 times the CPU baseline at N > 1 as well
@@ -97,7 +97,32 @@ def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--windows", "2", "--cpu-seconds", "2"],
                        cwd=REPO, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
-    d = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert r.stdout.count("\n") == 1 and len(r.stdout) < 8192
+    d = json.loads(r.stdout)
     print({k: d[k] for k in ("value", "n_gpus", "ms_per_step", "per_rank_clips_s", "metric_reduction")})
     assert d["n_gpus"] == 2 and d["metric_reduction"]["backend"] == "nccl" and d["metric_reduction"]["clips_counted"] == 512
     assert d["outputs_finite"] and min(d["per_rank_clips_s"]) > 0.5 * max(d["per_rank_clips_s"])
+
+
+def test_bench_eight_ranks_dry_run_prints_one_compact_line():
+    """Dry run of the line the driver's 8-GPU scaling run will parse: eight ranks share this box's one device (gloo for the
+    metric reduction), tiny batch.  Asserted: stdout is ONE line under 8 KB that parses, n_gpus 8, eight entries per per-rank list, roofline
+    and cpu_baseline present; the detail file holds the full record.  No scaling number is read off this."""
+    env = dict(os.environ, PMCE_BENCH_SHARE_GPU="1", PMCE_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    detail = "/tmp/pmce_bench_detail_8r.json"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1", "--windows", "1", "--batch", "8",
+                        "--embed-dim", "256", "--cpu-seconds", "1", "--sustained-seconds", "1", "--detail-file", detail],
+                       cwd=REPO, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.count("\n") == 1 and len(r.stdout) < 8192, r.stdout[:2000]
+    d = json.loads(r.stdout)
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 64 and d["outputs_finite"] and d["value"] > 0
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0 and d["config"]["workload"] and d["dtype"] == "f32"
+    assert len(d["per_rank_clips_s"]) == 8 and all(v > 0 for v in d["per_rank_clips_s"])
+    assert d["metric_reduction"] == {"clips_counted": 64, "backend": "gloo"}
+    full = json.load(open(detail))
+    for k in ("per_rank_clips_s", "per_rank_ms_per_step", "per_rank_sustained_clock_ghz", "per_rank_weights_load_s", "per_rank_first_step_s"):
+        assert len(full[k]) == 8, k
+    assert full["value"] == d["value"] and full["kernel_ms_per_step"]
