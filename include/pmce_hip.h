@@ -235,7 +235,9 @@ int pmce_gemm_nt_split_f16_rowmap(const float* A, const float* Wp, const float* 
  * A[m] * 2^-e(m) (Ap: M*K floats of storage) and rscale[m] = 2^e(m), e(m) lifting the row's largest |a| into [2^14, 2^15) - the
  * per-row treatment pmce_gemm_pack_split_f16 gives W.  pmce_gemm_nt_split_f16_rs multiplies such an A:
  * C[m][n] = 2^e(m) 2^-s(n) (Ahi Whi + Ahi Wlo + Alo Whi) + bias[n]; c_div > 0 maps the output rows as in _rowmap (ldc == N then).
- * Rows holding inf / nan keep e = 0 and yield non-finite results in their own row only. */
+ * Rows holding inf / nan keep e = 0 and yield non-finite results in their own row only.
+ * A row-scaled product needs K >= 128 (K = 32 .. 127 returns PMCE_ERR_ARG: the kernels read a tile's row scales after its last k-tile while
+ * the LDS-DMA cursor runs up to three k-tile stages ahead; every row-scaled product of the path has K = 2048). */
 int pmce_split_rows_scaled_f16(const float* A, long long M, int K, long long lda, float* Ap, float* rscale, pmce_stream_t stream);
 int pmce_gemm_nt_split_f16_rs(const float* Ap, const float* rscale, const float* Wp, const float* wscale, const float* bias, float* C,
                               int M, int N, int K, long long ldc, int c_div, long long c_lo, long long c_hi, pmce_stream_t stream);

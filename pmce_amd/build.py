@@ -18,7 +18,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # in the matrix phase.  No packed-fp32 instruction is generated for ANY kernel of the library, which is what allows its kernels to
 # overlap each other (two streams inside a forward, pipeline lanes); tests/test_host_logic.py checks the device code.
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-FILE_FLAGS = {src: NO_PACKED_FP32 for src in SOURCES if src.endswith(".hip")}
+# PMCE_PACKED_FP32_FILES="coevo.hip,..." (A/B builds only, scripts/build_ab.sh): compile those files WITH compiler-chosen packed fp32
+_PACKED_AB = {f for f in os.environ.get("PMCE_PACKED_FP32_FILES", "").split(",") if f}
+FILE_FLAGS = {src: ([] if src in _PACKED_AB else NO_PACKED_FP32) for src in SOURCES if src.endswith(".hip")}
 
 # The diagnostics library (NOT the product): the bystander kernels of the matrix-pipe interference report, which ARE packed-fp32 code on
 # purpose, and the f16-subnormal probe.  (The two experimental split-GEMM variants it carried until round 4 - wave-specialised 192x256,
@@ -46,7 +48,7 @@ def source_id() -> str:
         h.update(f.encode())
         with open(osp.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS + NO_PACKED_FP32 + os.environ.get("PMCE_EXTRA_HIPCC_FLAGS", "").split()).encode())
+    h.update(" ".join(FLAGS + NO_PACKED_FP32 + os.environ.get("PMCE_EXTRA_HIPCC_FLAGS", "").split() + sorted(_PACKED_AB)).encode())
     return h.hexdigest()[:16]
 
 

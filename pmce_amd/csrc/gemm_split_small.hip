@@ -237,7 +237,7 @@ static int small_nwn_for(int M, int N) {
 bool pmce_gemm_split_small_applies(int M, int N, int K, int act, bool apack, bool opack, bool res, bool rs) {
   if (K % 32 != 0 || K < 64) return false;
   if (small_nwn_for(M, N) == 0) return false;
-  if (rs) return true;
+  if (rs) return K >= 128;  // (the row-scaled form's documented limit, enforced by gemm_split_any before either kernel is chosen)
   if (opack) return act == 1;
   if (apack) return act == 0;
   return act == 0 && !res;

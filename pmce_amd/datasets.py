@@ -104,13 +104,19 @@ def load_pw3d(data_path: str, split: str = "test") -> FrameTable:
         img = images[ann["image_id"]]
         seq, name, pid = img["sequence"], img["file_name"], ann["person_id"]
         s, i, p = str(seq), str(int(name[6:-4])), str(int(pid))
+        # the three joint tables are indexed BEFORE the feature lookup, as the reference does (PW3D/dataset.py:144-151): a frame missing
+        # from them raises (KeyError, as there) even when it has no feature either; only a missing FEATURE skips the annotation
+        jc, ji, jh = coco_cam[s][i][p], gt_img[s][i][p], h36m_cam[s][i][p]
         feat = raw_feats.get(f"{s}_{p}_{i}")
         if feat is None:
             skipped += 1
             continue
+        aid = str(int(ann["id"]))
+        if aid not in det:
+            raise ValueError(f"vitpose_3dpw_{split}_output.json holds no detection for annotation id {aid} ({seq}/{name}, person {pid})")
         sp = ann["smpl_param"]
-        rows.append((osp.join(str(pid), seq, name), seq + str(pid), (img["height"], img["width"]), det[str(int(ann["id"]))],
-                     feat, h36m_cam[s][i][p], coco_cam[s][i][p], gt_img[s][i][p], sp["pose"], sp["shape"], sp["trans"], sp["gender"]))
+        rows.append((osp.join(str(pid), seq, name), seq + str(pid), (img["height"], img["width"]), det[aid],
+                     feat, jh, jc, ji, sp["pose"], sp["shape"], sp["trans"], sp["gender"]))
     cols = list(zip(*rows))
     img_paths = np.array(cols[0])
     perm = np.argsort(img_paths)
@@ -243,6 +249,13 @@ def window_frames(win: np.ndarray, seqlen: int = 16) -> np.ndarray:
     win = np.asarray(win).reshape(-1, 2)
     step = (win[:, 1] != win[:, 0]).astype(np.int64)
     return win[:, :1] + step[:, None] * np.arange(seqlen)[None, :]
+
+
+def window_mid(win: np.ndarray, seqlen: int = 16) -> np.ndarray:
+    """Frame index whose targets a window carries: its middle frame, or the one repeated frame of a start == end window
+    (Human36M/dataset.py:737-740, PW3D/dataset.py:245-251) - the same rule as :func:`window_frames`."""
+    win = np.asarray(win).reshape(-1, 2)
+    return win[:, 0] + (seqlen // 2) * (win[:, 1] != win[:, 0])
 
 
 def window_batch(pose2d_frames, feat_frames, win, seqlen: int = 16):

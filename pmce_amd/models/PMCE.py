@@ -269,9 +269,10 @@ class Pipeline:
         for st in self.streams:
             st.synchronize()
         main = self._main
-        if main is None or not main.overflowed():
-            self._recent.clear()
+        if main is None or not (main.overflowed() or self.model._overflow_carried):     # (carried: a "rerun" forward() took an earlier report
+            self._recent.clear()                                                         #  out of the word - it is still this drain's to name)
             return []
+        self.model._overflow_carried = False
         recent = [t for t in ((r if isinstance(r, Pipeline.Ticket) else r()) for r in self._recent) if t is not None]
         bad = [t for t in recent if not all(bool(torch.isfinite(o).all()) for o in t.outputs if o is not None)]
         main.clear_overflow()

@@ -119,7 +119,8 @@ def split_rows_scaled_f16(A):
 
 
 def gemm_nt_split_rs(Ap, rscale, Wp, wscale, bias=None, out=None, rowmap=None):
-    """The three-product f16 GEMM on a row-scaled packed A (raw inputs: img_feat).  rowmap = (c_div, c_lo, c_hi) maps output rows."""
+    """The three-product f16 GEMM on a row-scaled packed A (raw inputs: img_feat).  rowmap = (c_div, c_lo, c_hi) maps output rows.
+    K >= 128 (include/pmce_hip.h at pmce_gemm_nt_split_f16_rs)."""
     lib = _lib.load()
     M, K = Ap.shape
     N = Wp.shape[0]

@@ -221,6 +221,7 @@ class HipModuleBase(nn.Module):
         self._split_min_batch = None
         self._overflow_policy = None   # None = "rerun" (or "strict" under PMCE_STRICT_OVERFLOW=1): see set_overflow_policy
         self.overflow_reruns = 0       # calls that were computed again on the fp32 pipe under the "rerun" policy
+        self._overflow_carried = False  # a report of EARLIER asynchronous work that a "rerun" call took out of the shared word (see _guarded)
 
     def set_gemm_mode(self, mode, min_batch=None):
         """Arithmetic of the large products (min_batch: calls with fewer clips stay on the fp32 pipe, default 1 = none): 'split_f16' (three f16 products per fp32 product on the f16 matrix
@@ -254,7 +255,7 @@ class HipModuleBase(nn.Module):
         eng = self._ensure_packed()
         if synchronize:
             torch.cuda.synchronize(eng.device)
-        return eng.overflowed()
+        return eng.overflowed() or self._overflow_carried
 
     OVERFLOW_POLICIES = ("rerun", "report", "strict")
 
@@ -288,13 +289,25 @@ class HipModuleBase(nn.Module):
         return self._overflow_policy
 
     def clear_overflow(self):
+        self._overflow_carried = False
         self._ensure_packed().clear_overflow()
 
     def _guarded(self, launch, eng=None):
-        """launch(engine) -> outputs, under the module's overflow policy (see set_overflow_policy)."""
+        """launch(engine) -> outputs, under the module's overflow policy (see set_overflow_policy).
+
+        The overflow word is shared by every engine on these weights (pipeline lanes) and sticky.  A word that is ALREADY set when a
+        "rerun" call starts belongs to earlier asynchronous work (a "report"-mode call, a lane): it must neither trigger a re-run of
+        THIS batch on the fp32 pipe (its numbers would then depend on what ran before it) nor be erased unseen.  It is moved into
+        ``_overflow_carried`` - still reported by :meth:`overflowed` and ``Pipeline.synchronize`` until :meth:`clear_overflow` - and the
+        word is cleared before the launch, so that only this call's products can set it."""
         eng = eng or self._ensure_packed()
+        rerun = self.overflow_policy() == "rerun" and eng.gemm_mode() == "split_f16" and not torch.cuda.is_current_stream_capturing()
+        if rerun and eng.overflowed():
+            torch.cuda.current_stream(eng.device).synchronize()
+            self._overflow_carried = True
+            eng.clear_overflow()
         out = launch(eng)
-        if self.overflow_policy() != "rerun" or eng.gemm_mode() != "split_f16" or torch.cuda.is_current_stream_capturing():
+        if not rerun:
             return out
         st = torch.cuda.current_stream(eng.device)
         st.synchronize()

@@ -59,7 +59,7 @@ def main():
         table = datasets.load_pw3d(args.data_dir, args.split) if args.dataset == "pw3d" else datasets.load_h36m(args.data_dir, args.split)
         win = table.windows(16, 1)
         if args.dataset == "h36m":                                      # Human36M.evaluate skips every sample whose middle frame is not camera 4
-            win = win[table.cam_idxs[win[:, 0] + 8] == 4]               # (data/Human36M/dataset.py:742-744): they are not run at all here
+            win = win[table.cam_idxs[datasets.window_mid(win)] == 4]               # (data/Human36M/dataset.py:742-744): they are not run at all here
         args.clips, args.joints = len(win), 19 if args.dataset == "pw3d" else 17
     rank, local, world = sharding.init_from_env()
     if os.environ.get("PMCE_BENCH_SHARE_GPU"):      # plumbing runs of the N > 1 path on a box with fewer GPUs (ranks share devices)
@@ -82,7 +82,7 @@ def main():
     seq_ids = np.arange(args.clips) // args.seq_len
     if table is not None:
         from pmce_amd import datasets
-        mid = win[:, 0] + 8                                             # the window's middle frame carries the targets (dataset.py:245-251)
+        mid = datasets.window_mid(win)                                         # the window's middle frame carries the targets (dataset.py:245-251)
         seq_ids = table.sequence_ids()[mid]
         pose_fr, feat_fr = table.pose2d(dev), table.features_on(dev)    # per-frame tables, uploaded once (8 KB per frame, not 16 x per window)
         gt_joints = torch.from_numpy(table.gt_joints_root_relative()[mid]).to(dev)

@@ -849,3 +849,37 @@ def test_smaller_batch_after_a_larger_one_reuses_the_workspace():
             assert torch.equal(a, c[:128])                                             # and a clip's result does not depend on the batch
     finally:
         model.set_gemm_mode(None)
+
+
+def test_a_stale_overflow_report_does_not_rerun_the_next_call():
+    """the overflow word is sticky and shared with the pipeline lanes.  A word left set by an EARLIER asynchronous call
+    ("report" policy; here a clip with a NaN input) must not make the next "rerun"-policy forward of CLEAN clips re-run on the fp32 pipe
+    (its numbers would depend on what ran before it), and must not be erased unseen: it stays visible through overflowed() until
+    clear_overflow()."""
+    from pmce_amd import synth
+    J, C, B = 17, 256, 2
+    model = get_model(J, C)
+    model.set_gemm_mode("split_f16", min_batch=1)
+    try:
+        p, f = synth.make_inputs(B, J, 31)
+        p, f = T(p).to(dev()), T(f).to(dev())
+        model.set_overflow_policy("rerun")
+        model.clear_overflow()
+        clean = [t.clone() for t in model(p, f)]
+        n0 = model.overflow_reruns
+        fbad = f.clone()
+        fbad[0, 3, 7] = float("nan")
+        model.set_overflow_policy("report")
+        model(p, fbad)
+        assert model.overflowed()                                   # the report of the asynchronous call
+        model.set_overflow_policy("rerun")
+        again = model(p, f)
+        assert model.overflow_reruns == n0                          # not re-run: the word was not this call's
+        assert all(torch.equal(a, b) for a, b in zip(again, clean))
+        assert model.overflowed()                                   # and the earlier report is still there to be read
+        model.clear_overflow()
+        assert not model.overflowed()
+    finally:
+        model.set_overflow_policy("rerun")
+        model.clear_overflow()
+        model.set_gemm_mode(None)
