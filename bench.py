@@ -767,6 +767,12 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    # stdout carries the record and nothing else: libraries write there too (gloo prints "[Gloo] Rank 0 is connected ..." on stdout, RCCL its
+    # NCCL_DEBUG lines).  File descriptor 1 is pointed at stderr for the rest of the process; the record goes to a private copy of the real one.
+    global _RECORD_OUT
+    sys.stdout.flush()
+    _RECORD_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     # The second complete record (the other pose-encoder width) is measured by a CHILD process running this same script,
     # BEFORE this process touches the GPU: a second model in one process shares HIP's few hardware queues with the first
@@ -852,9 +858,9 @@ def main():
         tmax = sharding.reduce_max(float(rank), cdev)
         sharding.barrier()
         if rank == 0:
-            print(json.dumps({"dist_check": True, "n_gpus": world, "backend": dist.get_backend() if world > 1 else None,
+            _print_record(json.dumps({"dist_check": True, "n_gpus": world, "backend": dist.get_backend() if world > 1 else None,
                               "clips": int(tot[0].item()), "ranks": int(tot[1].item()), "gathered": int(rows.shape[0]),
-                              "max_rank": int(tmax)}), flush=True)
+                              "max_rank": int(tmax)}))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -917,6 +923,15 @@ def main():
         import torch.distributed as dist
         sharding.barrier()        # (rank 0 timed the CPU baseline meanwhile)
         dist.destroy_process_group()
+
+
+_RECORD_OUT = None       # the process's real stdout (main() points fd 1 at stderr so that library chatter cannot share a stream with the record)
+
+
+def _print_record(text: str):
+    out = _RECORD_OUT or sys.stdout
+    out.write(text + "\n")
+    out.flush()
 
 
 COMPACT_LIMIT = 4096     # bytes; the round driver keeps only a few KB of stdout (BENCH_r05.json: a 24.7 KB line came back unparsed)
@@ -990,7 +1005,7 @@ def emit(full: dict, detail_file: str | None):
             sys.stderr.write(f"[bench] could not write {detail_file}: {e}\n")
             detail_file = None
     sys.stderr.write(f"[bench] full record ({len(json.dumps(full))} bytes): {detail_file}\n")
-    print(json.dumps(compact_record(full, detail_file)), flush=True)
+    _print_record(json.dumps(compact_record(full, detail_file)))
 
 
 if __name__ == "__main__":

@@ -24,6 +24,7 @@ def test_bench_spawns_its_own_ranks():
     r, lines = _run([sys.executable, "bench.py", "--gpus", "2", "--dist-check"])
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1, r.stdout                       # rank 0 only
+    assert r.stdout.count("\n") == 1 and r.stdout.startswith("{")      # and NOTHING else on stdout (gloo's own "[Gloo] Rank 0 is connected" goes to stderr)
     d = lines[0]
     assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["backend"] == "gloo"
     assert d["clips"] == 1000 and d["gathered"] == 1000 and d["max_rank"] == 1

@@ -834,11 +834,12 @@ def test_smaller_batch_after_a_larger_one_reuses_the_workspace():
     model = get_model(J, C)
     model.set_gemm_mode("split_f16", min_batch=1)
     try:
-        eng = model._engine
+        eng = model._ensure_packed()                    # (set_gemm_mode rebuilds the engine lazily: take the one the calls below use)
         eng.ws = None
         p, f = synth.make_inputs(130, J, 4242)
         p, f = T(p).to(dev()), T(f).to(dev())
         big = [t.clone() for t in model.forward_with_joints(p, f)]
+        assert model._engine is eng
         n130 = eng.ws.numel()
         small = [t.clone() for t in model.forward_with_joints(p[:128], f[:128])]       # must not raise PMCE_ERR_WORKSPACE
         assert eng.ws.numel() >= eng.lib.pmce_model_workspace_bytes(eng.handle, 128) and eng.ws.numel() >= n130
