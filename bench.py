@@ -824,13 +824,13 @@ def main():
         # 3DPW-sized clip-sharded evaluation (35,515 clips, COCO input J = 19: forward + on-device metrics + the one reduction)
         # and the stride-1 streaming of one long sequence (frame reuse + acceleration error), both on synthetic stand-ins
         other_configs["config_decoder_b64"] = script_record(
-            "decoder_bench.py", ["--batch", "64", "--steps", "50"], "BASELINE configs[1]: CoEvoDecoder-only forward, batch 64, 1 GPU")
+            "decoder_bench.py", ["--batch", "64", "--steps", "50", "--min-seconds", "5"], "BASELINE configs[1]: CoEvoDecoder-only forward, batch 64, 1 GPU")
         other_configs["config_eval_sharded_j19"] = script_record(
-            "eval_sharded.py", ["--clips", "35515", "--joints", "19"],
+            "eval_sharded.py", ["--clips", "35515", "--joints", "19", "--min-seconds", "5"],
             "BASELINE configs[3] stand-in: 35,515 clips (3DPW test-set size), J = 19, forward + on-device MPJPE / PA-MPJPE / MPVPE / accel + "
             "the final reduction; this rank count's shard of the clip range")
         other_configs["config_streaming"] = script_record(
-            "stream_bench.py", ["--frames", "16384"],
+            "stream_bench.py", ["--frames", "16384", "--min-seconds", "5"],
             "BASELINE configs[4] stand-in: one 16,384-frame sequence, stride-1 T = 16 windows with per-frame reuse, acceleration error on the device")
         C2 = 256 if C == 512 else 512
         variant = child_record(["--embed-dim", str(C2), "--gemm-mode", args.gemm_mode], True, sus=args.sustained_seconds / 2)

@@ -423,7 +423,10 @@ int pmce_j_regress_f32(const float* mesh, const int* indptr, const int* indices,
 /* Per sample b: mpvpe[b] = mean_v ||(pm*scale - rp) - (gm*scale - rg)||; joints P = pj - rowsum*rp (if rowsum), minus
  * joint root_j, restricted to eval_idx (int32[n_eval]); mpjpe[b] = mean ||P-G||; pampjpe[b] after rigid_align
  * (lib/coord_utils.py:151-173, fp64).  rp/rg NULL -> mesh roots are the samples' own joint root_j (compute_both_err).
- * out_pe/out_ge (optional, [B,n_eval,3]) receive the aligned eval joints for pmce_accel_error_f32. */
+ * out_pe/out_ge (optional, [B,n_eval,3]) receive the aligned eval joints for pmce_accel_error_f32.
+ * V == 0 (pm, gm, rp, rg, rowsum NULL): joints only - the pose-only flavours compute_joint_err / evaluate_joint
+ * (data/Human36M/dataset.py:600-713: root 0, the 14 eval joints; data/PW3D/dataset.py:260-349: COCO set, root = joint J-2, every joint)
+ * and MPII3D.evaluate (data/MPII3D/dataset.py:539-624: root 0, all 17 joints); mpvpe[b] = 0 then. */
 int pmce_sample_errors_f32(const float* pm, const float* gm, float scale, int V, const float* rp, const float* rg,
                            const float* pj, const float* gj, int NJ, const float* rowsum, const int* eval_idx, int n_eval,
                            int root_j, float* out_mpvpe, float* out_mpjpe, float* out_pampjpe, float* out_pe, float* out_ge,

@@ -96,3 +96,53 @@ def evaluate_samples(mesh_out, mesh_gt, reg_root, root_idx, reg_h36m, seq_ids, e
             start = n
     return dict(mpvpe=mpvpe, mpjpe=mpjpe, pampjpe=pampjpe, MPJPE=np.mean(mpjpe), PA_MPJPE=np.mean(pampjpe),
                 MPVPE=np.mean(mpvpe), ACCEL=acc / N, pred_j=P, gt_j=G)
+
+
+# ---- pose-only flavours (lifter evaluation, LiftTester.test lib/core/base.py:342-387) and MPII3D ------------------------------------------
+# (joint set, root joint, evaluated joints) of the three reference implementations:
+POSE_FLAVOURS = {
+    "pose_h36m": dict(root=0, eval_joint=H36M_EVAL_JOINT),         # Human36M/dataset.py:600-609,625-713 (+ camera-4 filter in evaluate_joint)
+    "pose_pw3d": dict(root=-2, eval_joint=None),                   # PW3D/dataset.py:260-267,284-349: COCO set (19), root [-2:-1], every joint
+    "mpii3d": dict(root=0, eval_joint=None),                       # MPII3D/dataset.py:539-547,560-624: 17 joints, root 0, every joint
+}
+
+
+def compute_joint_err(pred_joint, target_joint, root=0, eval_joint=None):
+    """dataset.compute_joint_err: root-align both joint sets [B,J,3], (H36M: keep the eval joints,) mean per-joint L2 over the batch."""
+    root = root % pred_joint.shape[1]
+    pj, tj = pred_joint - pred_joint[:, root:root + 1, :], target_joint - target_joint[:, root:root + 1, :]
+    if eval_joint is not None:
+        pj, tj = pj[:, eval_joint, :], tj[:, eval_joint, :]
+    return np.sqrt(((pj - tj) ** 2).sum(axis=2)).mean()
+
+
+def evaluate_joint_samples(pred_j, gt_j, seq_ids, root=0, eval_joint=None, keep=None):
+    """Per-sample arithmetic of dataset.evaluate_joint / MPII3D.evaluate for joint sets [N,J,3] in mm: root alignment, (eval joints,) MPJPE,
+    PA-MPJPE after rigid_align, acceleration error per sequence with the end samples counted as 0.  keep: Human36M.evaluate_joint's camera-4
+    samples (:640-642,663-665) - the others take part nowhere."""
+    pred_j, gt_j, seq_ids = np.asarray(pred_j, np.float64), np.asarray(gt_j, np.float64), np.asarray(seq_ids)
+    if keep is not None:
+        keep = np.asarray(keep, dtype=bool)
+        pred_j, gt_j, seq_ids = pred_j[keep], gt_j[keep], seq_ids[keep]
+    N, J = pred_j.shape[:2]
+    root = root % J
+    ej = list(range(J)) if eval_joint is None else list(eval_joint)
+    mpjpe, pampjpe = np.zeros((N, len(ej))), np.zeros((N, len(ej)))
+    P, G = [], []
+    for n in range(N):
+        po, pg = pred_j[n] - pred_j[n][root:root + 1], gt_j[n] - gt_j[n][root:root + 1]
+        po, pg = po[ej, :], pg[ej, :]
+        mpjpe[n] = np.sqrt(np.sum((po - pg) ** 2, 1))
+        pampjpe[n] = np.sqrt(np.sum((rigid_align(po, pg) - pg) ** 2, 1))
+        P.append(po); G.append(pg)
+    P, G = np.array(P), np.array(G)
+    acc, start = 0.0, 0
+    for n in range(1, N + 1):
+        if n == N or seq_ids[n] != seq_ids[start]:
+            L = n - start
+            a = np.zeros(L)
+            if L >= 3:
+                a[1:-1] = compute_error_accel(joints_pred=P[start:n], joints_gt=G[start:n])
+            acc += np.mean(a) * L
+            start = n
+    return dict(mpjpe=mpjpe, pampjpe=pampjpe, MPJPE=np.mean(mpjpe), PA_MPJPE=np.mean(pampjpe), ACCEL=acc / N, acc_sum=acc, pred_j=P, gt_j=G)

@@ -45,6 +45,8 @@ __device__ void jacobi3(double S[3][3], double V[3][3], double w[3]) {
 //   joints:      P = pj - rowsum*rp (if rowsum) ; P -= P[root_j] ; P = P[eval_idx]      (dataset.py:272,277 / :392-397)
 //   MPJPE = mean_j ||P - G|| ; PA-MPJPE = mean_j ||rigid_align(P, G) - G||               (:431-433, coord_utils.py:151-173)
 // rp / rg == nullptr  ->  roots are the samples' own joint root_j (compute_both_err semantics).
+// V == 0 (pm / gm unused, may be null)  ->  joints only: the pose-only flavours (compute_joint_err / evaluate_joint, Human36M/dataset.py:600-713,
+// PW3D/dataset.py:260-349; MPII3D.evaluate, MPII3D/dataset.py:539-624, whose compute_both_err reports a mesh error of 0); out_mpvpe = 0.
 __global__ __launch_bounds__(256) void sample_errors_kernel(const float* __restrict__ pm, const float* __restrict__ gm,
                                                             float scale, int V, const float* __restrict__ rp,
                                                             const float* __restrict__ rg, const float* __restrict__ pj,
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void sample_errors_kernel(const float* __restr
   if ((tid & 63) == 0) red[tid >> 6] = s;
   __syncthreads();
   if (tid != 0) return;
-  out_mpvpe[b] = (float)((red[0] + red[1] + red[2] + red[3]) / V);
+  out_mpvpe[b] = V > 0 ? (float)((red[0] + red[1] + red[2] + red[3]) / V) : 0.f;
 
   // ---- joints: one lane, fp64 ----
   double P[MAXJ][3], G[MAXJ][3];
@@ -217,11 +219,12 @@ extern "C" int pmce_sample_errors_f32(const float* pm, const float* gm, float sc
                                       const float* pj, const float* gj, int NJ, const float* rowsum, const int* eval_idx,
                                       int n_eval, int root_j, float* out_mpvpe, float* out_mpjpe, float* out_pampjpe,
                                       float* out_pe, float* out_ge, int B, hipStream_t stream) {
-  PMCE_REQUIRE(pm && gm && pj && gj && eval_idx && out_mpvpe && out_mpjpe && out_pampjpe, "sample_errors: null pointer");
+  PMCE_REQUIRE(((pm && gm) || V == 0) && pj && gj && eval_idx && out_mpvpe && out_mpjpe && out_pampjpe, "sample_errors: null pointer");
   PMCE_REQUIRE((rp == nullptr) == (rg == nullptr), "sample_errors: give both mesh roots or neither");
   PMCE_REQUIRE((out_pe == nullptr) == (out_ge == nullptr), "sample_errors: give both joint outputs or neither");
-  PMCE_REQUIRE(B > 0 && V > 0 && NJ > 0 && NJ <= MAXJ && n_eval >= 3 && n_eval <= MAXJ && root_j >= 0 && root_j < NJ,
-               "sample_errors: bad sizes (NJ, n_eval <= 32; n_eval >= 3)");
+  PMCE_REQUIRE(B > 0 && V >= 0 && NJ > 0 && NJ <= MAXJ && n_eval >= 3 && n_eval <= MAXJ && root_j >= 0 && root_j < NJ,
+               "sample_errors: bad sizes (NJ, n_eval <= 32; n_eval >= 3; V = 0 for joints only)");
+  PMCE_REQUIRE(V > 0 || (rp == nullptr && rowsum == nullptr), "sample_errors: joints only (V = 0) takes no mesh roots and no rowsum");
   hipLaunchKernelGGL(sample_errors_kernel, dim3(B), dim3(256), 0, stream, pm, gm, scale, V, rp, rg, pj, gj, NJ, rowsum,
                      eval_idx, n_eval, root_j, out_mpvpe, out_mpjpe, out_pampjpe, out_pe, out_ge);
   return pmce_check_launch("sample_errors");

@@ -66,6 +66,14 @@ class FrameTable:
         from .staging import mesh_window_table
         return mesh_window_table(list(self.img_paths), seqlen, stride, self.mid_valid)
 
+    def pose_windows(self, seqlen: int = 16, stride: int = 1) -> np.ndarray:
+        """``self.vid_indices`` of the reference's POSE-ONLY test configurations (cfg.MODEL.name == 'PoseEst'): Human3.6M uses
+        ``split_into_chunks_pose`` - no SMPL-fit filter (Human36M/dataset.py:99-100); 3DPW uses the mesh table there too (PW3D/dataset.py:61)."""
+        from .staging import pose_window_table
+        if self.cam_idxs is None:
+            return self.windows(seqlen, stride)
+        return pose_window_table(list(self.img_paths), seqlen, stride)
+
     def sequence_ids(self) -> np.ndarray:
         """int id of every frame's video (first appearance order): the grouping key of the acceleration error."""
         _, first, inv = np.unique(self.vid_names, return_index=True, return_inverse=True)

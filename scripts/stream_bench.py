@@ -15,6 +15,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--joints", type=int, default=17)
     ap.add_argument("--lanes", type=int, default=2)
+    ap.add_argument("--min-seconds", type=float, default=5.0, help="the sequence is streamed again and again until this much time has passed (at "
+                                                                   "least three passes); windows_per_s is the MEDIAN pass, `sustained` the whole run")
     args = ap.parse_args()
     from pmce_amd import assets, models, streaming, synth
     from pmce_amd.eval import Evaluator, RunningEval
@@ -33,10 +35,15 @@ def main():
         cache = streaming.precompute_frames(model, pose_fr, feat_fr)
         return streaming.stream_forward_cached(model, cache, windows=win, batch=args.batch, lanes=args.lanes)
     run(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    mesh, pose, pose3d = run()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    pass_s = []
+    t_all = time.perf_counter()
+    while len(pass_s) < 3 or time.perf_counter() - t_all < args.min_seconds:    # (one 16,384-frame sequence is 0.24 s: BASELINE configs[4] asks for SUSTAINED clips/s)
+        t0 = time.perf_counter()
+        mesh, pose, pose3d = run()
+        torch.cuda.synchronize()
+        pass_s.append(time.perf_counter() - t0)
+    total_s = time.perf_counter() - t_all
+    dt = float(np.median(pass_s))
     ev = Evaluator(dev)
     runev = RunningEval(ev)
     for a in range(0, len(win), 1024):
@@ -57,6 +64,9 @@ def main():
     kernel_ms = {k: round(v[0] / 3, 4) for k, v in prof.items() if v[1] > 0}
     launches = {k: int(v[1] // 3) for k, v in prof.items() if v[1] > 0}
     res.update({"frames": L, "windows": int(len(win)), "windows_per_s": round(len(win) / dt, 1), "ms_per_window_batch": round(dt / max(1, (len(win) + args.batch - 1) // args.batch) * 1e3, 4),
+                "passes": len(pass_s), "windows_per_s_min_max": [round(len(win) / max(pass_s), 1), round(len(win) / min(pass_s), 1)],
+                "sustained": {"windows_per_s": round(len(win) * len(pass_s) / total_s, 1), "seconds": round(total_s, 2),
+                              "what": "the whole sequence streamed back to back (per-frame precompute + window batches each pass)"},
                 "batch": args.batch, "lanes": args.lanes, "J": J, "gemm_mode": model.gemm_mode(),
                 "roofline": bench.dominant_kernel_roofline(kernel_ms, launches, nb, J, 256, model.gemm_mode(), streaming=True),
                 "kernel_ms_per_window_batch": {k: v for k, v in kernel_ms.items() if v > 0.01},

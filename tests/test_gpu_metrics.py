@@ -117,3 +117,41 @@ def test_running_eval_equals_one_shot(golden):
     for a, b in ((0, 6), (6, 10)):
         run.add(pm[a:b], gm[a:b], gj[a:b])
     assert run.finish(seqs, keep_global=cams == 4) == want
+
+
+def test_pose_only_flavours_match_reference(golden):
+    """Evaluator.compute_joint_err / evaluate_joint (and the MPII3D flavour's compute_both_err / evaluate) on the device against fixtures made
+    from the reference's own Human36M / PW3D / MPII3D functions (tests/golden/make_golden_metrics_pose.py), and RunningEval.add_joints batch
+    by batch == the one-shot call."""
+    from make_golden_metrics_pose import pose_inputs
+    from pmce_amd.eval import Evaluator, RunningEval
+    dev = torch.device("cuda:0")
+    z = golden("metrics_pose.npz")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    for name, J, seed, key, use_cam in (("pose_h36m", 17, 7, "h36m", True), ("pose_pw3d", 19, 7, "pw3d", False), ("mpii3d", 17, 9, "mpii3d", False)):
+        pred, gt, seq, cams = pose_inputs(J, seed=seed)
+        ev = Evaluator.for_flavour(name, dev)
+        keep = (cams == 4) if use_cam else None
+        want_err = float(z["mpii3d_both_joint"]) if name == "mpii3d" else float(z[f"{key}_joint_err"])
+        got_err = ev.compute_joint_err(t(pred), t(gt))
+        assert abs(got_err - want_err) < 1e-3, (name, got_err, want_err)
+        if name == "mpii3d":                                         # MPII3D.compute_both_err: the joints only, mesh error 0
+            assert ev.compute_both_err(None, None, t(pred), t(gt)) == (got_err, 0.0)
+        mj, pa, pe, ge = ev.joint_errors(t(pred), t(gt))
+        sel = keep if keep is not None else np.ones(len(seq), bool)
+        e_mj = np.abs(mj.cpu().numpy()[sel] - z[f"{key}_mpjpe"]).max()
+        e_pa = np.abs(pa.cpu().numpy()[sel] - z[f"{key}_pampjpe"]).max()
+        res = ev.evaluate_joint(t(pred), t(gt), seq, keep_global=keep)
+        print(name, f"per-sample vs reference: MPJPE {e_mj:.2e} PA-MPJPE {e_pa:.2e} mm;", res)
+        assert e_mj < 1e-3 and e_pa < 1e-3
+        assert res["MPVPE"] is None and res["samples"] == int(sel.sum())
+        assert abs(res["MPJPE"] - z[f"{key}_mpjpe"].mean()) < 1e-3 and abs(res["PA-MPJPE"] - z[f"{key}_pampjpe"].mean()) < 1e-3
+        assert abs(res["ACCEL"] * res["samples"] - float(z[f"{key}_acc_sum"])) < 1e-2
+        ref = MO.evaluate_joint_samples(pred, gt, seq, MO.POSE_FLAVOURS[name]["root"], MO.POSE_FLAVOURS[name]["eval_joint"], keep=keep)
+        assert abs(res["ACCEL"] - ref["ACCEL"]) < 1e-3 and abs(res["PA-MPJPE"] - ref["PA_MPJPE"]) < 1e-3
+        run = RunningEval(ev)
+        for a, b in ((0, 5), (5, 6), (6, len(seq))):
+            run.add_joints(t(pred[a:b]), t(gt[a:b]))
+        assert run.finish(seq, keep_global=keep) == res
+    with pytest.raises(ValueError):
+        Evaluator.for_flavour("pose_pw3d", dev).compute_joint_err(t(pred), t(gt))      # 17 joints given to the 19-joint COCO flavour

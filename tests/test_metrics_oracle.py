@@ -69,3 +69,34 @@ def test_h36m_flavour_matches_reference(golden):
     np.testing.assert_allclose(r["pampjpe"].mean(1), z["pampjpe"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(r["mpvpe"].mean(1), z["mpvpe"], rtol=0, atol=1e-4)
     assert abs(r["ACCEL"] * int(z["n"]) - float(z["acc_error_sum"])) < 1e-3
+
+
+def test_pose_only_flavours_match_the_reference(golden):
+    """The pose-only evaluation flavours of the oracle against fixtures made from the reference's own functions
+    (tests/golden/make_golden_metrics_pose.py): Human36M.compute_joint_err / evaluate_joint (camera-4 samples, 14 eval joints), PW3D's (COCO
+    set, root = joint [-2], every joint) and MPII3D.compute_both_err / evaluate (17 joints, root 0, every joint; mesh error 0)."""
+    sys.path.insert(0, osp.join(osp.dirname(osp.abspath(__file__)), "golden"))
+    from make_golden_metrics_pose import pose_inputs
+    z = golden("metrics_pose.npz")
+    # Human3.6M
+    pred, gt, seq, cams = pose_inputs(17)
+    f = MO.POSE_FLAVOURS["pose_h36m"]
+    assert abs(MO.compute_joint_err(pred, gt, f["root"], f["eval_joint"]) - float(z["h36m_joint_err"])) < 1e-3
+    r = MO.evaluate_joint_samples(pred, gt, seq, f["root"], f["eval_joint"], keep=cams == 4)
+    assert len(r["mpjpe"]) == int(z["h36m_n"]) == int((cams == 4).sum())
+    assert np.abs(r["mpjpe"].mean(1) - z["h36m_mpjpe"]).max() < 1e-4 and np.abs(r["pampjpe"].mean(1) - z["h36m_pampjpe"]).max() < 1e-4
+    assert abs(r["acc_sum"] - float(z["h36m_acc_sum"])) < 1e-3
+    # 3DPW (COCO joint set)
+    pred, gt, seq, _ = pose_inputs(19)
+    f = MO.POSE_FLAVOURS["pose_pw3d"]
+    assert abs(MO.compute_joint_err(pred, gt, f["root"], f["eval_joint"]) - float(z["pw3d_joint_err"])) < 1e-3
+    r = MO.evaluate_joint_samples(pred, gt, seq, f["root"], f["eval_joint"])
+    assert np.abs(r["mpjpe"].mean(1) - z["pw3d_mpjpe"]).max() < 1e-4 and np.abs(r["pampjpe"].mean(1) - z["pw3d_pampjpe"]).max() < 1e-4
+    assert abs(r["acc_sum"] - float(z["pw3d_acc_sum"])) < 1e-3
+    # MPI-INF-3DHP
+    pred, gt, seq, _ = pose_inputs(17, seed=9)
+    f = MO.POSE_FLAVOURS["mpii3d"]
+    assert abs(MO.compute_joint_err(pred, gt, f["root"], f["eval_joint"]) - float(z["mpii3d_both_joint"])) < 1e-3 and float(z["mpii3d_both_mesh"]) == 0.0
+    r = MO.evaluate_joint_samples(pred, gt, seq, f["root"], f["eval_joint"])
+    assert np.abs(r["mpjpe"].mean(1) - z["mpii3d_mpjpe"]).max() < 1e-4 and np.abs(r["pampjpe"].mean(1) - z["mpii3d_pampjpe"]).max() < 1e-4
+    assert abs(r["acc_sum"] - float(z["mpii3d_acc_sum"])) < 1e-3
