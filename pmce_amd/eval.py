@@ -47,7 +47,10 @@ class Evaluator:
         self.lib = _lib.load()
         jr = assets.load_j_regressor("h36m") if j_regressor_h36m is None else np.asarray(j_regressor_h36m)
         self.jr = jr.astype(np.float32)
-        root = self.jr[root_joint] if root_regressor_row is None else np.asarray(root_regressor_row, dtype=np.float32)
+        # (a root joint beyond the regressor's rows is a joint of ANOTHER joint set - the COCO Pelvis of the pose-only 3DPW flavour - and has no
+        # regressor row: that flavour never touches a mesh)
+        root = (self.jr[root_joint if root_joint < self.jr.shape[0] else 0] if root_regressor_row is None
+                else np.asarray(root_regressor_row, dtype=np.float32))
         self.root_row = root.reshape(1, -1)
         self.rowsum = torch.from_numpy(self.jr.astype(np.float64).sum(1).astype(np.float32)).to(self.device)
         self.eval_idx = torch.tensor(list(eval_joint), dtype=torch.int32, device=self.device)
