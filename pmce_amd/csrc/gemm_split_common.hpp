@@ -41,6 +41,18 @@ __device__ __forceinline__ void sdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
       : "memory");
 }
 
+// The same with the LDS destination as base + compile-time offset - what the k-loop issues (round 6): ONE base scalar per stage instead of one live
+// scalar per instruction (the compiler had parked those in VGPR lanes and fetched each with a v_readlane per k-tile - vector instructions, which cost
+// matrix time on this chip).
+__device__ __forceinline__ void sdma16o(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff, unsigned lds_base, int imm) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(lds_base), "s"(soff), "n"(imm)
+      : "memory", "scc");
+}
+
 // fp32 -> (hi, lo * 2^11) f16
 __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, f16x8& hi, f16x8& lo) {
   const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};

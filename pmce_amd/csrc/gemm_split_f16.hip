@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
 #pragma unroll
     for (int q = 0; q < DPS; ++q) {
       const int g = wave + 4 * q;
-      if (g < GA)
+      if (q < GA / 4)   // (== g < GA: GA is a multiple of 4, so a wave's first GA / 4 instructions are A's whatever the wave)
         doff[q] = ((unsigned)min(mb + 16 * g + drow, p.M - 1) * p.lda + dchunk) * 4u;
       else {
         const unsigned r = (unsigned)min(nb + 16 * (g - GA) + drow, p.N - 1);
@@ -139,13 +139,14 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
   const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
   const int kstep_w = p.wblk ? 4096 : 64;  // bytes from one k-tile of a W row (block) to the next
   auto issue = [&](int kt, int stage) {
+    const unsigned stage_base = lds_wave + stage * (SF * 4);   // ONE scalar per k-tile: the instruction's slot is added as an immediate
 #pragma unroll
     for (int sub = 0; sub < KSUB; ++sub) {
       const int ko = (kt * KSUB + sub) * 64, kw = (kt * KSUB + sub) * kstep_w;  // bytes
 #pragma unroll
       for (int q = 0; q < DPS; ++q) {
-        const bool is_a = (wave + 4 * q) < GA;
-        sdma16(is_a ? rsrc_a : rsrc_w, doff[q], is_a ? ko : kw, lds_wave + stage * (SF * 4) + sub * (SUBF * 4) + q * 4096);
+        const bool is_a = q < GA / 4;   // compile-time: no run-time choice of descriptor and offset per instruction
+        sdma16o(is_a ? rsrc_a : rsrc_w, doff[q], is_a ? ko : kw, stage_base + sub * (SUBF * 4), q * 4096);
       }
     }
   };
