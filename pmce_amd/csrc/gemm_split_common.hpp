@@ -66,9 +66,24 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, f16x8& 
 __device__ __forceinline__ float pow2_recip(float x) { return __uint_as_float(0x7f000000u - __float_as_uint(x)); }
 
 // exponent field all ones: infinity or NaN
-__device__ __forceinline__ bool nonfinite(float v) { return __builtin_amdgcn_class(v, 0x203); }  // signalling / quiet NaN, -inf, +inf
+__device__ __forceinline__ bool nonfinite(float v) { return __builtin_amdgcn_class(v, 0x207); }  // signalling / quiet NaN, -inf, +inf (0x203, until round 6, lacked the -inf bit)
 __device__ __forceinline__ void report_nonfinite(unsigned* sink, bool lane_saw_one) {
   if (sink && __builtin_amdgcn_ballot_w64(lane_saw_one) != 0ull && (threadIdx.x & 63) == 0) *reinterpret_cast<volatile unsigned*>(sink) = 1u;
+}
+
+// One element of a PRE-SPLIT result: x -> (hi, lo * 2^11) f16 in one dword, exchanged with the neighbour lane (lane ^ 1) so that even lanes store
+// {hi(n), hi(n + 1)} and odd lanes {lo(n - 1), lo(n)} - the layout [16 hi | 16 lo] of a 16-column group.  perm_sel = split_perm_sel(lane).
+// Round 6: 20 instead of 25 vector instructions per element beside the GELU (v_pack_b32_f16, v_perm_b32, the class test on the f16 itself) -
+// the epilogue's vector work costs the CU's other workgroup matrix time.  The same bits as the shift / mask form it replaces.
+__device__ __forceinline__ unsigned split_perm_sel(int lane) { return (lane & 1) ? 0x03020706u : 0x05040100u; }
+__device__ __forceinline__ unsigned split_pack_exchange(float x, unsigned perm_sel, bool& bad) {
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  const _Float16 h = (_Float16)x;
+  bad = bad || __builtin_amdgcn_classh(h, 0x207);  // inf / nan: also a finite x beyond f16's 65504 - the next product could not read it
+  const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
+  const unsigned w = __builtin_bit_cast(unsigned, h2_t{h, l});
+  const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);  // lane ^ 1
+  return __builtin_amdgcn_perm(nbr, w, perm_sel);
 }
 
 template <int N>

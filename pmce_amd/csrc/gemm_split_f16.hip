@@ -349,6 +349,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
           layer_norm(p.ln2_w, p.ln2_b, p.ln2_eps);
           // pre-split [row][K/16][16 hi | 16 lo*2^11] f16 in the bytes of the fp32 row, as the OPACK epilogue writes it
           const bool odd = lane & 1;
+          const unsigned psel = split_perm_sel(lane);
           const int colf = (n0 >> 4) * 32 + (odd ? 16 + ((n0 - 1) & 15) : (n0 & 15));
           unsigned lane_pk = (unsigned)(wm * 32 + 4 * hb) * row_bytes + (unsigned)(wn * 128) * 4u + (unsigned)colf * 2u;
           asm volatile("" : "+v"(lane_pk));
@@ -357,13 +358,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
           for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float x = pinned(acc[0][j][r]);
-              const _Float16 h = (_Float16)x;
-              bad = bad || nonfinite((float)h);
-              const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
-              const unsigned w = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
-              const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);  // lane ^ 1
-              const unsigned outw = odd ? ((nbr >> 16) | (w & 0xffff0000u)) : ((w & 0xffffu) | (nbr << 16));
+              const unsigned outw = split_pack_exchange(pinned(acc[0][j][r]), psel, bad);
               const unsigned vo = lane_pk + (unsigned)((r & 3) + 8 * (r >> 2)) * row_bytes + (unsigned)(j * 32) * 4u;
               __builtin_amdgcn_raw_buffer_store_b32(outw, rsrc_x, vo, 0, 0);  // write-back: the next product's A operand (as ln_chain's out2)
             }
@@ -407,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
         // f16 in the bytes of the fp32 row.  A lane holds ONE column of 16 rows; adjacent lanes pair up (DPP quad_perm) so that
         // every lane still stores one dword per element: even lanes {hi(n), hi(n+1)}, odd lanes {lo(n-1), lo(n)}.
         const bool odd = lane & 1;
+        const unsigned psel = split_perm_sel(lane);
         const int colf = (n0 >> 4) * 32 + (odd ? 16 + ((n0 - 1) & 15) : (n0 & 15));  // f16 index inside the 32-column group
         // Buffer-form stores: 16 lane offsets (row r of a 32x32 block + this lane's f16 pair) serve every block; the block's position
         // is added to the lane offset (NOT passed as the scalar offset: the range check that drops the rows beyond M covers the
@@ -429,13 +425,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
               if (ACT == 1) v = gelu_erf2(v);
 #pragma unroll
               for (int e = 0; e < 2; ++e) {
-                const float x = pinned(e ? v.y : v.x);
-                const _Float16 h = (_Float16)x;
-                bad = bad || nonfinite((float)h);  // also a finite x beyond f16's 65504: the next product could not read it
-                const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
-                const unsigned w = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
-                const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);  // lane ^ 1
-                const unsigned outw = odd ? ((nbr >> 16) | (w & 0xffff0000u)) : ((w & 0xffffu) | (nbr << 16));
+                const unsigned outw = split_pack_exchange(pinned(e ? v.y : v.x), psel, bad);
                 __builtin_amdgcn_raw_buffer_store_b32(outw, rsrc_c, voff[r + e] + so, 0, 2);
               }
             }
