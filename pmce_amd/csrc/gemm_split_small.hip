@@ -170,6 +170,7 @@ __global__ __launch_bounds__(128 * NWN) void gemm_split_small_kernel(SplitParams
   } else if constexpr (OPACK) {
     // pre-split result [row][K/16][16 hi | 16 lo*2^11] f16 in the bytes of the fp32 row: adjacent lanes pair up (see gemm_split_kernel)
     const bool odd = lane & 1;
+    const unsigned psel = split_perm_sel(lane);
     const int colf = (n0 >> 4) * 32 + (odd ? 16 + ((n0 - 1) & 15) : (n0 & 15));
     const int cb = n_base + wn * 32;
     if (cb < p.N) {  // (N % 32 == 0: a 32-column block is all in or all out)
@@ -179,13 +180,7 @@ __global__ __launch_bounds__(128 * NWN) void gemm_split_small_kernel(SplitParams
         if (ACT == 1) v = gelu_erf2(v);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const float x = pinned(e ? v.y : v.x);
-          const _Float16 h = (_Float16)x;
-          bad = bad || nonfinite((float)h);
-          const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
-          const unsigned w = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
-          const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);  // lane ^ 1
-          const unsigned outw = odd ? ((nbr >> 16) | (w & 0xffff0000u)) : ((w & 0xffffu) | (nbr << 16));
+          const unsigned outw = split_pack_exchange(pinned(e ? v.y : v.x), psel, bad);   // (gemm_split_common.hpp: the persistent kernel's, bit for bit)
           const int mm = m_lane + ((r + e) & 3) + 8 * ((r + e) >> 2);
           if (mm < p.M) reinterpret_cast<unsigned*>(p.C + (size_t)mm * p.ldc + cb)[colf >> 1] = outw;
         }

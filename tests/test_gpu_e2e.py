@@ -884,3 +884,30 @@ def test_a_stale_overflow_report_does_not_rerun_the_next_call():
         model.set_overflow_policy("rerun")
         model.clear_overflow()
         model.set_gemm_mode(None)
+
+
+@pytest.mark.parametrize("mode", ["default", "f32"])
+def test_forward_batch16_matches_reference_fixture(golden, mode):
+    """The HIP path against the REFERENCE's own forward on sixteen clips (tests/golden/make_golden_batch.py): joints and the regressed joints in
+    full, the mesh at every 13th vertex, ALL vertices through the per-clip sum and sum of squares - in the default arithmetic (three-product
+    f16 form at this batch) and on the fp32 pipe."""
+    from pmce_amd import synth
+    z = golden("e2e_J17_C256_B16_subsampled.npz")
+    J, C, B, step = int(z["J"]), int(z["C"]), int(z["B"]), int(z["vertex_step"])
+    model = get_model(J, C)
+    model.set_gemm_mode(None if mode == "default" else "f32")
+    try:
+        assert np.array_equal(model.vj_relation, z["vj_relation"])
+        pose2d, img_feat = synth.make_inputs(B, J, int(z["input_seed"]))
+        mesh, pose, pose3d, pred = model.forward_with_joints(T(pose2d).to(dev()), T(img_feat).to(dev()))
+        torch.cuda.synchronize()
+    finally:
+        model.set_gemm_mode(None)
+    e = dict(mesh=maxabs(mesh[:, ::step], T(z["cam_mesh_sub"])), pose=maxabs(pose, T(z["cam_pose"])), pose3d_mm=maxabs(pose3d, T(z["pose3d"])),
+             pred_mm=maxabs(pred, T(z["pred_pose"])))
+    m64 = mesh.double().cpu()
+    e["mesh_sum"] = float((m64.sum(dim=(1, 2)) - T(z["mesh_sum"])).abs().max())
+    e["mesh_sumsq_rel"] = float(((m64 * m64).sum(dim=(1, 2)) / T(z["mesh_sumsq"]) - 1).abs().max())
+    print(f"B = 16 vs the reference ({mode}):", {k: f"{v:.2e}" for k, v in e.items()})
+    assert e["mesh"] < TIGHT_M and e["pose"] < TIGHT_M and e["pose3d_mm"] < TOL_MM and e["pred_mm"] < 1000 * TIGHT_M
+    assert e["mesh_sum"] < 0.05 and e["mesh_sumsq_rel"] < 1e-5

@@ -125,3 +125,20 @@ def test_fp32_noise_floor(golden):
         m64, p64, l64 = O.pmce_forward(sd, T(pose2d), T(img_feat), z["vj_relation"], dtype=torch.float64)
     print("fp32-vs-fp64: mesh %.2e m, pose %.2e m, pose3d %.2e mm" % (maxabs(m32, m64), maxabs(p32, p64), maxabs(l32, l64)))
     assert maxabs(m32, m64) < 1e-4 and maxabs(l32, l64) < 2e-2
+
+
+def test_e2e_batch16_matches_reference(golden):
+    """The reference's own forward on SIXTEEN clips (tests/golden/make_golden_batch.py; the other end-to-end fixtures are B <= 2): joints in full,
+    the mesh at every 13th vertex, every vertex through the per-clip float64 sum and sum of squares."""
+    z = golden("e2e_J17_C256_B16_subsampled.npz")
+    J, C, B, step = int(z["J"]), int(z["C"]), int(z["B"]), int(z["vertex_step"])
+    sd = cached_state_dict(J, C)
+    pose2d, img_feat = synth.make_inputs(B, J, int(z["input_seed"]))
+    with torch.no_grad():
+        mesh, pose, pose3d = O.pmce_forward(sd, T(pose2d), T(img_feat), z["vj_relation"])
+        pred = O.j_regress(mesh, assets.load_j_regressor("h36m"))
+    assert maxabs(mesh[:, ::step], z["cam_mesh_sub"]) < 2e-5 and maxabs(pose, z["cam_pose"]) < 2e-5
+    assert maxabs(pose3d, z["pose3d"]) < 5e-3 and maxabs(pred, z["pred_pose"]) < 2e-2              # millimetres
+    m64 = mesh.double()
+    assert maxabs(m64.sum(dim=(1, 2)), z["mesh_sum"]) < 2e-5 * 6890 * 3 * 0.05                      # (errors of 20,670 elements do not all align)
+    assert np.abs(np.asarray((m64 * m64).sum(dim=(1, 2))) / z["mesh_sumsq"] - 1).max() < 1e-5
