@@ -314,7 +314,7 @@ struct LifterWs {
   float *FS, *FR;  // split mode: the raw image features as row-scaled f16 planes [frames][2048] + 2^e per frame (prep_features)
 };
 struct DecoderWs {
-  float *GI0, *Y0, *GI1, *Y1, *GB, *VT[3], *JF[3], *KF[3], *S0[3], *VF[3], *CAI[3], *F1, *F2, *QKV, *KVJ, *FA, *JM;
+  float *GI0, *Y0, *Y0P, *GI1, *Y1, *GB, *VT[3], *JF[3], *KF[3], *S0[3], *VF[3], *CAI[3], *F1, *F2, *QKV, *KVJ, *FA, *JM;
 };
 
 void carve_lifter(Carver& c, const pmce_model* m, int B, LifterWs& w) {
@@ -330,6 +330,7 @@ void carve_lifter(Carver& c, const pmce_model* m, int B, LifterWs& w) {
 void carve_decoder(Carver& c, const pmce_model* m, int B, DecoderWs& w) {
   w.GI0 = c.take((size_t)T * B * 6 * GH);
   w.Y0 = c.take((size_t)T * B * 2 * GH);
+  w.Y0P = c.take((size_t)T * B * 2 * GH);  // the same rows pre-split (hi | lo*2^11 f16): the layer-1 projections' A operand in the split-f16 form
   w.GI1 = c.take((size_t)2 * 9 * B * 3 * GH);
   w.Y1 = c.take((size_t)T * B * 2 * GH);
   w.GB = c.take((size_t)B * N_ADA * 128);
@@ -582,10 +583,18 @@ int gru_rest(pmce_model* m, int B, DecoderWs& w, hipStream_t stream) {
     wih1_b.wp += (long long)3 * GH * 2 * GH;
     wih1_b.scale += 3 * GH;
   }
-  RUN(P_GEMM_GRU_IN, lgemm(m, w.Y0, m->w.wih1, m->s_wih1, m->w.bih1, nullptr, GI1f, 9 * B, 3 * GH, 2 * GH, 2 * GH,
-                           3 * GH, 0, stream));
-  RUN(P_GEMM_GRU_IN, lgemm(m, w.Y0 + (long long)8 * B * 2 * GH, m->w.wih1 + (long long)3 * GH * 2 * GH, wih1_b,
-                           m->w.bih1 + 3 * GH, nullptr, GI1b, 8 * B, 3 * GH, 2 * GH, 2 * GH, 3 * GH, 0, stream));
+  // Split-f16 form (round 6): layer 0's output is split ONCE (34 MB at B = 256, one HBM-rate pass) instead of inside the two products' k-loops,
+  // where splitting an fp32 operand costs 80 vector instructions per k-tile and wave - matrix time.  The same planes, the same results.
+  const bool y0_packed = m->split_now && m->s_wih1.wp;
+  const float* y0 = w.Y0;
+  if (y0_packed) {
+    RUN(P_GEMM_GRU_IN, pmce_split_rows_f16(w.Y0, (long long)T * B, 2 * GH, 2 * GH, w.Y0P, stream));
+    y0 = w.Y0P;
+  }
+  RUN(P_GEMM_GRU_IN, lgemm(m, y0, m->w.wih1, m->s_wih1, m->w.bih1, nullptr, GI1f, 9 * B, 3 * GH, 2 * GH, 2 * GH,
+                           3 * GH, 0, stream, y0_packed ? 1 : 0));
+  RUN(P_GEMM_GRU_IN, lgemm(m, y0 + (long long)8 * B * 2 * GH, m->w.wih1 + (long long)3 * GH * 2 * GH, wih1_b,
+                           m->w.bih1 + 3 * GH, nullptr, GI1b, 8 * B, 3 * GH, 2 * GH, 2 * GH, 3 * GH, 0, stream, y0_packed ? 1 : 0));
   PMCE_TRY(gru_layer(m, 1, GI1f, GI1b, 3 * GH, 0, T - 1, 9, 8, w.Y1, B, stream));
   const float* g = w.Y1 + (long long)8 * B * 2 * GH;  // img_feat = y[seqlen // 2], [B, 2048]
 
