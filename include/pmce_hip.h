@@ -267,6 +267,12 @@ int pmce_gemm_split_set_tuning(int tile);
 /* PoseEstimation.py:78-81 — x[tok] = joint_embed(pose2d) + imgfeat_embed(img_feat)[b,t] + spatial_pos[j]. */
 int pmce_embed_tokens_f32(const float* pose2d, const float* E, const float* Wje, const float* bje, const float* spos,
                           float* x, long long ntok, int J, int C, pmce_stream_t stream);
+/* The same followed by LayerNorm(w2, b2, eps2) of every token row (SpatialBlocks[0].norm1, PoseEstimation.py:13-29 via :83) in ONE launch:
+ * x = the tokens (fp32 [ntok, C]), xn = their LayerNorm - fp32, or pre-split [row][C/16][16 hi | 16 lo*2^11] f16 when xn_split (the operand of a
+ * three-product f16 GEMM).  Bit-identical to pmce_embed_tokens_f32 + pmce_ln_chain_ex_f32(out2).  C = 256 or 512. */
+int pmce_embed_ln_f32(const float* pose2d, const float* E, const float* Wje, const float* bje, const float* spos, float* x,
+                      long long ntok, int J, int C, const float* w2, const float* b2, float eps2, float* xn, int xn_split,
+                      pmce_stream_t stream);
 /* nn.LayerNorm chain over rows of C channels: y1 = (w1 ? LN(x;w1,b1,eps1) : x) + add[(row/add_div)%add_mod];
  * out1 = y1 (optional); out2 = LN(y1;w2,b2,eps2) (optional).  norm1/norm2/norm_s/norm_t (PoseEstimation.py:17,23,58-59). */
 /* _ex forms: out2 / out / XN written pre-split ([row][C/16][16 hi | 16 lo*2^11] f16 in the bytes of the fp32 row), i.e. directly as
@@ -294,6 +300,11 @@ int pmce_seq_attention_f32(const float* qkv, float* out, int nseq, int N, int C,
 /* PoseEstimation.py:62-66,109-113 — LayerNorm(1e-5) + Linear(C->3) + Conv2d(T->1) frame fusion. */
 int pmce_lifter_head_f32(const float* x, const float* lnw, const float* lnb, const float* Wr, const float* br,
                          const float* wf, const float* bf, float* pose3d, int B, int T, int J, int C, pmce_stream_t stream);
+/* prew != NULL: x is the LAST TemporalBlock's output BEFORE its post-norm, and every row passes through LayerNorm(prew, preb, pre_eps) (norm_t,
+ * PoseEstimation.py:92) on the way in - bit-identical to pmce_ln_chain_f32(out1) followed by pmce_lifter_head_f32, without the launch and the round trip. */
+int pmce_lifter_head_ex_f32(const float* x, const float* prew, const float* preb, float pre_eps, const float* lnw, const float* lnb,
+                            const float* Wr, const float* br, const float* wf, const float* bf, float* pose3d, int B, int T, int J, int C,
+                            pmce_stream_t stream);
 
 /* Fused nn.GRU time step for ndir directions: gh = h_prev W_hh^T + b_hh on the matrix cores, then the gate update
  * (CoevoDecoder.py:216-221); gi = W_ih x + b_ih comes from pmce_gemm_nt_f32.  hp == NULL means h_prev = 0. */

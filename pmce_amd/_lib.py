@@ -78,9 +78,11 @@ PROTOTYPES = {
     "pmce_gemm_nt_split_f16_rowmap": [_f, _f, _f, _f, _f, _i, _i, _i, _l, _i, _l, _l, _s],
     "pmce_gemm_split_set_tuning": [_i],
     "pmce_embed_tokens_f32": [_f, _f, _f, _f, _f, _f, _l, _i, _i, _s],
+    "pmce_embed_ln_f32": [_f, _f, _f, _f, _f, _f, _l, _i, _i, _f, _f, _fl, _f, _i, _s],
     "pmce_ln_chain_f32": [_f, _l, _i, _f, _f, _fl, _f, _i, _i, _f, _f, _f, _fl, _f, _s],
     "pmce_seq_attention_f32": [_f, _f, _i, _i, _i, _i, _l, _l, _l, _s],
     "pmce_lifter_head_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _s],
+    "pmce_lifter_head_ex_f32": [_f, _f, _f, _fl, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _s],
     "pmce_gru_step_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _l, _l, _i, _i, _i, _s],
     "pmce_gru_step_split_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _l, _l, _i, _i, _i, _s],
     "pmce_gru_step_split_blk_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _l, _l, _i, _i, _i, _s],

@@ -132,6 +132,55 @@ __global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Token embedding + the first LayerNorm in one pass (round 6): embed_tokens followed by ln_chain(out2 = norm1 of SpatialBlocks[0]) wrote the
+// tokens and read them straight back (143 MB at B = 256, C = 512).  One wavefront per token computes the row in registers - lane l holds
+// channels 256 i4 + 4 l + [0, 4) as ln_chain does -, stores it (x: the residual stream) and stores its LayerNorm (xn: the first product's A
+// operand, pre-split when xn_split).  The same operations in the same order as the two kernels: bit-identical.
+// ------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__ pose2d, const float* __restrict__ E,
+                                                       const float* __restrict__ Wje, const float* __restrict__ bje,
+                                                       const float* __restrict__ spos, float* __restrict__ x, long long ntok, int J,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2, float eps2,
+                                                       float* __restrict__ xn, int xn_split) {
+  constexpr int NV = C / 64;
+  const int lane = threadIdx.x & 63;
+  const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= ntok) return;
+  const long long bt = tok / J;
+  const int j = (int)(tok % J);
+  const float p0 = pose2d[tok * 2 + 0], p1 = pose2d[tok * 2 + 1];
+  float v[NV];
+#pragma unroll
+  for (int i4 = 0; i4 < NV / 4; ++i4) {
+    const int c = i4 * 256 + lane * 4;
+    const f32x4 e = *reinterpret_cast<const f32x4*>(E + bt * C + c);
+    const f32x4 sp = *reinterpret_cast<const f32x4*>(spos + (long long)j * C + c);
+    const f32x4 bj = *reinterpret_cast<const f32x4*>(bje + c);
+    const f32x4 w01 = *reinterpret_cast<const f32x4*>(Wje + c * 2), w23 = *reinterpret_cast<const f32x4*>(Wje + c * 2 + 4);
+    const float wa[4] = {w01[0], w01[2], w23[0], w23[2]}, wb[4] = {w01[1], w01[3], w23[1], w23[3]};
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // same association as the reference (and as embed_tokens_kernel): (joint_embed(x)) + imgfeat_embed + spatial_pos
+      const float je = wa[i] * p0 + wb[i] * p1 + bj[i];
+      o[i] = (je + e[i]) + sp[i];
+      v[i4 * 4 + i] = o[i];
+    }
+    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(x + tok * C + c));
+  }
+  ln_regs<C>(v, w2, b2, eps2, lane);
+#pragma unroll
+  for (int i4 = 0; i4 < NV / 4; ++i4) {
+    f32x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = v[i4 * 4 + i];
+    if (xn_split) store4_split_f16(xn + tok * C, i4 * 256 + lane * 4, t);
+    else *reinterpret_cast<f32x4*>(xn + tok * C + i4 * 256 + lane * 4) = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // short-sequence multi-head attention (timm Attention == CoevoDecoder.py:118-131), N <= 32 tokens, 8 heads.
 // One workgroup per sequence; K/V of the sequence staged once in LDS; wave w owns heads 2w, 2w+1; lane =
 // (head-in-pair, query).  Online softmax over the <= 32 keys, all in registers; the K/V reads are
@@ -398,7 +447,8 @@ __global__ __launch_bounds__(256) void lifter_head_kernel(const float* __restric
                                                           const float* __restrict__ lnb, const float* __restrict__ Wr,
                                                           const float* __restrict__ br, const float* __restrict__ wf,
                                                           const float* __restrict__ bf, float* __restrict__ pose3d,
-                                                          int B, int T, int J) {
+                                                          int B, int T, int J, const float* __restrict__ prew,
+                                                          const float* __restrict__ preb, float pre_eps) {
   constexpr int NV = C / 64;
   const int lane = threadIdx.x & 63;
   const int bj = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -414,6 +464,7 @@ __global__ __launch_bounds__(256) void lifter_head_kernel(const float* __restric
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i4 * 4 + i] = tt[i];
     }
+    if (prew) ln_regs<C>(v, prew, preb, pre_eps, lane);  // the last block's post-norm (norm_t), when no launch of its own ran it
     ln_regs<C>(v, lnw, lnb, 1e-5f, lane);
     float d0 = 0.f, d1 = 0.f, d2 = 0.f;
 #pragma unroll
@@ -455,6 +506,21 @@ extern "C" int pmce_embed_tokens_f32(const float* pose2d, const float* E, const 
   hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pose2d, E, Wje, bje, spos,
                      x, ntok, J, C);
   return pmce_check_launch("embed_tokens");
+}
+
+// The same followed by LayerNorm(w2, b2, eps2) of every token row in one launch: x = the tokens (fp32), xn = their LayerNorm (pre-split [row][C/16][16 hi |
+// 16 lo*2^11] f16 when xn_split) - pmce_embed_tokens_f32 + pmce_ln_chain_ex_f32(out2) without the round trip of the tokens.  C = 256 or 512.
+extern "C" int pmce_embed_ln_f32(const float* pose2d, const float* E, const float* Wje, const float* bje, const float* spos, float* x,
+                                 long long ntok, int J, int C, const float* w2, const float* b2, float eps2, float* xn, int xn_split,
+                                 hipStream_t stream) {
+  PMCE_REQUIRE(pose2d && E && Wje && bje && spos && x && w2 && b2 && xn, "embed_ln: null pointer");
+  PMCE_REQUIRE((C == 256 || C == 512) && J > 0 && ntok > 0, "embed_ln: C must be 256 or 512, J and ntok positive");
+  const unsigned grid = (unsigned)((ntok + 3) / 4);
+  if (C == 256)
+    hipLaunchKernelGGL((embed_ln_kernel<256>), dim3(grid), dim3(256), 0, stream, pose2d, E, Wje, bje, spos, x, ntok, J, w2, b2, eps2, xn, xn_split);
+  else
+    hipLaunchKernelGGL((embed_ln_kernel<512>), dim3(grid), dim3(256), 0, stream, pose2d, E, Wje, bje, spos, x, ntok, J, w2, b2, eps2, xn, xn_split);
+  return pmce_check_launch("embed_ln");
 }
 
 extern "C" int pmce_ln_chain_ex_f32(const float* x, long long rows, int C, const float* w1, const float* b1, float eps1,
@@ -573,14 +639,22 @@ extern "C" int pmce_seq_attention_f32(const float* qkv, float* out, int nseq, in
   return pmce_seq_attention_ex_f32(qkv, out, nseq, N, C, seq_div, seq_lo, seq_hi, tok_stride, 0, stream);
 }
 
+// prew != null: x holds the LAST TemporalBlock's output BEFORE its post-norm; the rows pass through LayerNorm(prew, preb, pre_eps) (norm_t,
+// PoseEstimation.py:92) on the way in - the head then needs no ln_chain launch (and no 2 x 143 MB round trip at B = 256, C = 512) in front of it.
+extern "C" int pmce_lifter_head_ex_f32(const float* x, const float* prew, const float* preb, float pre_eps, const float* lnw,
+                                       const float* lnb, const float* Wr, const float* br, const float* wf, const float* bf,
+                                       float* pose3d, int B, int T, int J, int C, hipStream_t stream) {
+  PMCE_REQUIRE(C == 256 || C == 512, "lifter_head: C must be 256 or 512");
+  PMCE_REQUIRE((prew == nullptr) == (preb == nullptr), "lifter_head: the pre-norm needs weight and bias");
+  const unsigned grid = (unsigned)((B * J + 3) / 4);
+  if (C == 256)
+    hipLaunchKernelGGL((lifter_head_kernel<256>), dim3(grid), dim3(256), 0, stream, x, lnw, lnb, Wr, br, wf, bf, pose3d, B, T, J, prew, preb, pre_eps);
+  else
+    hipLaunchKernelGGL((lifter_head_kernel<512>), dim3(grid), dim3(256), 0, stream, x, lnw, lnb, Wr, br, wf, bf, pose3d, B, T, J, prew, preb, pre_eps);
+  return pmce_check_launch("lifter_head");
+}
 extern "C" int pmce_lifter_head_f32(const float* x, const float* lnw, const float* lnb, const float* Wr, const float* br,
                                     const float* wf, const float* bf, float* pose3d, int B, int T, int J, int C,
                                     hipStream_t stream) {
-  PMCE_REQUIRE(C == 256 || C == 512, "lifter_head: C must be 256 or 512");
-  const unsigned grid = (unsigned)((B * J + 3) / 4);
-  if (C == 256)
-    hipLaunchKernelGGL((lifter_head_kernel<256>), dim3(grid), dim3(256), 0, stream, x, lnw, lnb, Wr, br, wf, bf, pose3d, B, T, J);
-  else
-    hipLaunchKernelGGL((lifter_head_kernel<512>), dim3(grid), dim3(256), 0, stream, x, lnw, lnb, Wr, br, wf, bf, pose3d, B, T, J);
-  return pmce_check_launch("lifter_head");
+  return pmce_lifter_head_ex_f32(x, nullptr, nullptr, 0.f, lnw, lnb, Wr, br, wf, bf, pose3d, B, T, J, C, stream);
 }

@@ -465,11 +465,9 @@ int lifter_frames(pmce_model* m, const float* pose2d, const float* img_feat, int
   else
     RUN(P_GEMM_LIFTER, lgemm(m, img_feat, m->w.ie_w, m->s_ie, m->w.ie_b, nullptr, w.E,
                             nframes, C, F, F, C, 0, stream));
-  RUN(P_EMBED, pmce_embed_tokens_f32(pose2d, w.E, m->w.je_w, m->w.je_b,
-                                     m->w.spos, w.X, M, J, C, stream));
-  RUN(P_LN, pmce_ln_chain_ex_f32(w.X, M, C, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr,
-                                 m->w.blk[0][0].norm1_w, m->w.blk[0][0].norm1_b, 1e-6f, w.XN, pk(m),
-                                 stream));
+  // tokens + SpatialBlocks[0].norm1 in one pass (the tokens do not travel to HBM and back between the two)
+  RUN(P_EMBED, pmce_embed_ln_f32(pose2d, w.E, m->w.je_w, m->w.je_b, m->w.spos, w.X, M, J, C, m->w.blk[0][0].norm1_w,
+                                 m->w.blk[0][0].norm1_b, 1e-6f, w.XN, pk(m), stream));
   return lifter_block_body(m, 0, 0, M, nframes, 0, w, stream);
 }
 
@@ -497,15 +495,19 @@ int lifter_post_norm(pmce_model* m, int kind, int i, long long M, LifterWs& w, h
 int lifter_rest(pmce_model* m, float* pose3d, int B, LifterWs& w, hipStream_t stream) {
   const int J = m->J, C = m->C;
   const long long M = (long long)B * T * J;
+  bool head_pre = false;
   for (int i = 0; i < m->depth; ++i) {
     for (int kind = (i == 0 ? 1 : 0); kind < 2; ++kind) {  // (SpatialBlocks[0] - the one whose post-norm adds the position embedding - is lifter_frames')
       const PostNorm pn = post_norm_of(m, kind, i);
-      PMCE_TRY(lifter_block_body(m, kind, i, M, B * T, B, w, stream, &pn));
+      // The LAST block's post-norm (norm_t, nothing after it but the head) runs inside the head when it would be a launch of its own
+      // (where the product's epilogue carries it - ln_in_product - it stays there).
+      const bool last = kind == 1 && i + 1 == m->depth;
+      head_pre = last && !ln_in_product(m);
+      PMCE_TRY(lifter_block_body(m, kind, i, M, B * T, B, w, stream, head_pre ? nullptr : &pn));
     }
   }
-  RUN(P_HEAD, pmce_lifter_head_f32(w.X, m->w.reg0_w, m->w.reg0_b,
-                                   m->w.reg1_w, m->w.reg1_b,
-                                   m->w.fus_w, m->w.fus_b, pose3d, B, T, J, C, stream));
+  RUN(P_HEAD, pmce_lifter_head_ex_f32(w.X, head_pre ? m->w.nt_w : nullptr, head_pre ? m->w.nt_b : nullptr, 1e-6f, m->w.reg0_w, m->w.reg0_b,
+                                      m->w.reg1_w, m->w.reg1_b, m->w.fus_w, m->w.fus_b, pose3d, B, T, J, C, stream));
   return PMCE_OK;
 }
 

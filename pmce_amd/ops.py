@@ -162,6 +162,28 @@ def ln_chain(x, w1=None, b1=None, eps1=1e-6, add=None, add_div=1, add_mod=1, wan
     return out1, out2
 
 
+def embed_tokens(pose2d, E, Wje, bje, spos):
+    """Token embedding (PoseEstimation.py:78-81): pose2d [BT, J, 2], E = imgfeat_embed(img_feat) [BT, C] -> tokens [BT * J, C]."""
+    lib = _lib.load()
+    BT, J, _ = pose2d.shape
+    Cc = E.shape[1]
+    x = torch.empty(BT * J, Cc, device=E.device, dtype=torch.float32)
+    _lib.check(lib.pmce_embed_tokens_f32(P(_c(pose2d)), P(_c(E)), P(_c(Wje)), P(_c(bje)), P(_c(spos)), P(x), BT * J, J, Cc, _st()), "embed_tokens")
+    return x
+
+
+def embed_ln(pose2d, E, Wje, bje, spos, w2, b2, eps2=1e-6, xn_split=False):
+    """embed_tokens + LayerNorm(w2, b2) of every row in one launch: (tokens, their LayerNorm - pre-split planes when xn_split)."""
+    lib = _lib.load()
+    BT, J, _ = pose2d.shape
+    Cc = E.shape[1]
+    x = torch.empty(BT * J, Cc, device=E.device, dtype=torch.float32)
+    xn = torch.empty_like(x)
+    _lib.check(lib.pmce_embed_ln_f32(P(_c(pose2d)), P(_c(E)), P(_c(Wje)), P(_c(bje)), P(_c(spos)), P(x), BT * J, J, Cc, P(_c(w2)), P(_c(b2)), eps2,
+                                     P(xn), 1 if xn_split else 0, _st()), "embed_ln")
+    return x, xn
+
+
 def seq_attention(qkv, nseq, N, Cc, seq_div, seq_lo, seq_hi, tok_stride, out_split=False):
     lib = _lib.load()
     qkv = _c(qkv)

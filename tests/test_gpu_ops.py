@@ -965,3 +965,30 @@ def test_gemm_split_layernorm_epilogue(M, K, case):
         if case != "large_mean":     # (there the two fp32 LayerNorm values themselves differ in their low bits: x carries an ulp of 2e-3)
             assert (h != h_two).float().mean().item() < 1e-3
     print()
+
+
+@pytest.mark.parametrize("J,C", [(17, 512), (19, 256)])
+def test_embed_ln_equals_embed_then_ln_chain(J, C):
+    """Round 6: the token embedding and SpatialBlocks[0].norm1 in ONE launch (pmce_embed_ln_f32: the tokens do not travel to HBM and back) against
+    pmce_embed_tokens_f32 followed by pmce_ln_chain_ex_f32 - tokens and LayerNorm bit for bit, fp32 and pre-split output - and against fp64."""
+    from pmce_amd import ops
+    BT = 37
+    pose2d = rnd("emb.p", (BT, J, 2)).to(dev())
+    E = rnd("emb.E", (BT, C)).to(dev())
+    Wje = rnd("emb.W", (C, 2)).to(dev())
+    bje = rnd("emb.b", (C,), scale=0.1).to(dev())
+    spos = rnd("emb.s", (J, C), scale=0.2).to(dev())
+    w2 = (1.0 + rnd("emb.w2", (C,), scale=0.1)).to(dev())
+    b2 = rnd("emb.b2", (C,), scale=0.1).to(dev())
+    x_ref = ops.embed_tokens(pose2d, E, Wje, bje, spos)
+    for split in (False, True):
+        _, xn_ref = ops.ln_chain(x_ref, want_out1=False, w2=w2, b2=b2, eps2=1e-6, out2_split=split)
+        x, xn = ops.embed_ln(pose2d, E, Wje, bje, spos, w2, b2, 1e-6, xn_split=split)
+        assert torch.equal(x, x_ref), f"tokens differ (split={split})"
+        assert torch.equal(xn.view(torch.int32), xn_ref.view(torch.int32)), f"LayerNorm output differs (split={split})"
+    tok = (pose2d.double().reshape(-1, 2) @ Wje.double().T + bje.double()) + E.double().repeat_interleave(J, 0) + spos.double().repeat(BT, 1)
+    ln = torch.nn.functional.layer_norm(tok, (C,), w2.double(), b2.double(), 1e-6)
+    _, xn32 = ops.embed_ln(pose2d, E, Wje, bje, spos, w2, b2, 1e-6, xn_split=False)
+    e = (maxabs(x, tok), maxabs(xn32, ln))
+    print(f"embed_ln J={J} C={C}: tokens vs fp64 {e[0]:.2e}, LayerNorm vs fp64 {e[1]:.2e}; bit-identical to the two-launch form")
+    assert e[0] < 2e-6 and e[1] < 5e-6
