@@ -184,6 +184,18 @@ def embed_ln(pose2d, E, Wje, bje, spos, w2, b2, eps2=1e-6, xn_split=False):
     return x, xn
 
 
+def lifter_head(x, lnw, lnb, Wr, br, wf, bf, B, T, J, pre=None):
+    """Regression head + frame fusion (PoseEstimation.py:62-66,109-113): x [B*T*J, C] -> pose3d [B, J, 3].  pre = (weight, bias, eps): the rows
+    pass through that LayerNorm first (the last block's norm_t folded into the head)."""
+    lib = _lib.load()
+    Cc = x.shape[1]
+    out = torch.empty(B, J, 3, device=x.device, dtype=torch.float32)
+    pw, pb, pe = (_c(pre[0]), _c(pre[1]), float(pre[2])) if pre is not None else (None, None, 0.0)
+    _lib.check(lib.pmce_lifter_head_ex_f32(P(_c(x)), P(pw), P(pb), pe, P(_c(lnw)), P(_c(lnb)), P(_c(Wr)), P(_c(br)), P(_c(wf)), P(_c(bf)), P(out),
+                                           B, T, J, Cc, _st()), "lifter_head")
+    return out
+
+
 def seq_attention(qkv, nseq, N, Cc, seq_div, seq_lo, seq_hi, tok_stride, out_split=False):
     lib = _lib.load()
     qkv = _c(qkv)

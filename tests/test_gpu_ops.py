@@ -992,3 +992,27 @@ def test_embed_ln_equals_embed_then_ln_chain(J, C):
     e = (maxabs(x, tok), maxabs(xn32, ln))
     print(f"embed_ln J={J} C={C}: tokens vs fp64 {e[0]:.2e}, LayerNorm vs fp64 {e[1]:.2e}; bit-identical to the two-launch form")
     assert e[0] < 2e-6 and e[1] < 5e-6
+
+
+@pytest.mark.parametrize("J,C", [(17, 512), (19, 256)])
+def test_lifter_head_with_folded_post_norm(J, C):
+    """Round 6: the last TemporalBlock's post-norm (norm_t) inside the regression head (pmce_lifter_head_ex_f32) against pmce_ln_chain_f32(out1)
+    followed by the plain head - bit for bit - and against an fp64 evaluation of PoseEstimation.py:92,109-113."""
+    from pmce_amd import ops
+    B, T = 3, 16
+    x = rnd("head.x", (B * T * J, C), scale=2.0).to(dev())
+    ntw = (1.0 + rnd("head.ntw", (C,), scale=0.1)).to(dev()); ntb = rnd("head.ntb", (C,), scale=0.1).to(dev())
+    lnw = (1.0 + rnd("head.lnw", (C,), scale=0.1)).to(dev()); lnb = rnd("head.lnb", (C,), scale=0.1).to(dev())
+    Wr = rnd("head.Wr", (3, C), scale=C ** -0.5).to(dev()); br = rnd("head.br", (3,), scale=0.1).to(dev())
+    wf = rnd("head.wf", (T,), scale=0.25).to(dev()); bf = rnd("head.bf", (1,), scale=0.1).to(dev())
+    y, _ = ops.ln_chain(x, ntw, ntb, 1e-6)
+    two = ops.lifter_head(y, lnw, lnb, Wr, br, wf, bf, B, T, J)
+    one = ops.lifter_head(x, lnw, lnb, Wr, br, wf, bf, B, T, J, pre=(ntw, ntb, 1e-6))
+    assert torch.equal(one, two)
+    F = torch.nn.functional
+    y64 = F.layer_norm(x.double(), (C,), ntw.double(), ntb.double(), 1e-6)
+    p = F.layer_norm(y64, (C,), lnw.double(), lnb.double(), 1e-5) @ Wr.double().T + br.double()            # [B*T*J, 3]
+    ref = (p.reshape(B, T, J, 3) * wf.double()[None, :, None, None]).sum(1) + bf.double()
+    e = maxabs(one, ref)
+    print(f"lifter head with norm_t folded in, J={J} C={C}: bit-identical to ln_chain + head; vs fp64 {e:.2e}")
+    assert e < 5e-6
