@@ -89,7 +89,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitParams p) {
   const int chunk_start = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
   const int chunk_len = cq + (xcd < cr ? 1 : 0);
   if (bx >= chunk_len) return;
-  constexpr int GROUP_M = 8;
+  // (8 until round 6, as gemm_f32.hip has it; 4 measures 0.2-0.9 % faster on the lifter's products at C = 512 and, through what they leave in the
+  // caches, 2.5 % on the ln_chain launches between them - equal at C = 256; 16 slower, 2 / 1 mixed: profiles/r06_p_*, r06_q_*)
+  constexpr int GROUP_M = 4;
   const int per_group = GROUP_M * p.ntn;
   auto tile_coords = [&](int bid, int& mb, int& nb) {
     const int group = bid / per_group;

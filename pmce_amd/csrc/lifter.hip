@@ -67,6 +67,37 @@ __device__ __forceinline__ void ln_regs(float* v, const float* __restrict__ w, c
   }
 }
 
+// The same with the weight and bias of this lane's channels already in registers (kernels that normalise several rows per wavefront: fetched
+// per row, the parameters are more vector-cache traffic than the row itself).  The same operations in the same order: the same bits.
+template <int C>
+__device__ __forceinline__ void ln_regs_pre(float* v, const float* wreg, const float* breg, float eps) {
+  constexpr int NV = C / 64;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += v[i];
+  const float mean = wave_sum(s) * (1.0f / C);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float d = v[i] - mean;
+    ss += d * d;
+  }
+  const float var = wave_sum(ss) * (1.0f / C);
+  const float inv = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = (v[i] - mean) * inv * wreg[i] + breg[i];
+}
+// this lane's channels (256 i4 + 4 lane + [0, 4)) of a per-channel vector
+template <int C>
+__device__ __forceinline__ void lane_channels(const float* __restrict__ p, int lane, float* out) {
+#pragma unroll
+  for (int i4 = 0; i4 < C / 256; ++i4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p + i4 * 256 + lane * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i4 * 4 + i] = t[i];
+  }
+}
+
 // Optional window gather (streaming): with win != nullptr, output row (w*T + t)*J + j reads input row
 // frame(w,t)*J + j, frame = win[2w] + t (or win[2w] when win[2w] == win[2w+1]: a single frame repeated).
 template <int C>
@@ -137,46 +168,61 @@ __global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__
 // channels 256 i4 + 4 l + [0, 4) as ln_chain does -, stores it (x: the residual stream) and stores its LayerNorm (xn: the first product's A
 // operand, pre-split when xn_split).  The same operations in the same order as the two kernels: bit-identical.
 // ------------------------------------------------------------------------------------------------------
+// A frame's J tokens are shared by `wpf` wavefronts (wavefront w of the frame takes j = w, w + wpf, ...): the frame's image-feature row, the
+// embedding's per-channel constants and the LayerNorm's parameters are fetched once per WAVEFRONT and serve all its tokens.  Fetched per token
+// (one token per wavefront, as until round 6) they are 14 KB through the vector cache for 4 KB of stores - that, not HBM, bounded the kernel
+// (88 us for 285 MB of stores at B = 256, C = 512).  The launcher picks wpf so that there are enough wavefronts to fill the chip: 2 at
+// B = 256, J (one token per wavefront, the old form) for a single clip.
 template <int C>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__ pose2d, const float* __restrict__ E,
                                                        const float* __restrict__ Wje, const float* __restrict__ bje,
-                                                       const float* __restrict__ spos, float* __restrict__ x, long long ntok, int J,
+                                                       const float* __restrict__ spos, float* __restrict__ x, long long nframes, int J,
                                                        const float* __restrict__ w2, const float* __restrict__ b2, float eps2,
-                                                       float* __restrict__ xn, int xn_split) {
+                                                       float* __restrict__ xn, int xn_split, int wpf) {
   constexpr int NV = C / 64;
   const int lane = threadIdx.x & 63;
-  const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tok >= ntok) return;
-  const long long bt = tok / J;
-  const int j = (int)(tok % J);
-  const float p0 = pose2d[tok * 2 + 0], p1 = pose2d[tok * 2 + 1];
-  float v[NV];
+  const unsigned wid = blockIdx.x * 4u + (threadIdx.x >> 6);  // (ntok < 2^31: 32-bit division)
+  const long long bt = wid / (unsigned)wpf;
+  if (bt >= nframes) return;
+  float e[NV], bj[NV], wa[NV], wb[NV], lw[NV], lb[NV];
+  lane_channels<C>(E + bt * C, lane, e);
+  lane_channels<C>(bje, lane, bj);
+  lane_channels<C>(w2, lane, lw);
+  lane_channels<C>(b2, lane, lb);
 #pragma unroll
   for (int i4 = 0; i4 < NV / 4; ++i4) {
     const int c = i4 * 256 + lane * 4;
-    const f32x4 e = *reinterpret_cast<const f32x4*>(E + bt * C + c);
-    const f32x4 sp = *reinterpret_cast<const f32x4*>(spos + (long long)j * C + c);
-    const f32x4 bj = *reinterpret_cast<const f32x4*>(bje + c);
     const f32x4 w01 = *reinterpret_cast<const f32x4*>(Wje + c * 2), w23 = *reinterpret_cast<const f32x4*>(Wje + c * 2 + 4);
-    const float wa[4] = {w01[0], w01[2], w23[0], w23[2]}, wb[4] = {w01[1], w01[3], w23[1], w23[3]};
-    f32x4 o;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      // same association as the reference (and as embed_tokens_kernel): (joint_embed(x)) + imgfeat_embed + spatial_pos
-      const float je = wa[i] * p0 + wb[i] * p1 + bj[i];
-      o[i] = (je + e[i]) + sp[i];
-      v[i4 * 4 + i] = o[i];
-    }
-    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(x + tok * C + c));
+    wa[i4 * 4 + 0] = w01[0]; wa[i4 * 4 + 1] = w01[2]; wa[i4 * 4 + 2] = w23[0]; wa[i4 * 4 + 3] = w23[2];
+    wb[i4 * 4 + 0] = w01[1]; wb[i4 * 4 + 1] = w01[3]; wb[i4 * 4 + 2] = w23[1]; wb[i4 * 4 + 3] = w23[3];
   }
-  ln_regs<C>(v, w2, b2, eps2, lane);
+  for (int j = (int)(wid % (unsigned)wpf); j < J; j += wpf) {
+    const long long tok = bt * J + j;
+    const float p0 = pose2d[tok * 2 + 0], p1 = pose2d[tok * 2 + 1];
+    float v[NV];
 #pragma unroll
-  for (int i4 = 0; i4 < NV / 4; ++i4) {
-    f32x4 t;
+    for (int i4 = 0; i4 < NV / 4; ++i4) {
+      const int c = i4 * 256 + lane * 4;
+      const f32x4 sp = *reinterpret_cast<const f32x4*>(spos + (long long)j * C + c);
+      f32x4 o;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) t[i] = v[i4 * 4 + i];
-    if (xn_split) store4_split_f16(xn + tok * C, i4 * 256 + lane * 4, t);
-    else *reinterpret_cast<f32x4*>(xn + tok * C + i4 * 256 + lane * 4) = t;
+      for (int i = 0; i < 4; ++i) {
+        // same association as the reference (and as embed_tokens_kernel): (joint_embed(x)) + imgfeat_embed + spatial_pos
+        const float je = wa[i4 * 4 + i] * p0 + wb[i4 * 4 + i] * p1 + bj[i4 * 4 + i];
+        o[i] = (je + e[i4 * 4 + i]) + sp[i];
+        v[i4 * 4 + i] = o[i];
+      }
+      __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(x + tok * C + c));
+    }
+    ln_regs_pre<C>(v, lw, lb, eps2);
+#pragma unroll
+    for (int i4 = 0; i4 < NV / 4; ++i4) {
+      f32x4 t;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[i] = v[i4 * 4 + i];
+      if (xn_split) store4_split_f16(xn + tok * C, i4 * 256 + lane * 4, t);
+      else *reinterpret_cast<f32x4*>(xn + tok * C + i4 * 256 + lane * 4) = t;
+    }
   }
 }
 
@@ -449,50 +495,66 @@ __global__ __launch_bounds__(256) void lifter_head_kernel(const float* __restric
                                                           const float* __restrict__ bf, float* __restrict__ pose3d,
                                                           int B, int T, int J, const float* __restrict__ prew,
                                                           const float* __restrict__ preb, float pre_eps) {
-  constexpr int NV = C / 64;
-  const int lane = threadIdx.x & 63;
-  const int bj = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (bj >= B * J) return;
+  // One WORKGROUP per (b, j); wavefront w takes the frames t = w, w + 4, ... and has FOUR of their rows in flight before it touches the
+  // first (round 6; until then one wavefront walked the T rows one after the other - sixteen dependent row fetches, 17 wavefronts per CU:
+  // 54 us for a 142 MB read).  The per-frame results meet in LDS and are added in the order of t, as the serial loop added them.
+  constexpr int NV = C / 64, RPW = 4;
+  __shared__ float part[64][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bj = blockIdx.x;
   const int b = bj / J, j = bj % J;
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-  for (int t = 0; t < T; ++t) {
-    const float* row = x + ((long long)(b * T + t) * J + j) * C;
-    float v[NV];
+  // every per-channel parameter once per wavefront (fetched per row they are 14 KB through the vector cache for a 2 KB row)
+  float pw[NV], pb[NV], hw[NV], hbv[NV], r0[NV], r1[NV], r2[NV];
+  if (prew) {
+    lane_channels<C>(prew, lane, pw);
+    lane_channels<C>(preb, lane, pb);
+  }
+  lane_channels<C>(lnw, lane, hw);
+  lane_channels<C>(lnb, lane, hbv);
+  lane_channels<C>(Wr, lane, r0);
+  lane_channels<C>(Wr + C, lane, r1);
+  lane_channels<C>(Wr + 2 * C, lane, r2);
+  for (int t0 = 0; t0 < T; t0 += 4 * RPW) {
+    f32x4 raw[RPW][NV / 4];
 #pragma unroll
-    for (int i4 = 0; i4 < NV / 4; ++i4) {
-      const f32x4 tt = *reinterpret_cast<const f32x4*>(row + i4 * 256 + lane * 4);
+    for (int k = 0; k < RPW; ++k) {
+      const int t = min(t0 + wave + 4 * k, T - 1);
+      const float* row = x + ((long long)(b * T + t) * J + j) * C;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i4 * 4 + i] = tt[i];
+      for (int i4 = 0; i4 < NV / 4; ++i4) raw[k][i4] = *reinterpret_cast<const f32x4*>(row + i4 * 256 + lane * 4);
     }
-    if (prew) ln_regs<C>(v, prew, preb, pre_eps, lane);  // the last block's post-norm (norm_t), when no launch of its own ran it
-    ln_regs<C>(v, lnw, lnb, 1e-5f, lane);
-    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
 #pragma unroll
-    for (int i4 = 0; i4 < NV / 4; ++i4) {
-      const int c = i4 * 256 + lane * 4;
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wr + c);
-      const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wr + C + c);
-      const f32x4 w2 = *reinterpret_cast<const f32x4*>(Wr + 2 * C + c);
+    for (int k = 0; k < RPW; ++k) {
+      const int t = t0 + wave + 4 * k;
+      float v[NV];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        d0 += v[i4 * 4 + i] * w0[i];
-        d1 += v[i4 * 4 + i] * w1[i];
-        d2 += v[i4 * 4 + i] * w2[i];
+      for (int i4 = 0; i4 < NV / 4; ++i4)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i4 * 4 + i] = raw[k][i4][i];
+      if (prew) ln_regs_pre<C>(v, pw, pb, pre_eps);  // the last block's post-norm (norm_t), when no launch of its own ran it
+      ln_regs_pre<C>(v, hw, hbv, 1e-5f);
+      float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        d0 += v[i] * r0[i];
+        d1 += v[i] * r1[i];
+        d2 += v[i] * r2[i];
+      }
+      d0 = wave_sum(d0) + br[0];
+      d1 = wave_sum(d1) + br[1];
+      d2 = wave_sum(d2) + br[2];
+      if (lane == 0 && t < T) {
+        part[t][0] = d0;
+        part[t][1] = d1;
+        part[t][2] = d2;
       }
     }
-    d0 = wave_sum(d0) + br[0];
-    d1 = wave_sum(d1) + br[1];
-    d2 = wave_sum(d2) + br[2];
-    const float w = wf[t];
-    acc0 += w * d0;
-    acc1 += w * d1;
-    acc2 += w * d2;
   }
-  if (lane == 0) {
-    float* o = pose3d + (long long)bj * 3;
-    o[0] = acc0 + bf[0];
-    o[1] = acc1 + bf[0];
-    o[2] = acc2 + bf[0];
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) acc += wf[t] * part[t][threadIdx.x];
+    pose3d[(long long)bj * 3 + threadIdx.x] = acc + bf[0];
   }
 }
 
@@ -514,12 +576,17 @@ extern "C" int pmce_embed_ln_f32(const float* pose2d, const float* E, const floa
                                  long long ntok, int J, int C, const float* w2, const float* b2, float eps2, float* xn, int xn_split,
                                  hipStream_t stream) {
   PMCE_REQUIRE(pose2d && E && Wje && bje && spos && x && w2 && b2 && xn, "embed_ln: null pointer");
-  PMCE_REQUIRE((C == 256 || C == 512) && J > 0 && ntok > 0, "embed_ln: C must be 256 or 512, J and ntok positive");
-  const unsigned grid = (unsigned)((ntok + 3) / 4);
+  PMCE_REQUIRE((C == 256 || C == 512) && J > 0 && ntok > 0 && ntok % J == 0 && ntok < (1ll << 31),
+               "embed_ln: C must be 256 or 512, J positive, ntok a positive multiple of J (whole frames) below 2^31");
+  const long long nframes = ntok / J;
+  // wavefronts per frame: enough wavefronts for the chip (8 per SIMD of 256 CUs), as few as that allows
+  long long wpf = (8192 + nframes - 1) / nframes;
+  wpf = wpf < 1 ? 1 : (wpf > J ? J : wpf);
+  const unsigned grid = (unsigned)((nframes * wpf + 3) / 4);
   if (C == 256)
-    hipLaunchKernelGGL((embed_ln_kernel<256>), dim3(grid), dim3(256), 0, stream, pose2d, E, Wje, bje, spos, x, ntok, J, w2, b2, eps2, xn, xn_split);
+    hipLaunchKernelGGL((embed_ln_kernel<256>), dim3(grid), dim3(256), 0, stream, pose2d, E, Wje, bje, spos, x, nframes, J, w2, b2, eps2, xn, xn_split, (int)wpf);
   else
-    hipLaunchKernelGGL((embed_ln_kernel<512>), dim3(grid), dim3(256), 0, stream, pose2d, E, Wje, bje, spos, x, ntok, J, w2, b2, eps2, xn, xn_split);
+    hipLaunchKernelGGL((embed_ln_kernel<512>), dim3(grid), dim3(256), 0, stream, pose2d, E, Wje, bje, spos, x, nframes, J, w2, b2, eps2, xn, xn_split, (int)wpf);
   return pmce_check_launch("embed_ln");
 }
 
@@ -646,11 +713,13 @@ extern "C" int pmce_lifter_head_ex_f32(const float* x, const float* prew, const 
                                        float* pose3d, int B, int T, int J, int C, hipStream_t stream) {
   PMCE_REQUIRE(C == 256 || C == 512, "lifter_head: C must be 256 or 512");
   PMCE_REQUIRE((prew == nullptr) == (preb == nullptr), "lifter_head: the pre-norm needs weight and bias");
-  const unsigned grid = (unsigned)((B * J + 3) / 4);
+  PMCE_REQUIRE(T > 0 && T <= 64, "lifter_head: 1..64 frames per clip");
+  const unsigned grid = (unsigned)(B * J);
+  const unsigned threads = 256u;
   if (C == 256)
-    hipLaunchKernelGGL((lifter_head_kernel<256>), dim3(grid), dim3(256), 0, stream, x, lnw, lnb, Wr, br, wf, bf, pose3d, B, T, J, prew, preb, pre_eps);
+    hipLaunchKernelGGL((lifter_head_kernel<256>), dim3(grid), dim3(threads), 0, stream, x, lnw, lnb, Wr, br, wf, bf, pose3d, B, T, J, prew, preb, pre_eps);
   else
-    hipLaunchKernelGGL((lifter_head_kernel<512>), dim3(grid), dim3(256), 0, stream, x, lnw, lnb, Wr, br, wf, bf, pose3d, B, T, J, prew, preb, pre_eps);
+    hipLaunchKernelGGL((lifter_head_kernel<512>), dim3(grid), dim3(threads), 0, stream, x, lnw, lnb, Wr, br, wf, bf, pose3d, B, T, J, prew, preb, pre_eps);
   return pmce_check_launch("lifter_head");
 }
 extern "C" int pmce_lifter_head_f32(const float* x, const float* lnw, const float* lnb, const float* Wr, const float* br,

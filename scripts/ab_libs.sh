@@ -13,7 +13,7 @@ for C in $widths; do
       AB_C=$C timeout 300 python scripts/microbench/ab_kernels.py $batches 2>>$O/ab.err | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
-keys=('gemm_lifter','ln_chain','seq_attention','gru_step','gemm_gru_in','joint_embed','ca_fold','vertex_ca_mlp','adaln_qkv','vertex_sa','adaln_mlp','tokens_kv','joint_stream','gemm_ada','gemm_final','wall_us','sum_us')
+keys=('gemm_lifter','ln_chain','seq_attention','embed_tokens','lifter_head','gru_step','gemm_gru_in','joint_embed','ca_fold','vertex_ca_mlp','adaln_qkv','vertex_sa','adaln_mlp','tokens_kv','joint_stream','gemm_ada','gemm_final','wall_us','sum_us')
 for b,v in d.items():
     if not b.startswith('B'): continue
     print('$t', 'C=$C', b, ' '.join(f'{k}={v[k]}' for k in keys if k in v))
