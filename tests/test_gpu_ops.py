@@ -967,12 +967,13 @@ def test_gemm_split_layernorm_epilogue(M, K, case):
     print()
 
 
-@pytest.mark.parametrize("J,C", [(17, 512), (19, 256)])
-def test_embed_ln_equals_embed_then_ln_chain(J, C):
+@pytest.mark.parametrize("J,C,BT", [(17, 512, 37), (19, 256, 37), (17, 512, 1700), (17, 256, 5000), (19, 512, 9000)])
+def test_embed_ln_equals_embed_then_ln_chain(J, C, BT):
     """Round 6: the token embedding and SpatialBlocks[0].norm1 in ONE launch (pmce_embed_ln_f32: the tokens do not travel to HBM and back) against
-    pmce_embed_tokens_f32 followed by pmce_ln_chain_ex_f32 - tokens and LayerNorm bit for bit, fp32 and pre-split output - and against fp64."""
+    pmce_embed_tokens_f32 followed by pmce_ln_chain_ex_f32 - tokens and LayerNorm bit for bit, fp32 and pre-split output - and against fp64.
+    The frame counts cover every way the kernel shares a frame's tokens among wavefronts: one token per wavefront (37 frames), 5, 2 and 1
+    wavefronts per frame (1,700 / 5,000 / 9,000 frames; B = 256 clips are 4,096 frames: 2)."""
     from pmce_amd import ops
-    BT = 37
     pose2d = rnd("emb.p", (BT, J, 2)).to(dev())
     E = rnd("emb.E", (BT, C)).to(dev())
     Wje = rnd("emb.W", (C, 2)).to(dev())
