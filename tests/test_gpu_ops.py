@@ -995,12 +995,12 @@ def test_embed_ln_equals_embed_then_ln_chain(J, C, BT):
     assert e[0] < 2e-6 and e[1] < 5e-6
 
 
-@pytest.mark.parametrize("J,C", [(17, 512), (19, 256)])
-def test_lifter_head_with_folded_post_norm(J, C):
+@pytest.mark.parametrize("J,C,T", [(17, 512, 16), (19, 256, 16), (17, 512, 5), (17, 256, 23)])
+def test_lifter_head_with_folded_post_norm(J, C, T):
     """Round 6: the last TemporalBlock's post-norm (norm_t) inside the regression head (pmce_lifter_head_ex_f32) against pmce_ln_chain_f32(out1)
     followed by the plain head - bit for bit - and against an fp64 evaluation of PoseEstimation.py:92,109-113."""
     from pmce_amd import ops
-    B, T = 3, 16
+    B = 3      # (T = 16 is the path's clip length; 5 and 23 frames walk the kernel's partly filled and second group of sixteen rows)
     x = rnd("head.x", (B * T * J, C), scale=2.0).to(dev())
     ntw = (1.0 + rnd("head.ntw", (C,), scale=0.1)).to(dev()); ntb = rnd("head.ntb", (C,), scale=0.1).to(dev())
     lnw = (1.0 + rnd("head.lnw", (C,), scale=0.1)).to(dev()); lnb = rnd("head.lnb", (C,), scale=0.1).to(dev())
