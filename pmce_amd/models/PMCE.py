@@ -106,7 +106,7 @@ class PMCE(HipModuleBase):
     def profile_read(self):
         return self._ensure_packed().profile_read()
 
-    def pipeline(self, depth: int = 2, stagger: bool = True, on_overflow: str = "warn") -> "Pipeline":
+    def pipeline(self, depth: int = 2, stagger: bool = False, on_overflow: str = "warn") -> "Pipeline":
         """Several batches in flight at once on shared weights; see :class:`Pipeline`."""
         return Pipeline(self, depth, stagger, on_overflow)
 
@@ -179,11 +179,14 @@ class Pipeline:
                     t.record_stream(cur)
             return self.outputs
 
-    def __init__(self, model: "PMCE", depth: int = 2, stagger: bool = True, on_overflow: str = "warn"):
+    def __init__(self, model: "PMCE", depth: int = 2, stagger: bool = False, on_overflow: str = "warn"):
         """on_overflow: what :meth:`synchronize` does when a product reported a non-finite value - "warn" (default: name the batches),
         "raise", or "rerun" (compute them again on the fp32 pipe into the same output tensors).  Only "rerun" keeps references to a
         batch's INPUT tensors (the last 4 x depth submits) - the caller must then leave them unmodified until the next synchronize();
-        otherwise the pipeline holds the recent tickets weakly and retains nothing the caller has dropped."""
+        otherwise the pipeline holds the recent tickets weakly and retains nothing the caller has dropped.
+        stagger: start a batch's pose lifter only when the previous batch's has finished (pmce_model_wait_lifter).  The default until round 6;
+        with that round's kernels free-running lanes measure equal at B = 256, C = 512 and faster everywhere else (+1 % at C = 256, +5 % at
+        J = 19 / B = 128, +9 % at B = 64: profiles/r06_v_lanes_staggered_vs_free.txt), so it is off by default."""
         self.stagger, self.prev = stagger, None
         if depth < 1:
             raise ValueError("depth must be >= 1")
