@@ -973,7 +973,7 @@ def compact_record(full: dict, detail_file: str | None) -> dict:
     if cpu and isinstance(cpu.get("sample"), str):
         cpu["sample"] = cpu["sample"][:160]
     cfg = _pick(full.get("config"), ("workload", "global_batch", "seq_len", "joints", "embed_dim", "parallelism", "gemm_mode", "streams",
-                                     "batches_enqueued_ahead"))
+                                     "batches_enqueued_ahead", "lanes"))
     if cfg:
         cfg["workload"] = cfg["workload"][:200]
     others = {}
