@@ -449,7 +449,7 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
         inputs.append((p, f))
 
     depth = 1 if args.single_stream else max(1, args.pipeline_depth)
-    pipe = model.pipeline(depth, stagger=args.stagger).prepare(B) if depth > 1 else None
+    pipe = model.pipeline(depth, stagger=(True if args.stagger else False if args.no_stagger else None)).prepare(B) if depth > 1 else None
     if args.single_stream:
         model.set_concurrency(False)
     k = [0]
@@ -508,7 +508,7 @@ def measure_config(args, dev, rank, world, J, C, B, steps, warmup, windows, full
                       "parallelism": f"clip-sharded dp{world}, weights replicated",
                       "gemm_mode": gemm_mode, "overflow_policy": "report (asynchronous calls; outputs_finite is checked after the timed region)",
                       "streams": 1 if (args.single_stream or (gemm_mode == "split_f16" and not _lib.split_overlap())) else 2 * depth,
-                      "batches_enqueued_ahead": depth, "lanes": "staggered" if (args.stagger and depth > 1) else "free-running",
+                      "batches_enqueued_ahead": depth, "lanes": ("staggered" if pipe.staggers(B) else "free-running") if pipe is not None else "one batch at a time",
                       "distinct_input_batches": NB},
            "ref_equiv_tflops": round(fpc * clips_per_s / 1e12, 2), "outputs_finite": finite,
            "per_rank_clips_s": [round(x, 1) for x in per_rank],
@@ -758,9 +758,9 @@ def main():
     ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="batches in flight (models.PMCE.Pipeline): a step's decoder overlaps the next step's pose lifter; "
                          "1 = strictly one batch at a time")
-    ap.add_argument("--stagger", action="store_true", help="start a batch's lifter when the previous batch's has finished (the default until "
-                                                           "round 6) instead of letting the pipeline lanes run free")
-    ap.add_argument("--no-stagger", action="store_true", help="(the default since round 6; accepted for older command lines)")
+    ap.add_argument("--stagger", action="store_true", help="always start a batch's lifter when the previous batch's has finished (default: the "
+                                                           "pipeline decides from the batch size - staggered from 192 clips on)")
+    ap.add_argument("--no-stagger", action="store_true", help="always let the pipeline lanes run free")
     ap.add_argument("--sustained-seconds", type=float, default=20.0,
                     help="length of the one long window behind the `sustained` record (0 = skip); the C = 256 record runs half of it")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the extra (untimed-for-value) host-fed measurement")
@@ -799,7 +799,7 @@ def main():
                "--windows", str(args.windows), "--batch", str(B), "--joints", str(J),
                "--pipeline-depth", str(args.pipeline_depth), "--no-variant", "--no-host-fed", "--no-latency",
                "--cpu-seconds", str(min(args.cpu_seconds, 8.0)), "--sustained-seconds", str(sus), *extra]
-        cmd += ["--stagger"] if args.stagger else []
+        cmd += ["--stagger"] if args.stagger else ["--no-stagger"] if args.no_stagger else []
         cmd += ["--no-cpu-baseline"] if (args.no_cpu_baseline or not cpu_ok) else []
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
         import tempfile

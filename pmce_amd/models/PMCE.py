@@ -106,7 +106,7 @@ class PMCE(HipModuleBase):
     def profile_read(self):
         return self._ensure_packed().profile_read()
 
-    def pipeline(self, depth: int = 2, stagger: bool = False, on_overflow: str = "warn") -> "Pipeline":
+    def pipeline(self, depth: int = 2, stagger=None, on_overflow: str = "warn") -> "Pipeline":
         """Several batches in flight at once on shared weights; see :class:`Pipeline`."""
         return Pipeline(self, depth, stagger, on_overflow)
 
@@ -179,14 +179,16 @@ class Pipeline:
                     t.record_stream(cur)
             return self.outputs
 
-    def __init__(self, model: "PMCE", depth: int = 2, stagger: bool = False, on_overflow: str = "warn"):
+    def __init__(self, model: "PMCE", depth: int = 2, stagger=None, on_overflow: str = "warn"):
         """on_overflow: what :meth:`synchronize` does when a product reported a non-finite value - "warn" (default: name the batches),
         "raise", or "rerun" (compute them again on the fp32 pipe into the same output tensors).  Only "rerun" keeps references to a
         batch's INPUT tensors (the last 4 x depth submits) - the caller must then leave them unmodified until the next synchronize();
         otherwise the pipeline holds the recent tickets weakly and retains nothing the caller has dropped.
-        stagger: start a batch's pose lifter only when the previous batch's has finished (pmce_model_wait_lifter).  The default until round 6;
-        with that round's kernels free-running lanes measure equal at B = 256, C = 512 and faster everywhere else (+1 % at C = 256, +5 % at
-        J = 19 / B = 128, +9 % at B = 64: profiles/r06_v_lanes_staggered_vs_free.txt), so it is off by default."""
+        stagger: start a batch's pose lifter only when the previous batch's has finished (pmce_model_wait_lifter), so that it is lifter(k+1)
+        that runs beside decoder(k).  None (default) decides per submit from the batch size (:meth:`staggers`): free-running lanes are faster for
+        small and medium batches (+9 % at B = 64, +5 % at J = 19 / B = 128), staggered ones when a large batch shares the GPU with other streams
+        (B = 256: equal back to back, +8 % through the evaluation harness with its metric kernels, +2.6 % host-fed:
+        profiles/r06_v_lanes_staggered_vs_free.txt).  True / False force one form."""
         self.stagger, self.prev = stagger, None
         if depth < 1:
             raise ValueError("depth must be >= 1")
@@ -199,6 +201,12 @@ class Pipeline:
         self._recent = collections.deque(maxlen=4 * depth)   # tickets a drain can still check (weak references unless on_overflow == "rerun")
         self.reran = []                                       # indices of batches a drain re-ran on the fp32 pipe
         self._bind()
+
+    STAGGER_FROM_BATCH = 192
+
+    def staggers(self, batch: int) -> bool:
+        """Whether a submit of ``batch`` clips waits for the previous batch's lifter."""
+        return bool(self.stagger) if self.stagger is not None else batch >= Pipeline.STAGGER_FROM_BATCH
 
     def _bind(self):
         """(Re)build the lanes on the model's current packed weights (they are re-packed after load_state_dict / .to())."""
@@ -226,7 +234,7 @@ class Pipeline:
         ready = torch.cuda.Event()
         ready.record(cur)                      # inputs produced on the caller's stream
         st.wait_event(ready)
-        if self.stagger and self.prev is not None and self.prev is not self.engines[lane]:
+        if self.staggers(pose2d.shape[0]) and self.prev is not None and self.prev is not self.engines[lane]:
             # start this batch's pose lifter when the previous batch's has finished: lifter(k+1) overlaps decoder(k)
             _lib.check(self.engines[lane].lib.pmce_model_wait_lifter(self.prev.handle, C.c_void_p(st.cuda_stream)), "model_wait_lifter")
         self.prev = self.engines[lane]

@@ -48,6 +48,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--clips", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--stagger", action="store_true", help="start a batch's lifter when the previous batch's has finished (Pipeline(stagger=True))")
     ap.add_argument("--joints", type=int, default=19)          # 3DPW uses COCO input: J = 19 (PW3D/dataset.py:42,54-55)
     ap.add_argument("--seq-len", type=int, default=500, help="clips per synthetic sequence (for the acceleration error)")
     ap.add_argument("--data-dir", default=None, help="directory holding the reference's 3DPW files (3DPW_latest_<split>.json, ...): "
@@ -130,7 +131,7 @@ def main():
         model.set_overflow_policy("report")                                    # asynchronous calls; the word is polled once per pass
         pipe = None
     else:
-        pipe = model.pipeline(2).prepare(args.batch)
+        pipe = model.pipeline(2, stagger=(True if args.stagger else None)).prepare(args.batch)
 
     def joints_gt(pred_mm, b0):
         if gt_joints is not None:
