@@ -169,6 +169,16 @@ def test_stream_bench_script():
     assert r and r["kernel"] and 0 < r["frac"] < 1 and "gemm_lifter" in got["kernel_ms_per_window_batch"]
 
 
+def test_soak_script_is_deterministic_across_lanes_and_batch_sizes():
+    """scripts/soak.py, a few seconds of it: forwards of changing batch sizes through the two pipeline lanes and through direct calls - every
+    result bit-identical to the first one of its batch size, clip 0's mesh the same bits at every batch size (the round's 90-second run:
+    22,731 forwards, 2.0 M clips, profiles/r06_y_soak.txt)."""
+    got = _run_script("soak.py", ["--seconds", "6", "--embed-dim", "256", "--batches", "1,3,16,64,200"])
+    assert got["forwards"] > 50 and len(got["per_batch"]) == 5
+    assert got["bit_mismatches"] == 0 and got["nonfinite_results"] == 0 and not got["overflow_word"]
+    assert got["mesh_of_clip_0_max_abs_across_batch_sizes_m"] == 0.0
+
+
 def test_decoder_bench_script():
     got = _run_script("decoder_bench.py", ["--batch", "64", "--steps", "10", "--min-seconds", "1"])
     assert got["passes"] >= 3 and got["sustained"]["seconds"] >= 1.0 and got["clips_per_s_min_max"][0] <= got["clips_per_s"] <= got["clips_per_s_min_max"][1]
