@@ -80,7 +80,9 @@ __device__ __forceinline__ unsigned split_pack_exchange(float x, unsigned perm_s
   typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
   const _Float16 h = (_Float16)x;
   bad = bad || __builtin_amdgcn_classh(h, 0x207);  // inf / nan: also a finite x beyond f16's 65504 - the next product could not read it
-  const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
+  // (x - h) * 2^11 as ONE fused multiply-add on the f16 itself (v_fma_mix: no separate conversion and subtraction): x - h and the products by
+  // 2^11 are exact in fp32, so the fused form has the bits of the three-instruction form
+  const _Float16 l = (_Float16)fmaf((float)h, -2048.0f, x * 2048.0f);
   const unsigned w = __builtin_bit_cast(unsigned, h2_t{h, l});
   const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);  // lane ^ 1
   return __builtin_amdgcn_perm(nbr, w, perm_sel);

@@ -42,6 +42,19 @@
 
 namespace {
 
+// lo plane of x given hi = rne16(x): rne16((x - hi) * 2^11), written as ONE fused multiply-add on the f16 itself (v_fma_mix_f32: no separate
+// f16 -> f32 conversion, no separate subtraction).  x - hi is exact in fp32 (hi is x rounded to 11 bits), so is every product by 2^11, so
+// the fused form has the same bits as the three-instruction form - the kernel is bound by vector issue (980 vector instructions per head and
+// unit against 24 matrix instructions, 66 % of its time by the PMC counts), and the splits are a third of them.
+__device__ __forceinline__ _Float16 lo_plane(float x, _Float16 hi) { return (_Float16)fmaf((float)hi, -2048.0f, x * 2048.0f); }
+__device__ __forceinline__ void split8_fused(const f32x4& x0, const f32x4& x1, f16x8& hi, f16x8& lo) {
+  const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) hi[e] = (_Float16)v[e];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) lo[e] = lo_plane(v[e], hi[e]);
+}
+
 template <int HD, int N>
 struct AttnCfg {
   static constexpr int C = 8 * HD;
@@ -122,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void seq_attention_mfma_kernel(const float*
     __syncthreads();  // every wave's rows of unit `it` are in LDS; every wave is done with the other slot
     f16x8 qh[QL / 2], ql[QL / 2];
 #pragma unroll
-    for (int i = 0; i < QL / 2; ++i) split8(qraw[2 * i], qraw[2 * i + 1], qh[i], ql[i]);
+    for (int i = 0; i < QL / 2; ++i) split8_fused(qraw[2 * i], qraw[2 * i + 1], qh[i], ql[i]);
     if (it + 1 < nmine) {
       load_q(it + 1, qraw);
       issue(it + 1, slot ^ 1);
@@ -146,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void seq_attention_mfma_kernel(const float*
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           xh[e] = (_Float16)x[i][e];
-          xl[e] = (_Float16)((x[i][e] - (float)xh[e]) * 2048.0f);
+          xl[e] = lo_plane(x[i][e], xh[e]);
         }
         // 16 consecutive lanes (a ds_write_b64 service group) hold one row's four groups: groups 0, 1 write hi first and groups 2, 3
         // lo first, so that the 16 eight-byte stores of an instruction fall on 16 different bank pairs (hi and lo areas of groups g
@@ -223,7 +236,16 @@ __global__ __launch_bounds__(256, 2) void seq_attention_mfma_kernel(const float*
       }
       sum += __shfl_xor(sum, 32);
       const float inv = 1.0f / sum;
-      // ---- out^T = V^T P^T, one 32-channel block at a time ----
+      // ---- out^T = V^T P^T, one 32-channel block at a time; P split ONCE for the head (it was split again for every block) ----
+      f16x8 ph[Cfg::PSTEPS], pl[Cfg::PSTEPS];
+#pragma unroll
+      for (int s = 0; s < Cfg::PSTEPS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float pv32 = pinned(p[8 * s + e]);
+          ph[s][e] = (_Float16)pv32;
+          pl[s][e] = lo_plane(pv32, ph[s][e]);
+        }
 #pragma unroll
       for (int blk = 0; blk < Cfg::DBLK; ++blk) {
         f32x16 o_main, o_cross;
@@ -231,16 +253,9 @@ __global__ __launch_bounds__(256, 2) void seq_attention_mfma_kernel(const float*
         for (int r = 0; r < 16; ++r) o_main[r] = o_cross[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < Cfg::PSTEPS; ++s) {
-          f16x8 ph, pl;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float pv32 = pinned(p[8 * s + e]);
-            ph[e] = (_Float16)pv32;
-            pl[e] = (_Float16)((pv32 - (float)ph[e]) * 2048.0f);
-          }
-          o_main = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[blk][s], ph, o_main, 0, 0, 0);
-          o_cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[blk][s], pl, o_cross, 0, 0, 0);
-          o_cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[blk][s], ph, o_cross, 0, 0, 0);
+          o_main = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[blk][s], ph[s], o_main, 0, 0, 0);
+          o_cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[blk][s], pl[s], o_cross, 0, 0, 0);
+          o_cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[blk][s], ph[s], o_cross, 0, 0, 0);
         }
         // register r is channel 32 blk + 4 hb + (r & 3) + 8 (r >> 2) of query l31: four consecutive channels per r >> 2, written
         // pre-split into this head's bytes of the (dead) K row of that query
@@ -254,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void seq_attention_mfma_kernel(const float*
               const float v = pinned(fmaf(o_cross[4 * rq + e], two_m11, o_main[4 * rq + e]) * inv);
               bad = bad || nonfinite(v);
               oh[e] = (_Float16)v;
-              ol[e] = (_Float16)((v - (float)oh[e]) * 2048.0f);
+              ol[e] = lo_plane(v, oh[e]);
             }
             const int g16 = 2 * blk + (rq >> 1), idx = 8 * (rq & 1) + 4 * hb;
             *reinterpret_cast<f16x4*>(po + g16 * 64 + idx * 2) = oh;
