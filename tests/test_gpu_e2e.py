@@ -310,6 +310,29 @@ def test_pipeline_matches_direct_forward():
     pipe.synchronize()
 
 
+@pytest.mark.parametrize("stagger", [None, True, False])
+def test_pipeline_lane_forms_give_the_same_bits(stagger):
+    """Pipeline(stagger=...): staggered lanes (a batch's lifter waits for the previous batch's), free-running lanes and the default (decided per
+    submit from the batch size: staggered from 192 clips on, round 6) all return the direct forward's bits - also when batches of both kinds
+    alternate through the same lanes."""
+    from pmce_amd import synth
+    from pmce_amd.models.PMCE import Pipeline
+    J, C = 17, 256
+    model = get_model(J, C)
+    pipe = model.pipeline(depth=2, stagger=stagger)
+    assert pipe.staggers(256) == (True if stagger is None else stagger) and pipe.staggers(8) == (False if stagger is None else stagger)
+    assert Pipeline.STAGGER_FROM_BATCH == 192
+    sizes = [5, 200, 3, 192, 191]
+    batches = [synth.make_inputs(b, J, 40 + k) for k, b in enumerate(sizes)]
+    dev_batches = [(T(p).to(dev()), T(f).to(dev())) for p, f in batches]
+    tickets = [pipe.submit(p, f) for p, f in dev_batches]
+    for (p, f), t in zip(dev_batches, tickets):
+        ref = model.forward_with_joints(p, f)
+        for a, b in zip(t.result(), ref):
+            assert torch.equal(a, b)
+    assert not pipe.synchronize()
+
+
 def test_pipeline_lanes_share_packed_weights_and_split_batches():
     """Pipeline lanes in split_f16 mode: (1) batches large enough for the three-product f16 form come out bit-identical to direct
     forwards (the lanes overlap on their own streams); (2) a lane does not pack its own copy of the f16 weight planes (0.5 GB at
