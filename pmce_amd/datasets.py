@@ -20,6 +20,9 @@ the 'human36' input joint set of config/test_mesh_h36m.yml): per-subject annotat
 feature database walked with each video's start index, the CPN detections, every second frame, the reference's drops (one sequence by name,
 empty bounding boxes), world -> camera -> pixel projection of the annotated joints.  The 'coco' joint set of the training configs (NeuralAnnot
 COCO joints + noise files) is not restated.
+
+``load_mpii3d`` reads the MPI-INF-3DHP validation files of ``data/MPII3D/dataset.py:249-292`` (config/test_mesh_mpii3d.yml): the joblib
+database and the ViTPose detections; the training split (NeuralAnnot SMPL fits, camera files) is not restated.
 """
 from __future__ import annotations
 
@@ -250,6 +253,47 @@ def load_h36m(data_path: str, split: str = "test", protocol: int = 2, sampling_r
               "trans": np.asarray([r[7]["trans"] if r[7] else z3 for r in rows], np.float32), "gender": np.array(["neutral"] * len(rows))},
         skipped=skipped, joints_name=H36M_JOINTS, extra_joints=0, mid_valid=valid, cam_idxs=col(6, np.int64),
         extras={"bboxs": col(5), "cam_focals": col(8), "cam_princpts": col(9), "cam_Rs": col(10), "cam_ts": col(11)})
+
+
+# The 17 MPI-INF-3DHP test joints (lib/_kp_utils.py:46-65) as rows of the database's 49-joint SPIN order (:212-263), ``convert_kps(joints3D,
+# "spin", "mpii3d_test")`` (data/MPII3D/dataset.py:270): headtop, neck, r/l shoulder-elbow-wrist, r/l hip-knee-ankle, hip, Spine (H36M), Head (H36M)
+MPII3D_FROM_SPIN = (38, 37, 33, 32, 31, 34, 35, 36, 27, 26, 25, 28, 29, 30, 39, 41, 43)
+# ... which the dataset names ('Head', 'Neck', 'R_Shoulder', ..., 'L_Ankle', 'Pelvis', 'Torso', 'Nose') (dataset.py:36-39), re-ordered into the
+# Human3.6M joint set by ``transform_joint_to_other_db`` (:271; lib/aug_utils.py:10-21): H36M_JOINTS[k] = mpii3d joint MPII3D_TO_H36M[k]
+MPII3D_TO_H36M = (14, 8, 9, 10, 11, 12, 13, 15, 1, 16, 0, 5, 6, 7, 2, 3, 4)
+
+
+def load_mpii3d(data_path: str, split: str = "val") -> FrameTable:
+    """What ``MPII3D.load_data_val`` reads (data/MPII3D/dataset.py:249-292; the validation split is the reference's test split, :24-25): the
+    joblib database ``mpii3d_<split>_scale12_db.pt`` (image names, 2048-d features, 49 SPIN joints in metres) and the ViTPose output
+    ``vitpose_mpii3d_<split>_output.json`` - sorted by image name; joints as the reference makes them (17 test joints -> Human3.6M order,
+    fp32, x 1000 mm); every image 2048 x 2048.  The model input is the COCO set of 19 (config/test_mesh_mpii3d.yml: pelvis and neck appended
+    by ``FrameTable.pose2d``), the windows are ``FrameTable.windows`` (``split_into_chunks_pose``, :103: no frame is filtered), the target of
+    ``MPII3D.evaluate`` is ``FrameTable.gt_joints_root_relative`` (:482-484, 501)."""
+    db_file = osp.join(data_path, f"mpii3d_{split}_scale12_db.pt")
+    vit_file = osp.join(data_path, f"vitpose_mpii3d_{split}_output.json")
+    missing = [p for p in (db_file, vit_file) if not osp.exists(p)]
+    if missing:
+        raise FileNotFoundError("MPI-INF-3DHP files missing under %s: %s" % (data_path, ", ".join(osp.basename(p) for p in missing)))
+    import joblib
+    db = joblib.load(db_file)
+    det = {str(item["image_name"]): np.asarray(item["keypoints"], dtype=np.float32)[:, :3] for item in json.load(open(vit_file))}
+    names = [str(n) for n in db["img_name"]]
+    absent = [n for n in names if n not in det]
+    if absent:
+        raise ValueError(f"vitpose_mpii3d_{split}_output.json holds no detection for {len(absent)} image(s), first: {absent[0]}")
+    j49 = np.asarray(db["joints3D"])
+    # convert_kps copies the rows into a float64 table, transform_joint_to_other_db into a float32 one; the factor 1000 acts on the fp32 values
+    joints = np.asarray(j49[:, MPII3D_FROM_SPIN, :3], dtype=np.float64)[:, MPII3D_TO_H36M].astype(np.float32) * 1000
+    img_paths = np.array(names)
+    perm = np.argsort(img_paths)
+    img_paths = img_paths[perm]
+    n = len(img_paths)
+    return FrameTable(
+        name=f"MPI-INF-3DHP {split}", img_paths=img_paths, vid_names=np.array([p[:-11] for p in img_paths]),
+        img_shapes=np.full((n, 2), 2048, dtype=np.int32), keypoints=np.stack([det[p] for p in img_paths]).astype(np.float32),
+        features=np.asarray(db["features"], dtype=np.float32)[perm], joints_cam_h36m=np.ascontiguousarray(joints[perm], dtype=np.float32),
+        joints_cam_coco=np.zeros((n, 19, 3), np.float32), gt_joints_img_coco=np.zeros((n, 19, 3), np.float32))
 
 
 def window_frames(win: np.ndarray, seqlen: int = 16) -> np.ndarray:

@@ -10,11 +10,13 @@ that are uploaded ONCE and windowed on the device.
     python scripts/eval_sharded.py --dataset h36m --data-dir /data/Human36M/h36m_data [--checkpoint mesh_h36m.pth.tar]
     python scripts/eval_sharded.py --lifter-only [--joints 17|19] [--data-dir ...]     # config/test_pose_{h36m,3dpw}.yml: LiftTester.test
     python scripts/eval_sharded.py --flavour mpii3d                                    # config/test_mesh_mpii3d.yml: joints only, all 17
+    python scripts/eval_sharded.py --dataset mpii3d --data-dir /data/MPII3D/mpii3d_data  # the same on the reference's validation files
 
 --lifter-only runs the temporal pose encoder alone (models.PoseEstimation, reference lib/core/base.py:342-387) and evaluates its joints with
 ``Evaluator.evaluate_joint`` - the Human3.6M flavour (17 joints, root 0, the 14 evaluation joints, camera-4 samples) or the 3DPW flavour (COCO
 set of 19, root = Pelvis, every joint); --flavour mpii3d evaluates the joints regressed from the predicted mesh against joint targets the way
-MPII3D.evaluate does (data/MPII3D/dataset.py:560-624; synthetic stand-in only: the MPI-INF-3DHP reader is not restated).
+MPII3D.evaluate does (data/MPII3D/dataset.py:560-624) - on the synthetic stand-in, or with --dataset mpii3d --data-dir DIR on the reference's
+MPI-INF-3DHP validation files (the joblib database + ViTPose output of MPII3D.load_data_val, :249-292; pmce_amd.datasets.load_mpii3d).
 
 Every rank owns a contiguous block of the clip range (weights replicated), runs the HIP forward in batches, computes the
 per-sample metrics on the device (pmce_amd.eval) against a synthetic ground truth, and the ranks meet in ONE reduction
@@ -53,7 +55,7 @@ def main():
     ap.add_argument("--seq-len", type=int, default=500, help="clips per synthetic sequence (for the acceleration error)")
     ap.add_argument("--data-dir", default=None, help="directory holding the reference's 3DPW files (3DPW_latest_<split>.json, ...): "
                                                      "evaluate the real stride-1 window list instead of the synthetic stand-in")
-    ap.add_argument("--dataset", default="pw3d", choices=("pw3d", "h36m"), help="format of --data-dir: the reference's 3DPW files (J = 19) or its "
+    ap.add_argument("--dataset", default="pw3d", choices=("pw3d", "h36m", "mpii3d"), help="format of --data-dir: the reference's 3DPW files (J = 19) or its "
                                                                               "Human3.6M files (J = 17; the windows of camera 4, as Human36M.evaluate keeps them)")
     ap.add_argument("--split", default="test")
     ap.add_argument("--checkpoint", default=None, help="a reference mesh_*.pth.tar / pose_*.pth.tar (default: deterministic synthetic weights)")
@@ -62,9 +64,11 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=0.0, help="repeat the whole evaluation until this much time has passed; the rate is the "
                                                                    "median pass, the spread is reported (a single pass is 0.7 s at 35 k clips)")
     args = ap.parse_args()
+    if args.data_dir and args.dataset == "mpii3d":      # the reference's MPI-INF-3DHP validation files: config/test_mesh_mpii3d.yml
+        args.flavour = "mpii3d"
     if args.flavour == "mpii3d":
-        if args.lifter_only or args.data_dir:
-            ap.error("--flavour mpii3d runs the full model on the synthetic stand-in")
+        if args.lifter_only or (args.data_dir and args.dataset != "mpii3d"):
+            ap.error("--flavour mpii3d runs the full model, on the synthetic stand-in or on --dataset mpii3d --data-dir DIR")
         args.joints = 17
     from pmce_amd import models, sharding, synth
     from pmce_amd.eval import Evaluator
@@ -72,11 +76,14 @@ def main():
     if args.data_dir:
         from pmce_amd import datasets
         # every rank parses the (host-side) files; the GPU work is sharded
-        table = datasets.load_pw3d(args.data_dir, args.split) if args.dataset == "pw3d" else datasets.load_h36m(args.data_dir, args.split)
+        if args.dataset == "mpii3d":       # (the reference maps its 'test' split to the files' 'val', data/MPII3D/dataset.py:24-25)
+            table = datasets.load_mpii3d(args.data_dir, "val" if args.split == "test" else args.split)
+        else:
+            table = datasets.load_pw3d(args.data_dir, args.split) if args.dataset == "pw3d" else datasets.load_h36m(args.data_dir, args.split)
         win = table.pose_windows(16, 1) if args.lifter_only else table.windows(16, 1)
         if args.dataset == "h36m":                                      # Human36M.evaluate skips every sample whose middle frame is not camera 4
             win = win[table.cam_idxs[datasets.window_mid(win)] == 4]               # (data/Human36M/dataset.py:742-744): they are not run at all here
-        args.clips, args.joints = len(win), 19 if args.dataset == "pw3d" else 17
+        args.clips, args.joints = len(win), 17 if args.dataset == "h36m" else 19      # (3DPW and MPI-INF-3DHP feed the COCO set of 19)
     rank, local, world = sharding.init_from_env()
     if os.environ.get("PMCE_BENCH_SHARE_GPU"):      # plumbing runs of the N > 1 path on a box with fewer GPUs (ranks share devices)
         local = local % max(torch.cuda.device_count(), 1)

@@ -130,3 +130,53 @@ def test_h36m_inconsistent_files_are_refused(tmp_path):
     json.dump(det, open(f, "w"))
     with pytest.raises(ValueError, match="no CPN detection"):
         datasets.load_h36m(path)
+
+
+# ---- MPI-INF-3DHP (config/test_mesh_mpii3d.yml) ---------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def mpii3d_table(tmp_path_factory):
+    import mpii3d_files
+    from pmce_amd import datasets
+    root = str(tmp_path_factory.mktemp("mpii3d"))
+    return datasets.load_mpii3d(mpii3d_files.write(root), "val")
+
+
+def test_mpii3d_tables_windows_and_model_inputs_equal_the_reference_loader(mpii3d_table):
+    """pmce_amd.datasets.load_mpii3d against the reference's own ``MPII3D('test')`` (data/MPII3D/dataset.py:249-292,467-517) on the synthetic
+    directory of tests/golden/mpii3d_files.py (fixture: make_golden_datasets_mpii3d.py): rows sorted by image name, the 49 SPIN joints as
+    Human3.6M joints in millimetres bit for bit (convert_kps + transform_joint_to_other_db), 2048 x 2048 images, ``vid_indices``
+    (split_into_chunks_pose with the VIBE tail rule; the 11-frame video gives no window) and, for sampled windows, what ``__getitem__`` hands
+    the model and the joint target."""
+    from oracle import staging_oracle as S
+    from pmce_amd import datasets
+    t = mpii3d_table
+    g = np.load(osp.join(HERE, "golden", "datasets_mpii3d.npz"))
+    assert len(t) == 101 and list(t.img_paths) == list(g["img_paths"]) and np.array_equal(t.img_shapes, g["img_shapes"])
+    assert np.array_equal(t.features[:, ::64], g["features_sub"]) and np.array_equal(t.joints_cam_h36m, g["joints_cam"])
+    ext = np.stack([S.add_pelvis_and_neck(k) for k in t.keypoints])
+    assert np.array_equal(ext, g["pred_pose2ds"])
+    win = t.windows(16, 1)
+    assert np.array_equal(win, g["vid_indices"]) and len(win) == int(g["n_items"]) == 50
+    pose2d = np.stack([np.asarray(S.normalize_screen_coordinates(ext[i][:, :2], w=2048, h=2048), dtype=np.float32) for i in range(len(t))])
+    gt = t.gt_joints_root_relative()
+    frames = datasets.window_frames(win)
+    for k in g["sample_windows"]:
+        idx = frames[k]
+        assert np.array_equal(pose2d[idx], g[f"item{k}_pose2d"])
+        assert np.array_equal(t.features[idx][:, ::64], g[f"item{k}_img_feature_sub"])
+        assert np.array_equal(gt[idx[8]], g[f"item{k}_reg_pose3d"])
+    seq = t.sequence_ids()
+    assert len(np.unique(seq)) == 3 and np.all(np.diff(seq) >= 0)
+
+
+def test_mpii3d_missing_files_and_detections_are_named(tmp_path):
+    import json
+    import mpii3d_files
+    from pmce_amd import datasets
+    with pytest.raises(FileNotFoundError, match="mpii3d_val_scale12_db.pt"):
+        datasets.load_mpii3d(str(tmp_path))
+    path = mpii3d_files.write(str(tmp_path))
+    vit = json.load(open(osp.join(path, "vitpose_mpii3d_val_output.json")))
+    json.dump(vit[1:], open(osp.join(path, "vitpose_mpii3d_val_output.json"), "w"))
+    with pytest.raises(ValueError, match="no detection for 1 image"):
+        datasets.load_mpii3d(path)

@@ -169,6 +169,40 @@ def test_stream_bench_script():
     assert r and r["kernel"] and 0 < r["frac"] < 1 and "gemm_lifter" in got["kernel_ms_per_window_batch"]
 
 
+def test_eval_sharded_script_on_mpii3d_format_files(tmp_path):
+    """`eval_sharded.py --dataset mpii3d --data-dir` on a directory in the reference's MPI-INF-3DHP validation file formats
+    (tests/golden/mpii3d_files.py; the reader is pinned against the reference's own ``MPII3D`` class in tests/test_datasets_host.py): two ranks,
+    the stride-1 window list of split_into_chunks_pose (50 windows of 2 videos - the third is shorter than a clip), COCO-19 input, the joints
+    regressed from the predicted mesh against the annotated joints, all 17, root 0 (config/test_mesh_mpii3d.yml, MPII3D.evaluate) - against
+    the metrics oracle on predictions recomputed unsharded here from host-assembled windows."""
+    from oracle import metrics_oracle as MO
+    from oracle import staging_oracle as S
+    from pmce_amd import assets, datasets, models, synth
+    sys.path.insert(0, osp.join(HERE, "golden"))
+    import mpii3d_files
+    path = mpii3d_files.write(str(tmp_path))
+    got = _run_script("eval_sharded.py", ["--dataset", "mpii3d", "--data-dir", path, "--batch", "16"], world=2)
+    table = datasets.load_mpii3d(path)
+    win = table.windows()
+    assert got["n_gpus"] == 2 and got["samples"] == len(win) == 50 and got["J"] == 19 and got["flavour"] == "mpii3d"
+    assert got["MPVPE"] is None and "MPI-INF-3DHP val" in got["data"]
+    assets.allow_synthetic_base_data()
+    dev = torch.device("cuda:0")
+    model = models.PMCE.get_model(19, 256, 3)
+    model.load_state_dict(synth.make_state_dict(synth.pmce_spec(19, 256, 3), seed=123))
+    model.set_j_regressor(assets.load_j_regressor("h36m"))
+    model = model.to(dev)
+    ext = np.stack([S.add_pelvis_and_neck(k) for k in table.keypoints])
+    pose2d = np.stack([np.asarray(S.normalize_screen_coordinates(ext[i][:, :2], w=2048, h=2048), dtype=np.float32) for i in range(len(table))])
+    fr = datasets.window_frames(win)
+    pj = model.forward_with_joints(torch.from_numpy(pose2d[fr]).to(dev), torch.from_numpy(table.features[fr]).to(dev))[3]
+    mid = datasets.window_mid(win)
+    ref = MO.evaluate_joint_samples(pj.double().cpu().numpy(), table.gt_joints_root_relative()[mid].astype(np.float64), table.sequence_ids()[mid], 0, None)
+    print("2 ranks:", {k: got[k] for k in ("MPJPE", "PA-MPJPE", "ACCEL")}, "\noracle :", {k: ref[k] for k in ("MPJPE", "PA_MPJPE", "ACCEL")})
+    for k, r in (("MPJPE", "MPJPE"), ("PA-MPJPE", "PA_MPJPE"), ("ACCEL", "ACCEL")):
+        assert abs(got[k] - ref[r]) < 2e-3 * max(1.0, abs(ref[r]) / 100), (k, got[k], ref[r])
+
+
 def test_soak_script_is_deterministic_across_lanes_and_batch_sizes():
     """scripts/soak.py, a few seconds of it: forwards of changing batch sizes through the two pipeline lanes and through direct calls - every
     result bit-identical to the first one of its batch size, clip 0's mesh the same bits at every batch size (the round's 90-second run:
